@@ -1,0 +1,153 @@
+/*
+ * plx.h -- C ABI of the MI355X permutohedral-lattice filter (libplx.so).
+ *
+ * This is the drop-in boundary for the reference's one native entry point,
+ *
+ *     filter(src[N,vd], ref[N,d], coeffs[R]) -> out[N,vd]
+ *         gpytorch_lattice_kernel/cpp/lattice.cpp:6-16            (CPU)
+ *         gpytorch_lattice_kernel/cuda/permutohedral_cuda.cpp:12-22 (CUDA)
+ *
+ * restated as plain pointers and sizes (no torch types), plus the staged form
+ * the reference fuses into that call (PermutohedralLattice ctor + splat, blur,
+ * slice: cpp/permutohedral.h:346-392, 395-486, 513-572, 497-510), so that one
+ * lattice can serve every MVM on the same inputs (all conjugate-gradient
+ * iterations, the backward pass) and so that a sharded job can put one RCCL
+ * all-reduce between splat and blur.
+ *
+ * Conventions
+ *   - every data pointer is DEVICE memory (fp32, row-major, contiguous) on the
+ *     lattice's device unless the name starts with h_ (host);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued on it.  plx_build() synchronises that stream once (it
+ *     must learn the vertex count m to size the lattice); plx_splat / plx_blur /
+ *     plx_slice / plx_apply never synchronise and never allocate once their
+ *     workspace has reached its high-water mark, so they are graph-capturable;
+ *   - every function returns PLX_OK (0) or an error code; nothing calls exit()
+ *     (reference: cuda/permutohedral_cuda_kernel.cu:24-32 does).
+ *     plx_last_error() returns a thread-local detail string;
+ *   - a plx_lattice is not safe for concurrent use from two threads.
+ */
+#ifndef PLX_H
+#define PLX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plx_lattice plx_lattice;
+
+enum {
+    PLX_OK = 0,
+    PLX_ERR_INVALID = 1,     /* bad argument (shape, NULL, even tap count, ...)        */
+    PLX_ERR_HIP = 2,         /* a HIP runtime call failed (see plx_last_error)         */
+    PLX_ERR_KEY_RANGE = 3,   /* a lattice coordinate left the int16 key range
+                                (the reference wraps silently, permutohedral.h:417-419) */
+    PLX_ERR_DIM = 4,         /* d or order outside the compiled range                  */
+    PLX_ERR_STATE = 5,       /* lattice not built / wrong sizes for this lattice        */
+    PLX_ERR_TOO_LARGE = 6    /* n*(d+1) does not fit the 31-bit entry index             */
+};
+
+#define PLX_MAX_DIM 32       /* position dimension d, 1..PLX_MAX_DIM                    */
+#define PLX_MAX_ORDER 8      /* taps R = 2*order+1, order 0..PLX_MAX_ORDER              */
+
+/* names for plx_export() */
+enum {
+    PLX_ARRAY_KEYS = 0,          /* int16  [m][d]        vertex keys, first-touch order (h:73-79)   */
+    PLX_ARRAY_ENTRY_VERTEX = 1,  /* int32  [d+1][n]      vertex id of simplex corner r of point p   */
+    PLX_ARRAY_ENTRY_WEIGHT = 2,  /* float  [d+1][n]      barycentric weight (h:460-465)             */
+    PLX_ARRAY_NEIGHBORS = 3,     /* int32  [d+1][2r][m]  blur neighbour ids, -1 absent (h:539-544)  */
+    PLX_ARRAY_ROW_PTR = 4,       /* int32  [m+1]         splat CSR row pointers (owned points)      */
+    PLX_ARRAY_CSR_POINT = 5,     /* int32  [nnz]         splat CSR point index                      */
+    PLX_ARRAY_CSR_WEIGHT = 6     /* float  [nnz]         splat CSR weight                           */
+};
+
+const char *plx_strerror(int code);
+const char *plx_last_error(void);
+/* "libplx <version> gfx950" -- lets a host check which build it loaded */
+const char *plx_version(void);
+
+/* A lattice object owns its device buffers (grow-only); re-building it for new
+ * inputs reuses them.  `device` is a HIP device ordinal. */
+int plx_create(int device, plx_lattice **out);
+void plx_destroy(plx_lattice *lat);
+
+/*
+ * Build the lattice structure for positions d_ref[n][d] (already divided by the
+ * lengthscale, bilateral_kernel.py:198) and stencil taps h_taps[ntaps]
+ * (ntaps odd; they set the embedding scale through variance(), h:203-219,
+ * h:372-390, and are the blur weights, h:546).
+ *
+ * Replaces: PermutohedralLattice ctor (h:346-392), the structural half of
+ * splat() (h:395-475, 482-484: embedding, hashed vertex creation, replay
+ * entries), and every hashTable.lookup() of blur() (h:541-545), which becomes a
+ * neighbour table.  Vertex ids are the reference's first-touch ids.
+ *
+ * [own_begin, own_end) is the range of points this process splats and slices
+ * (0, n for a single GPU).  Every rank of a sharded job passes the SAME d_ref
+ * and gets the same vertex numbering; only the splat CSR and the slice tables
+ * are restricted to the owned rows.
+ */
+int plx_build(plx_lattice *lat, const float *d_ref, int64_t n, int d,
+              const float *h_taps, int ntaps,
+              int64_t own_begin, int64_t own_end, void *stream);
+
+int64_t plx_num_points(const plx_lattice *lat);    /* n                              */
+int64_t plx_num_owned(const plx_lattice *lat);     /* own_end - own_begin            */
+int64_t plx_num_vertices(const plx_lattice *lat);  /* m = hashTable.size(), h:44     */
+int plx_dim(const plx_lattice *lat);               /* d                              */
+int plx_order(const plx_lattice *lat);             /* (ntaps-1)/2                    */
+/* bytes of device memory currently held by the lattice */
+int64_t plx_device_bytes(const plx_lattice *lat);
+
+/*
+ * Stage 1 -- splat (h:478-479): d_values[m][vd] = S^T d_src, where d_src holds
+ * the OWNED rows only, [own_end-own_begin][vd].  Every row of d_values is
+ * written (vertices no owned point touches get 0).  Deterministic: no float
+ * atomics.
+ */
+int plx_splat(plx_lattice *lat, const float *d_src, int vd, float *d_values, void *stream);
+
+/*
+ * Stage 2 -- blur (h:513-572): d+1 Jacobi passes over the neighbour table,
+ * ping-ponging between d_values and d_scratch (both [m][vd]).  On return
+ * *result_in_scratch tells which of the two holds the result (d+1 odd => 1).
+ */
+int plx_blur(plx_lattice *lat, float *d_values, float *d_scratch, int vd,
+             int *result_in_scratch, void *stream);
+
+/*
+ * Stage 3 -- slice (h:497-510): d_out[own][vd] = S d_values / (1 + 2^-d) for
+ * the owned rows.
+ */
+int plx_slice(plx_lattice *lat, const float *d_values, int vd, float *d_out, void *stream);
+
+/* splat -> blur -> slice on the lattice's own workspace (single-GPU MVM). */
+int plx_apply(plx_lattice *lat, const float *d_src, int vd, float *d_out, void *stream);
+
+/*
+ * The reference's one-shot call (cpp:6-10 -> h:259-340): build a lattice for
+ * d_ref, apply it to d_src, leave nothing behind.  `scratch` may be NULL or a
+ * lattice object whose buffers are reused (avoids hipMalloc in steady state).
+ */
+int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref,
+               int64_t n, int d, int vd, const float *h_taps, int ntaps,
+               float *d_out, void *stream);
+
+/* Copy one structure array to host memory (parity tests, debugging).
+ * h_dst must hold `bytes` bytes, which must equal the array's size. */
+int plx_export(plx_lattice *lat, int which, void *h_dst, int64_t bytes, void *stream);
+/* size in bytes of an exportable array, or -1 */
+int64_t plx_export_bytes(const plx_lattice *lat, int which);
+
+/* Per-stage device time of the last plx_build on this lattice, in ms, in the
+ * order {embed, insert, number, ids, neighbours, csr}; 0 when timing is off.
+ * plx_set_timing(lat, 1) turns hipEvent timing on (adds event records only). */
+int plx_set_timing(plx_lattice *lat, int on);
+int plx_build_times(const plx_lattice *lat, float *h_ms6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLX_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libplx.so (C ABI: include/plx.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this
+module raises.  The product path never imports anything under oracle/.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplx.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "plx.h")
+
+PLX_OK = 0
+ARRAY_KEYS, ARRAY_ENTRY_VERTEX, ARRAY_ENTRY_WEIGHT, ARRAY_NEIGHBORS = 0, 1, 2, 3
+ARRAY_ROW_PTR, ARRAY_CSR_POINT, ARRAY_CSR_WEIGHT = 4, 5, 6
+MAX_DIM, MAX_ORDER = 32, 8
+
+
+class PlxError(RuntimeError):
+    def __init__(self, code, where, detail):
+        self.code = code
+        super().__init__(f"{where}: {detail} (plx error {code})")
+
+
+_lib = None
+_vp, _i64, _i32, _f32p = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_float)
+
+_SIGNATURES = {
+    "plx_strerror": (ctypes.c_char_p, [_i32]),
+    "plx_last_error": (ctypes.c_char_p, []),
+    "plx_version": (ctypes.c_char_p, []),
+    "plx_create": (_i32, [_i32, ctypes.POINTER(_vp)]),
+    "plx_destroy": (None, [_vp]),
+    "plx_build": (_i32, [_vp, _vp, _i64, _i32, _f32p, _i32, _i64, _i64, _vp]),
+    "plx_num_points": (_i64, [_vp]),
+    "plx_num_owned": (_i64, [_vp]),
+    "plx_num_vertices": (_i64, [_vp]),
+    "plx_dim": (_i32, [_vp]),
+    "plx_order": (_i32, [_vp]),
+    "plx_device_bytes": (_i64, [_vp]),
+    "plx_splat": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "plx_blur": (_i32, [_vp, _vp, _vp, _i32, ctypes.POINTER(_i32), _vp]),
+    "plx_slice": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "plx_apply": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "plx_filter": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32p, _i32, _vp, _vp]),
+    "plx_export": (_i32, [_vp, _i32, _vp, _i64, _vp]),
+    "plx_export_bytes": (_i64, [_vp, _i32]),
+    "plx_set_timing": (_i32, [_vp, _i32]),
+    "plx_build_times": (_i32, [_vp, _f32p]),
+}
+
+
+def declared_symbols():
+    """Function names declared in include/plx.h (used by the CPU-side ABI test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(plx_[a-z_0-9]+)\s*\(", text)))
+
+
+def lib():
+    """Load libplx.so; raise if it was not built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C simplex_gp_amd/csrc` "
+                "(or __graft_entry__.build()). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, where):
+    if rc != PLX_OK:
+        L = lib()
+        detail = L.plx_last_error().decode() or L.plx_strerror(rc).decode()
+        raise PlxError(rc, where, detail)

@@ -1,0 +1,288 @@
+// plx_api.hip -- extern "C" entry points declared in include/plx.h.
+#include "plx_internal.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+namespace plx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ensure(DevBuf &b, size_t bytes)
+{
+    if (bytes == 0) bytes = 4;
+    if (b.cap >= bytes) return PLX_OK;
+    if (b.p) { PLX_HIP_TRY(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    PLX_HIP_TRY(hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return PLX_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+static std::vector<DevBuf *> all_bufs(plx_lattice *L)
+{
+    return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
+            &L->sort_keys_in, &L->sort_keys_out, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
+            &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_w, &L->row_ptr,
+            &L->chunk_first, &L->chunk_last, &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b};
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace plx
+
+using namespace plx;
+
+extern "C" {
+
+const char *plx_strerror(int code)
+{
+    switch (code) {
+    case PLX_OK: return "ok";
+    case PLX_ERR_INVALID: return "invalid argument";
+    case PLX_ERR_HIP: return "HIP runtime error";
+    case PLX_ERR_KEY_RANGE: return "lattice coordinate outside the int16 key range";
+    case PLX_ERR_DIM: return "dimension or order outside the compiled range";
+    case PLX_ERR_STATE: return "lattice not built or size mismatch";
+    case PLX_ERR_TOO_LARGE: return "n*(d+1) exceeds the 31-bit entry index";
+    default: return "unknown error";
+    }
+}
+
+const char *plx_last_error(void) { return g_err; }
+
+const char *plx_version(void) { return "libplx 0.1.0 gfx950"; }
+
+int plx_create(int device, plx_lattice **out)
+{
+    if (!out) { set_error("plx_create: out is NULL"); return PLX_ERR_INVALID; }
+    DeviceGuard g(device);
+    if (!g.ok) { set_error("plx_create: cannot select device %d", device); return PLX_ERR_HIP; }
+    plx_lattice *L = new plx_lattice();
+    L->device = device;
+    if (hipHostMalloc((void **)&L->h_pinned, 64, hipHostMallocDefault) != hipSuccess) {
+        set_error("plx_create: hipHostMalloc failed");
+        delete L;
+        return PLX_ERR_HIP;
+    }
+    for (auto &e : L->ev)
+        if (hipEventCreate(&e) != hipSuccess) { set_error("plx_create: hipEventCreate failed"); return PLX_ERR_HIP; }
+    *out = L;
+    return PLX_OK;
+}
+
+void plx_destroy(plx_lattice *L)
+{
+    if (!L) return;
+    DeviceGuard g(L->device);
+    for (DevBuf *b : all_bufs(L)) release(*b);
+    if (L->h_pinned) (void)hipHostFree(L->h_pinned);
+    for (auto &e : L->ev) if (e) (void)hipEventDestroy(e);
+    delete L;
+}
+
+int plx_build(plx_lattice *L, const float *d_ref, int64_t n, int d, const float *h_taps, int ntaps,
+              int64_t own_begin, int64_t own_end, void *stream)
+{
+    if (!L || !d_ref || !h_taps) { set_error("plx_build: NULL argument"); return PLX_ERR_INVALID; }
+    if (n <= 0) { set_error("plx_build: n = %lld must be positive", (long long)n); return PLX_ERR_INVALID; }
+    if (d < 1 || d > PLX_MAX_DIM) { set_error("plx_build: d = %d outside 1..%d", d, PLX_MAX_DIM); return PLX_ERR_DIM; }
+    if (ntaps < 1 || (ntaps % 2) == 0) { set_error("plx_build: tap count %d must be odd", ntaps); return PLX_ERR_INVALID; }
+    if (ntaps / 2 > PLX_MAX_ORDER) { set_error("plx_build: order %d > %d", ntaps / 2, PLX_MAX_ORDER); return PLX_ERR_DIM; }
+    if (own_begin < 0 || own_end < own_begin || own_end > n) {
+        set_error("plx_build: owned range [%lld, %lld) outside [0, %lld)", (long long)own_begin,
+                  (long long)own_end, (long long)n);
+        return PLX_ERR_INVALID;
+    }
+    if (n * (int64_t)(d + 1) >= (1ll << 31) - 1024) {
+        set_error("plx_build: n*(d+1) = %lld does not fit the 31-bit entry index", (long long)(n * (d + 1)));
+        return PLX_ERR_TOO_LARGE;
+    }
+    DeviceGuard g(L->device);
+    if (!g.ok) { set_error("plx_build: cannot select device %d", L->device); return PLX_ERR_HIP; }
+    L->built = false;
+    L->n = n; L->d = d; L->ntaps = ntaps; L->order = ntaps / 2;
+    L->own_begin = own_begin; L->own_end = own_end;
+    memset(&L->taps, 0, sizeof(L->taps));
+    for (int i = 0; i < ntaps; ++i) L->taps.c[i] = h_taps[i];
+    int rc = build_impl(L, d_ref, (hipStream_t)stream);
+    if (rc == PLX_OK) L->built = true;
+    return rc;
+}
+
+int64_t plx_num_points(const plx_lattice *L) { return L ? L->n : -1; }
+int64_t plx_num_owned(const plx_lattice *L) { return L ? L->own_end - L->own_begin : -1; }
+int64_t plx_num_vertices(const plx_lattice *L) { return (L && L->built) ? L->m : -1; }
+int plx_dim(const plx_lattice *L) { return L ? L->d : -1; }
+int plx_order(const plx_lattice *L) { return L ? L->order : -1; }
+
+int64_t plx_device_bytes(const plx_lattice *L)
+{
+    if (!L) return -1;
+    int64_t total = 0;
+    for (DevBuf *b : all_bufs(const_cast<plx_lattice *>(L))) total += (int64_t)b->cap;
+    return total;
+}
+
+static int check_apply(const plx_lattice *L, const void *a, const void *b, int vd, const char *who)
+{
+    if (!L || !a || !b) { set_error("%s: NULL argument", who); return PLX_ERR_INVALID; }
+    if (!L->built) { set_error("%s: lattice not built", who); return PLX_ERR_STATE; }
+    if (vd < 1) { set_error("%s: vd = %d must be positive", who, vd); return PLX_ERR_INVALID; }
+    if ((int64_t)L->m * vd >= (1ll << 31) || (int64_t)(L->own_end - L->own_begin) * vd >= (1ll << 31)) {
+        set_error("%s: m*vd or n*vd exceeds 2^31 elements; split the columns", who);
+        return PLX_ERR_TOO_LARGE;
+    }
+    return PLX_OK;
+}
+
+int plx_splat(plx_lattice *L, const float *d_src, int vd, float *d_values, void *stream)
+{
+    PLX_TRY(check_apply(L, d_src, d_values, vd, "plx_splat"));
+    DeviceGuard g(L->device);
+    return splat_impl(L, d_src, vd, d_values, (hipStream_t)stream);
+}
+
+int plx_blur(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch, void *stream)
+{
+    PLX_TRY(check_apply(L, d_values, d_scratch, vd, "plx_blur"));
+    if (!result_in_scratch) { set_error("plx_blur: result_in_scratch is NULL"); return PLX_ERR_INVALID; }
+    DeviceGuard g(L->device);
+    return blur_impl(L, d_values, d_scratch, vd, result_in_scratch, (hipStream_t)stream);
+}
+
+int plx_slice(plx_lattice *L, const float *d_values, int vd, float *d_out, void *stream)
+{
+    PLX_TRY(check_apply(L, d_values, d_out, vd, "plx_slice"));
+    DeviceGuard g(L->device);
+    return slice_impl(L, d_values, vd, d_out, (hipStream_t)stream);
+}
+
+int plx_apply(plx_lattice *L, const float *d_src, int vd, float *d_out, void *stream)
+{
+    PLX_TRY(check_apply(L, d_src, d_out, vd, "plx_apply"));
+    DeviceGuard g(L->device);
+    PLX_TRY(ensure(L->val_a, (size_t)L->m * vd * 4));
+    PLX_TRY(ensure(L->val_b, (size_t)L->m * vd * 4));
+    hipStream_t s = (hipStream_t)stream;
+    PLX_TRY(splat_impl(L, d_src, vd, L->val_a.as<float>(), s));
+    int in_b = 0;
+    PLX_TRY(blur_impl(L, L->val_a.as<float>(), L->val_b.as<float>(), vd, &in_b, s));
+    return slice_impl(L, in_b ? L->val_b.as<float>() : L->val_a.as<float>(), vd, d_out, s);
+}
+
+int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref, int64_t n, int d, int vd,
+               const float *h_taps, int ntaps, float *d_out, void *stream)
+{
+    plx_lattice *L = scratch;
+    if (!L) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { set_error("plx_filter: hipGetDevice failed"); return PLX_ERR_HIP; }
+        PLX_TRY(plx_create(dev, &L));
+    }
+    int rc = plx_build(L, d_ref, n, d, h_taps, ntaps, 0, n, stream);
+    if (rc == PLX_OK) rc = plx_apply(L, d_src, vd, d_out, stream);
+    if (!scratch) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        plx_destroy(L);
+    }
+    return rc;
+}
+
+int64_t plx_export_bytes(const plx_lattice *L, int which)
+{
+    if (!L || !L->built) return -1;
+    const int64_t n = L->n, m = L->m, d1 = L->d + 1;
+    switch (which) {
+    case PLX_ARRAY_KEYS: return m * L->d * 2;
+    case PLX_ARRAY_ENTRY_VERTEX: return d1 * n * 4;
+    case PLX_ARRAY_ENTRY_WEIGHT: return d1 * n * 4;
+    case PLX_ARRAY_NEIGHBORS: return d1 * 2 * L->order * m * 4;
+    case PLX_ARRAY_ROW_PTR: return (m + 1) * 4;
+    case PLX_ARRAY_CSR_POINT: return L->nnz * 4;
+    case PLX_ARRAY_CSR_WEIGHT: return L->nnz * 4;
+    default: return -1;
+    }
+}
+
+int plx_export(plx_lattice *L, int which, void *h_dst, int64_t bytes, void *stream)
+{
+    if (!L || !h_dst) { set_error("plx_export: NULL argument"); return PLX_ERR_INVALID; }
+    if (!L->built) { set_error("plx_export: lattice not built"); return PLX_ERR_STATE; }
+    const int64_t want = plx_export_bytes(L, which);
+    if (want < 0) { set_error("plx_export: unknown array %d", which); return PLX_ERR_INVALID; }
+    if (want != bytes) { set_error("plx_export: array %d is %lld bytes, caller gave %lld", which, (long long)want, (long long)bytes); return PLX_ERR_INVALID; }
+    if (bytes == 0) return PLX_OK;
+    DeviceGuard g(L->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t m = L->m;
+    switch (which) {
+    case PLX_ARRAY_KEYS: {
+        // device keys are packed int16 pairs padded to DW words per vertex
+        const int dw = (L->d + 1) / 2;
+        std::vector<uint32_t> tmp((size_t)m * dw);
+        PLX_HIP_TRY(hipMemcpyAsync(tmp.data(), L->vkeys.p, tmp.size() * 4, hipMemcpyDeviceToHost, s));
+        PLX_HIP_TRY(hipStreamSynchronize(s));
+        int16_t *dst = (int16_t *)h_dst;
+        for (int64_t i = 0; i < m; ++i)
+            for (int c = 0; c < L->d; ++c)
+                dst[i * L->d + c] = (int16_t)((tmp[i * dw + (c >> 1)] >> ((c & 1) * 16)) & 0xFFFFu);
+        return PLX_OK;
+    }
+    case PLX_ARRAY_NEIGHBORS: {
+        // strip the plane padding (mstride -> m)
+        const int planes = (L->d + 1) * 2 * L->order;
+        PLX_HIP_TRY(hipMemcpy2DAsync(h_dst, (size_t)m * 4, L->nbr.p, (size_t)L->mstride * 4, (size_t)m * 4,
+                                     planes, hipMemcpyDeviceToHost, s));
+        break;
+    }
+    case PLX_ARRAY_ENTRY_VERTEX: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->evid.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    case PLX_ARRAY_ENTRY_WEIGHT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->ew.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    case PLX_ARRAY_ROW_PTR: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->row_ptr.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    case PLX_ARRAY_CSR_POINT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_pt.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    case PLX_ARRAY_CSR_WEIGHT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_w.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    }
+    PLX_HIP_TRY(hipStreamSynchronize(s));
+    return PLX_OK;
+}
+
+int plx_set_timing(plx_lattice *L, int on)
+{
+    if (!L) return PLX_ERR_INVALID;
+    L->timing = on != 0;
+    return PLX_OK;
+}
+
+int plx_build_times(const plx_lattice *L, float *h_ms6)
+{
+    if (!L || !h_ms6) return PLX_ERR_INVALID;
+    for (int i = 0; i < 6; ++i) h_ms6[i] = L->build_ms[i];
+    return PLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,601 @@
+// plx_build.hip -- lattice construction on gfx950.
+//
+// Replaces the structural half of the reference's splat() and every hash lookup
+// of its blur() (cpp/permutohedral.h:395-475, 482-484, 539-545; "h" below).
+// Nothing here is a translation of the reference's CUDA kernels: the reference
+// re-hashes every neighbour on every MVM and patches racy duplicate inserts
+// afterwards (cuda/permutohedral_cuda_kernel.cu:298-332); here the lattice is
+// built once, duplicate-free by construction, numbered exactly like the CPU
+// reference (first touch, h:73-79), and turned into gather tables.
+//
+// Pipeline (all arrays "entry"-indexed are SoA [r][p], r = simplex corner,
+// p = point, so that every wave access is a contiguous run):
+//   embed    per point: elevate, round, rank, barycentric (registers only)
+//            -> packed int16 keys ekeys[r][p][DW], weights ew[r][p]
+//   insert   per corner: open addressing on a uint32 table whose slot value is
+//            the SMALLEST reference entry index e = p*(d+1)+r seen with that
+//            key (CAS to claim, atomicMin to lower)  -> eslot[r][p]
+//   number   per point: corner is "first touch" iff table[slot] == e; counts are
+//            scanned in (p, r) order => vertex ids equal the reference's
+//   ids      per corner: evid[r][p] = id(table[eslot])
+//   neighbours  per (vertex, axis): hash the 2r neighbour keys once -> nbr table
+//   csr      stable radix sort of corners by vertex id -> splat CSR
+//
+// This file is compiled with -ffp-contract=off: the embedding must round
+// exactly like the reference's FMA-free x86-64 build or points on a rounding
+// boundary pick a different simplex.
+
+#include "plx_internal.h"
+
+#include <math.h>
+
+namespace plx {
+
+// ----------------------------------------------------------------------------
+// small device helpers
+
+__device__ __forceinline__ uint32_t mix_hash(const uint32_t *k, int dw)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int j = 0; j < dw; ++j) {
+        h ^= k[j];
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 32;
+    }
+    h *= 0xc4ceb9fe1a85ec53ull;
+    h ^= h >> 29;
+    return (uint32_t)h;
+}
+
+template <int DW>
+__device__ __forceinline__ void load_key(const uint32_t *__restrict__ base, size_t idx, uint32_t (&k)[DW])
+{
+    const uint32_t *p = base + idx * DW;
+    if constexpr (DW % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < DW / 4; ++j) {
+            uint4 v = reinterpret_cast<const uint4 *>(p)[j];
+            k[4 * j] = v.x; k[4 * j + 1] = v.y; k[4 * j + 2] = v.z; k[4 * j + 3] = v.w;
+        }
+    } else if constexpr (DW % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < DW / 2; ++j) {
+            uint2 v = reinterpret_cast<const uint2 *>(p)[j];
+            k[2 * j] = v.x; k[2 * j + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < DW; ++j) k[j] = p[j];
+    }
+}
+
+template <int DW>
+__device__ __forceinline__ void store_key(uint32_t *__restrict__ base, size_t idx, const uint32_t (&k)[DW])
+{
+    uint32_t *p = base + idx * DW;
+    if constexpr (DW % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < DW / 4; ++j)
+            reinterpret_cast<uint4 *>(p)[j] = make_uint4(k[4 * j], k[4 * j + 1], k[4 * j + 2], k[4 * j + 3]);
+    } else if constexpr (DW % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < DW / 2; ++j)
+            reinterpret_cast<uint2 *>(p)[j] = make_uint2(k[2 * j], k[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < DW; ++j) p[j] = k[j];
+    }
+}
+
+template <int DW>
+__device__ __forceinline__ bool key_equal(const uint32_t (&a)[DW], const uint32_t (&b)[DW])
+{
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < DW; ++j) eq = eq && (a[j] == b[j]);
+    return eq;
+}
+
+// exclusive scan of one int per thread over a 256-thread workgroup
+__device__ __forceinline__ int block_exclusive_scan(int val, int *total)
+{
+    __shared__ int wave_sums[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = val;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        int s = wave_sums[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - val;
+}
+
+// ----------------------------------------------------------------------------
+// embed: h:395-471 for one point per thread, everything in registers
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__ x, int n, ScaleArgs sf,
+                                                       uint32_t *__restrict__ ekeys,
+                                                       float *__restrict__ ew, int *__restrict__ counters)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+
+    float pos[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) pos[i] = x[(size_t)p * D + i];
+
+    // h:398-402, same association order as the reference expression
+    float el[D1];
+    el[D] = (float)(-D) * pos[D - 1] * sf.v[D - 1];
+#pragma unroll
+    for (int i = D - 1; i > 0; --i)
+        el[i] = (el[i + 1] - (float)i * pos[i - 1] * sf.v[i - 1] + (float)(i + 2) * pos[i] * sf.v[i]);
+    el[0] = el[1] + 2.0f * pos[0] * sf.v[0];
+
+    // h:405-423
+    constexpr float scale = 1.0f / (float)D1;
+    constexpr float limit = 32767.0f - 2.0f * (float)D1;   // room for the fix-up and the canonical offsets
+    int gr[D1];
+    int sum = 0;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+        float v = el[i] * scale;
+        float up = ceilf(v) * (float)D1;
+        float down = floorf(v) * (float)D1;
+        float g = (up - el[i] < el[i] - down) ? up : down;
+        if (!(fabsf(g) <= limit)) { bad = true; g = 0.f; }   // also catches NaN / Inf
+        gr[i] = (int)g;
+        sum += gr[i];
+    }
+    sum = (int)((float)sum * scale);   // int *= float, h:423
+
+    // h:427-433
+    int rk[D1];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) rk[i] = 0;
+    {
+        float df[D1];
+#pragma unroll
+        for (int i = 0; i < D1; ++i) df[i] = el[i] - (float)gr[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i + 1; j <= D; ++j) {
+                bool lt = df[i] < df[j];
+                rk[i] += lt ? 1 : 0;
+                rk[j] += lt ? 0 : 1;
+            }
+    }
+
+    // h:435-457
+    if (sum > 0) {
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+            bool wrap = rk[i] >= D1 - sum;
+            gr[i] -= wrap ? D1 : 0;
+            rk[i] += wrap ? (sum - D1) : sum;
+        }
+    } else if (sum < 0) {
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+            bool wrap = rk[i] < -sum;
+            gr[i] += wrap ? D1 : 0;
+            rk[i] += wrap ? (D1 + sum) : sum;
+        }
+    }
+
+    // h:460-465.  rank is a permutation of 0..d, so every barycentric cell gets
+    // exactly one "+=" and one "-=": bary[k] = delta[rank == d-k] - delta[rank == d+1-k].
+    // Select instead of indexing by rank (a runtime index would spill to scratch).
+    float sd[D1];   // delta ordered by rank
+#pragma unroll
+    for (int k = 0; k < D1; ++k) sd[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+        float delta = (el[i] - (float)gr[i]) * scale;
+#pragma unroll
+        for (int k = 0; k < D1; ++k) sd[k] = (rk[i] == k) ? delta : sd[k];
+    }
+    float bary[D1];
+#pragma unroll
+    for (int k = 1; k <= D; ++k) bary[k] = sd[D - k] - sd[D1 - k];
+    bary[0] = sd[D] + (1.0f + (0.0f - sd[0]));
+
+    if (bad) atomicOr(&counters[1], 1);
+
+    // h:468-471: corner r has key greedy + canonical[r][rank]
+#pragma unroll
+    for (int r = 0; r < D1; ++r) {
+        uint32_t kw[DW];
+#pragma unroll
+        for (int j = 0; j < DW; ++j) kw[j] = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            int c = gr[i] + ((rk[i] <= D - r) ? r : (r - D1));
+            kw[i >> 1] |= ((uint32_t)c & 0xFFFFu) << ((i & 1) * 16);
+        }
+        const size_t idx = (size_t)r * n + p;
+        store_key<DW>(ekeys, idx, kw);
+        ew[idx] = bary[r];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// insert: one thread per simplex corner.  Slot value = smallest reference entry
+// index e = p*(d+1)+r among the corners that share the slot's key.  Invariant:
+// every value ever stored in a slot belongs to a corner with the same key, so a
+// stale plain load can only cost an extra atomic, never a wrong match.
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restrict__ ekeys, int n,
+                                                        uint32_t *__restrict__ table, uint32_t mask,
+                                                        uint32_t *__restrict__ eslot)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const int r = blockIdx.y;
+    if (p >= n) return;
+    const size_t idx = (size_t)r * n + p;
+    const uint32_t e = (uint32_t)p * D1 + r;
+
+    uint32_t k[DW];
+    load_key<DW>(ekeys, idx, k);
+    uint32_t h = mix_hash(k, DW) & mask;
+    for (;;) {
+        uint32_t o = table[h];
+        if (o == kEmpty) {
+            o = atomicCAS(&table[h], kEmpty, e);
+            if (o == kEmpty) break;   // claimed an empty slot
+        }
+        if (o == e) break;
+        uint32_t ko[DW];
+        const uint32_t po = o / D1, ro = o - po * D1;
+        load_key<DW>(ekeys, (size_t)ro * n + po, ko);
+        if (key_equal<DW>(k, ko)) {
+            if (e < o) atomicMin(&table[h], e);
+            break;
+        }
+        h = (h + 1) & mask;
+    }
+    eslot[idx] = h;
+}
+
+// ----------------------------------------------------------------------------
+// number: first-touch flags per point, counted per workgroup ...
+
+__global__ __launch_bounds__(kBlock) void flag_kernel(const uint32_t *__restrict__ eslot,
+                                                      const uint32_t *__restrict__ table, int n, int d1,
+                                                      uint32_t *__restrict__ flagmask,
+                                                      int *__restrict__ blockcnt)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t bits = 0, bits_hi = 0;
+    if (p < n) {
+        for (int r = 0; r < d1; ++r) {
+            uint32_t slot = eslot[(size_t)r * n + p];
+            bool first = table[slot] == (uint32_t)p * d1 + r;
+            if (r < 32) bits |= (first ? 1u : 0u) << r;
+            else bits_hi |= (first ? 1u : 0u) << (r - 32);
+        }
+        flagmask[2 * (size_t)p] = bits;
+        flagmask[2 * (size_t)p + 1] = bits_hi;
+    }
+    int total;
+    block_exclusive_scan(__popc(bits) + __popc(bits_hi), &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+
+// ... scanned by one workgroup (nblocks <= ~16k for n = 4e6) ...
+__global__ __launch_bounds__(kBlock) void scan_blocks_kernel(int *__restrict__ blockcnt, int nblocks,
+                                                             int *__restrict__ counters)
+{
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += kBlock) {
+        int i = base + threadIdx.x;
+        int v = (i < nblocks) ? blockcnt[i] : 0;
+        int total;
+        int ex = block_exclusive_scan(v, &total);
+        if (i < nblocks) blockcnt[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) counters[0] = carry;   // m
+}
+
+// ... and turned into vertex ids: id order == (p, r) order == reference first touch.
+template <int D>
+__global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restrict__ flagmask,
+                                                        const int *__restrict__ blockoff,
+                                                        const uint32_t *__restrict__ eslot,
+                                                        const uint32_t *__restrict__ ekeys, int n,
+                                                        uint32_t *__restrict__ table,
+                                                        uint32_t *__restrict__ vkeys)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t bits = 0, bits_hi = 0;
+    if (p < n) { bits = flagmask[2 * (size_t)p]; bits_hi = flagmask[2 * (size_t)p + 1]; }
+    int total;
+    int id = blockoff[blockIdx.x] + block_exclusive_scan(__popc(bits) + __popc(bits_hi), &total);
+    if (p >= n) return;
+#pragma unroll
+    for (int r = 0; r < D1; ++r) {
+        bool first = (r < 32) ? ((bits >> r) & 1u) : ((bits_hi >> (r - 32)) & 1u);
+        if (first) {
+            const size_t idx = (size_t)r * n + p;
+            table[eslot[idx]] = (uint32_t)id;
+            uint32_t k[DW];
+            load_key<DW>(ekeys, idx, k);
+            store_key<DW>(vkeys, (size_t)id, k);
+            ++id;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ids_kernel(const uint32_t *__restrict__ eslot,
+                                                     const uint32_t *__restrict__ table, int n,
+                                                     int *__restrict__ evid)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const size_t idx = (size_t)blockIdx.y * n + p;
+    evid[idx] = (int)table[eslot[idx]];
+}
+
+// ----------------------------------------------------------------------------
+// neighbours: h:539-545 evaluated once per lattice instead of once per MVM.
+// nbr[(axis*2r + s)*mstride + i]; s enumerates nid = -r..-1, 1..r.
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__restrict__ vkeys, int m,
+                                                          int64_t mstride, int order,
+                                                          const uint32_t *__restrict__ table,
+                                                          uint32_t mask, int *__restrict__ nbr)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int axis = blockIdx.y;
+    if (i >= m) return;
+    uint32_t kw[DW];
+    load_key<DW>(vkeys, (size_t)i, kw);
+    int key[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) key[c] = (int)(int16_t)((kw[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu);
+
+    for (int s = 0; s < 2 * order; ++s) {
+        const int nid = (s < order) ? (s - order) : (s - order + 1);
+        uint32_t nk[DW];
+#pragma unroll
+        for (int j = 0; j < DW; ++j) nk[j] = 0;
+        bool in_range = true;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            // neighbour[k] = key[k] - nid, neighbour[axis] = key[axis] + nid*d  (h:541-542)
+            int v = key[c] - nid + ((c == axis) ? nid * D1 : 0);
+            in_range = in_range && (v >= -32768) && (v <= 32767);
+            nk[c >> 1] |= ((uint32_t)v & 0xFFFFu) << ((c & 1) * 16);
+        }
+        int found = -1;
+        if (in_range) {
+            uint32_t h = mix_hash(nk, DW) & mask;
+            for (;;) {
+                uint32_t v = table[h];
+                if (v == kEmpty) break;
+                uint32_t kv[DW];
+                load_key<DW>(vkeys, (size_t)v, kv);
+                if (key_equal<DW>(nk, kv)) { found = (int)v; break; }
+                h = (h + 1) & mask;
+            }
+        }
+        nbr[((size_t)axis * 2 * order + s) * mstride + i] = found;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// csr: corners of the owned points sorted (stably) by vertex id
+
+__global__ __launch_bounds__(kBlock) void csr_keys_kernel(const int *__restrict__ evid, int n, int own_begin,
+                                                          int n_own, uint32_t *__restrict__ keys,
+                                                          uint32_t *__restrict__ vals)
+{
+    const int pl = blockIdx.x * kBlock + threadIdx.x;
+    if (pl >= n_own) return;
+    const int r = blockIdx.y;
+    const size_t src = (size_t)r * n + own_begin + pl;
+    const size_t dst = (size_t)r * n_own + pl;
+    keys[dst] = (uint32_t)evid[src];
+    vals[dst] = (uint32_t)src;
+}
+
+__global__ __launch_bounds__(kBlock) void csr_finalize_kernel(const uint32_t *__restrict__ skeys,
+                                                              const uint32_t *__restrict__ svals,
+                                                              const float *__restrict__ ew, int n,
+                                                              int own_begin, int nnz, int m,
+                                                              int *__restrict__ csr_pt,
+                                                              float *__restrict__ csr_w,
+                                                              int *__restrict__ row_ptr,
+                                                              int *__restrict__ chunk_first,
+                                                              int *__restrict__ chunk_last)
+{
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nnz) return;
+    const uint32_t v = skeys[k];
+    const uint32_t idx = svals[k];
+    const uint32_t r = idx / (uint32_t)n;
+    csr_pt[k] = (int)(idx - r * (uint32_t)n) - own_begin;
+    csr_w[k] = ew[idx];
+    // row_ptr[u] = first k with skeys[k] >= u; rows no owned point touches are empty
+    const int prev = (k == 0) ? -1 : (int)skeys[k - 1];
+    for (int u = prev + 1; u <= (int)v; ++u) row_ptr[u] = k;
+    if (k == nnz - 1)
+        for (int u = (int)v + 1; u <= m; ++u) row_ptr[u] = nnz;
+    if (k % kSplatChunk == 0) chunk_first[k / kSplatChunk] = (int)v;
+    if (k % kSplatChunk == kSplatChunk - 1 || k == nnz - 1) chunk_last[k / kSplatChunk] = (int)v;
+}
+
+// ----------------------------------------------------------------------------
+// host side
+
+// h:203-219, fp32 throughout
+static float taps_variance(const float *c, int R)
+{
+    float mom0 = 0, mom1 = 0.f, mom2 = 0.f;
+    for (int i = 0; i < R; ++i) {
+        mom0 += c[i];
+        mom1 += i * c[i];
+        mom2 += i * i * c[i];
+    }
+    float mean = mom1 / mom0;
+    return mom2 / mom0 - mean * mean;
+}
+
+template <int D>
+static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    const int n = (int)L->n;
+    const int n_own = (int)(L->own_end - L->own_begin);
+    const int64_t E = (int64_t)n * D1;
+    const int nblocks = ceil_div(n, kBlock);
+    const bool T = L->timing;
+    int evi = 0;
+    auto mark = [&]() { if (T) (void)hipEventRecord(L->ev[evi++], stream); };
+
+    // scale factors exactly as the reference computes them (h:372-390)
+    ScaleArgs sf;
+    for (int i = 0; i < D; ++i) {
+        sf.v[i] = 1.0f / (sqrtf((float)(i + 1) * (i + 2)));
+        float sigma_blur = taps_variance(L->taps.c, L->ntaps);
+        sf.v[i] *= (D + 1) * sqrtf(sigma_blur + 1.0f / 6.0f);
+    }
+    L->slice_denom = 1 + powf(2, -D);
+
+    // table capacity: power of two >= 2E  (load factor <= 0.5)
+    uint64_t cap = 1024;
+    while (cap < 2ull * (uint64_t)E) cap <<= 1;
+    L->table_mask = (uint32_t)(cap - 1);
+
+    PLX_TRY(ensure(L->ekeys, (size_t)E * DW * 4));
+    PLX_TRY(ensure(L->ew, (size_t)E * 4));
+    PLX_TRY(ensure(L->eslot, (size_t)E * 4));
+    PLX_TRY(ensure(L->evid, (size_t)E * 4));
+    PLX_TRY(ensure(L->flagmask, (size_t)n * 8));
+    PLX_TRY(ensure(L->blockcnt, (size_t)(nblocks + 1) * 4));
+    PLX_TRY(ensure(L->table, (size_t)cap * 4));
+    PLX_TRY(ensure(L->counters, 64));
+
+    PLX_HIP_TRY(hipMemsetAsync(L->counters.p, 0, 64, stream));
+    PLX_HIP_TRY(hipMemsetAsync(L->table.p, 0xFF, (size_t)cap * 4, stream));
+
+    mark();
+    embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, n, sf, L->ekeys.as<uint32_t>(), L->ew.as<float>(),
+                                                    L->counters.as<int>());
+    mark();
+    insert_kernel<D><<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->ekeys.as<uint32_t>(), n,
+                                                                L->table.as<uint32_t>(), L->table_mask,
+                                                                L->eslot.as<uint32_t>());
+    mark();
+    flag_kernel<<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n, D1,
+                                                L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
+    scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
+    PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned, L->counters.p, 8, hipMemcpyDeviceToHost, stream));
+    PLX_HIP_TRY(hipStreamSynchronize(stream));   // the one sync of a build: m sizes everything below
+    if (L->h_pinned[1] != 0) {
+        set_error("a lattice coordinate left the int16 key range (|x/lengthscale| too large, NaN or Inf)");
+        return PLX_ERR_KEY_RANGE;
+    }
+    const int m = L->h_pinned[0];
+    L->m = m;
+    L->mstride = ((int64_t)m + 63) & ~63ll;
+    L->nnz = (int64_t)n_own * D1;
+    L->nchunks = ceil_div(L->nnz, kSplatChunk);
+    const int order = L->order;
+
+    PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4));
+    PLX_TRY(ensure(L->nbr, (size_t)D1 * 2 * order * L->mstride * 4 + 4));
+    PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
+    PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 4));
+    PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 4));
+    PLX_TRY(ensure(L->chunk_first, (size_t)L->nchunks * 4 + 4));
+    PLX_TRY(ensure(L->chunk_last, (size_t)L->nchunks * 4 + 4));
+
+    assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->blockcnt.as<int>(),
+                                                     L->eslot.as<uint32_t>(), L->ekeys.as<uint32_t>(), n,
+                                                     L->table.as<uint32_t>(), L->vkeys.as<uint32_t>());
+    mark();
+    ids_kernel<<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
+                                                         L->evid.as<int>());
+    mark();
+    if (order > 0)
+        neighbor_kernel<D><<<dim3(ceil_div(m, kBlock), D1), kBlock, 0, stream>>>(
+            L->vkeys.as<uint32_t>(), m, L->mstride, order, L->table.as<uint32_t>(), L->table_mask,
+            L->nbr.as<int>());
+    mark();
+
+    // splat CSR over the owned points
+    if (L->nnz > 0) {
+        int end_bit = 1;
+        while ((1ll << end_bit) < (int64_t)m) ++end_bit;
+        size_t temp_bytes = 0;
+        PLX_TRY(sort_pairs_temp_bytes(L->nnz, end_bit, &temp_bytes));
+        PLX_TRY(ensure(L->sort_keys_in, (size_t)L->nnz * 4));
+        PLX_TRY(ensure(L->sort_keys_out, (size_t)L->nnz * 4));
+        PLX_TRY(ensure(L->sort_vals_in, (size_t)L->nnz * 4));
+        PLX_TRY(ensure(L->sort_vals_out, (size_t)L->nnz * 4));
+        PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
+        csr_keys_kernel<<<dim3(ceil_div(n_own, kBlock), D1), kBlock, 0, stream>>>(
+            L->evid.as<int>(), n, (int)L->own_begin, n_own, L->sort_keys_in.as<uint32_t>(),
+            L->sort_vals_in.as<uint32_t>());
+        PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(),
+                           L->sort_keys_out.as<uint32_t>(), L->sort_vals_in.as<uint32_t>(),
+                           L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, stream));
+        csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
+            L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
+            (int)L->own_begin, (int)L->nnz, m, L->csr_pt.as<int>(), L->csr_w.as<float>(),
+            L->row_ptr.as<int>(), L->chunk_first.as<int>(), L->chunk_last.as<int>());
+    } else {
+        PLX_HIP_TRY(hipMemsetAsync(L->row_ptr.p, 0, (size_t)(m + 1) * 4, stream));
+    }
+    mark();
+    PLX_HIP_TRY(hipGetLastError());
+    if (T) {
+        PLX_HIP_TRY(hipStreamSynchronize(stream));
+        for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&L->build_ms[i], L->ev[i], L->ev[i + 1]);
+    }
+    return PLX_OK;
+}
+
+int build_impl(plx_lattice *L, const float *d_ref, hipStream_t stream)
+{
+    switch (L->d) {
+#define PLX_CASE(D) case D: return build_typed<D>(L, d_ref, stream);
+        PLX_CASE(1) PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8)
+        PLX_CASE(9) PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16)
+        PLX_CASE(17) PLX_CASE(18) PLX_CASE(19) PLX_CASE(20) PLX_CASE(21) PLX_CASE(22) PLX_CASE(23) PLX_CASE(24)
+        PLX_CASE(25) PLX_CASE(26) PLX_CASE(27) PLX_CASE(28) PLX_CASE(29) PLX_CASE(30) PLX_CASE(31) PLX_CASE(32)
+#undef PLX_CASE
+    default:
+        set_error("d = %d outside 1..%d", L->d, PLX_MAX_DIM);
+        return PLX_ERR_DIM;
+    }
+}
+
+}  // namespace plx

@@ -1,0 +1,110 @@
+// plx_internal.h -- shared declarations of libplx (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "plx.h"
+
+namespace plx {
+
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;   // empty hash slot
+constexpr int kBlock = 256;                // threads per workgroup for every kernel here
+constexpr int kSplatChunk = 1024;          // CSR entries staged per splat workgroup
+
+void set_error(const char *fmt, ...);
+
+#define PLX_HIP_TRY(expr)                                                            \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            plx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                           __FILE__, __LINE__);                                      \
+            return PLX_ERR_HIP;                                                      \
+        }                                                                            \
+    } while (0)
+
+#define PLX_TRY(expr)                 \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != PLX_OK) return _rc; \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ScaleArgs { float v[PLX_MAX_DIM]; };              // h:372-390 scale factors
+struct TapArgs { float c[2 * PLX_MAX_ORDER + 1]; };      // blur weights, h:546
+
+}  // namespace plx
+
+struct plx_lattice {
+    int device = 0;
+    bool built = false;
+    bool timing = false;
+    float build_ms[6] = {0, 0, 0, 0, 0, 0};
+
+    // problem
+    int64_t n = 0, own_begin = 0, own_end = 0;
+    int d = 0, order = 0, ntaps = 0;
+    plx::TapArgs taps;
+    float slice_denom = 1.f;       // 1 + 2^-d, h:507
+    int64_t m = 0;                 // vertices
+    int64_t mstride = 0;           // m rounded up to 64 (plane stride of the neighbour table)
+    int64_t nnz = 0;               // owned CSR entries = n_own * (d+1)
+    int64_t nchunks = 0;           // ceil(nnz / kSplatChunk)
+    uint32_t table_mask = 0;       // capacity - 1
+
+    // build scratch
+    plx::DevBuf ekeys;      // uint32 [d+1][n][DW]   packed int16 keys of every simplex corner
+    plx::DevBuf eslot;      // uint32 [d+1][n]       hash slot of every corner
+    plx::DevBuf flagmask;   // uint32 [n]            bit r set: corner r is the first touch of its vertex
+    plx::DevBuf blockcnt;   // int32  [nblocks+1]    per-workgroup first-touch counts, then offsets
+    plx::DevBuf table;      // uint32 [capacity]     slot -> min entry index, later slot -> vertex id
+    plx::DevBuf counters;   // int32  [8]            {m, error flag, ...}
+    plx::DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp;
+
+    // structure
+    plx::DevBuf vkeys;      // uint32 [m][DW]        packed vertex keys, first-touch order
+    plx::DevBuf ew;         // float  [d+1][n]       barycentric weights
+    plx::DevBuf evid;       // int32  [d+1][n]       vertex ids
+    plx::DevBuf nbr;        // int32  [d+1][2r][mstride]
+    plx::DevBuf csr_pt;     // int32  [nnz]          local (owned) point index, sorted by vertex
+    plx::DevBuf csr_w;      // float  [nnz]
+    plx::DevBuf row_ptr;    // int32  [m+1]
+    plx::DevBuf chunk_first, chunk_last;   // int32 [nchunks]
+
+    // apply workspace
+    plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
+    plx::DevBuf val_a, val_b;                 // float [m][vd]
+
+    int32_t *h_pinned = nullptr;   // pinned host staging for {m, err}
+    hipEvent_t ev[8] = {};
+};
+
+namespace plx {
+
+int ensure(DevBuf &b, size_t bytes);
+void release(DevBuf &b);
+
+// plx_build.hip
+int build_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);
+// plx_sort.hip (rocPRIM radix sort of (vertex id, entry index) pairs)
+int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes);
+int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
+               const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit,
+               hipStream_t stream);
+// plx_apply.hip
+int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream);
+int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
+              hipStream_t stream);
+int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream);
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace plx

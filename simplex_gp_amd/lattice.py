@@ -1,0 +1,227 @@
+"""Device lattice handle + the reference's `filter(src, ref, coeffs)` boundary.
+
+`filter` is the drop-in for the one native symbol of the reference
+(gpytorch_lattice_kernel/cpp/lattice.cpp:6-16, cuda/permutohedral_cuda.cpp:12-22):
+same argument order, shapes, dtype and return value.  `Lattice` is the staged
+form (build once, apply many times) that the CG loop and the backward pass use.
+
+torch is plumbing here: device memory, the current stream, nothing else.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as nv
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _taps_array(coeffs):
+    if isinstance(coeffs, torch.Tensor):
+        coeffs = coeffs.detach().to("cpu", torch.float32).numpy()
+    taps = np.ascontiguousarray(coeffs, dtype=np.float32).reshape(-1)
+    if taps.size % 2 != 1:
+        raise ValueError(f"coeffs must have an odd number of taps, got {taps.size}")
+    return taps
+
+
+def _check_f32_cuda(t, name, ndim=2):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA (HIP) tensor; this build has no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.dim() != ndim:
+        raise ValueError(f"{name} must be {ndim}-D, got shape {tuple(t.shape)}")
+
+
+class Lattice:
+    """One permutohedral lattice on one GPU.
+
+    build(ref, coeffs) fixes the structure (vertices, barycentric weights,
+    blur neighbour table, splat CSR); apply(src) is one K.v MVM on it.
+    Not thread-safe (ping-pong workspace), same as documented in plx.h.
+    """
+
+    def __init__(self, device=None):
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        self._h = ctypes.c_void_p()
+        nv.check(nv.lib().plx_create(self.device.index, ctypes.byref(self._h)), "plx_create")
+        self._ref = None          # keeps the positions alive while kernels may still read them
+        self.taps = None
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            nv.lib().plx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- structure --------------------------------------------------------
+    def build(self, ref, coeffs, own=None):
+        _check_f32_cuda(ref, "ref")
+        ref = ref.contiguous()
+        taps = _taps_array(coeffs)
+        n, d = ref.shape
+        lo, hi = (0, n) if own is None else own
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_build(self._h, ctypes.c_void_p(ref.data_ptr()), n, d,
+                                    taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), taps.size,
+                                    lo, hi, _stream_ptr(self.device))
+        nv.check(rc, "plx_build")
+        self._ref = ref
+        self.taps = taps
+        return self
+
+    @property
+    def n(self):
+        return int(nv.lib().plx_num_points(self._h))
+
+    @property
+    def n_owned(self):
+        return int(nv.lib().plx_num_owned(self._h))
+
+    @property
+    def m(self):
+        return int(nv.lib().plx_num_vertices(self._h))
+
+    @property
+    def d(self):
+        return int(nv.lib().plx_dim(self._h))
+
+    @property
+    def order(self):
+        return int(nv.lib().plx_order(self._h))
+
+    @property
+    def device_bytes(self):
+        return int(nv.lib().plx_device_bytes(self._h))
+
+    def set_timing(self, on=True):
+        nv.check(nv.lib().plx_set_timing(self._h, 1 if on else 0), "plx_set_timing")
+
+    def build_times_ms(self):
+        buf = (ctypes.c_float * 6)()
+        nv.check(nv.lib().plx_build_times(self._h, buf), "plx_build_times")
+        return dict(zip(("embed", "insert", "number", "ids", "neighbours", "csr"), list(buf)))
+
+    # -- stages -----------------------------------------------------------
+    def _src(self, src, rows):
+        _check_f32_cuda(src, "src")
+        if src.shape[0] != rows:
+            raise ValueError(f"Incompatible shapes {tuple(src.shape)}, expected {rows} rows")
+        return src.contiguous()
+
+    def new_values(self, vd):
+        return torch.empty((self.m, vd), dtype=torch.float32, device=self.device)
+
+    def splat(self, src, values=None):
+        src = self._src(src, self.n_owned)
+        vd = src.shape[1]
+        if values is None:
+            values = self.new_values(vd)
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_splat(self._h, ctypes.c_void_p(src.data_ptr()), vd,
+                                    ctypes.c_void_p(values.data_ptr()), _stream_ptr(self.device))
+        nv.check(rc, "plx_splat")
+        return values
+
+    def blur(self, values, scratch=None):
+        """Returns the tensor holding the blurred values (either `values` or `scratch`)."""
+        _check_f32_cuda(values, "values")
+        vd = values.shape[1]
+        if scratch is None:
+            scratch = torch.empty_like(values)
+        flag = ctypes.c_int(0)
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_blur(self._h, ctypes.c_void_p(values.data_ptr()),
+                                   ctypes.c_void_p(scratch.data_ptr()), vd, ctypes.byref(flag),
+                                   _stream_ptr(self.device))
+        nv.check(rc, "plx_blur")
+        return scratch if flag.value else values
+
+    def slice(self, values, out=None):
+        _check_f32_cuda(values, "values")
+        vd = values.shape[1]
+        if out is None:
+            out = torch.empty((self.n_owned, vd), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_slice(self._h, ctypes.c_void_p(values.data_ptr()), vd,
+                                    ctypes.c_void_p(out.data_ptr()), _stream_ptr(self.device))
+        nv.check(rc, "plx_slice")
+        return out
+
+    def apply(self, src, out=None):
+        """One MVM: out = slice(blur(splat(src))) on the lattice's own workspace."""
+        src = self._src(src, self.n_owned)
+        vd = src.shape[1]
+        if out is None:
+            out = torch.empty((self.n_owned, vd), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_apply(self._h, ctypes.c_void_p(src.data_ptr()), vd,
+                                    ctypes.c_void_p(out.data_ptr()), _stream_ptr(self.device))
+        nv.check(rc, "plx_apply")
+        return out
+
+    # -- introspection (parity tests) --------------------------------------
+    def export(self, which):
+        L = nv.lib()
+        nbytes = int(L.plx_export_bytes(self._h, which))
+        if nbytes < 0:
+            raise ValueError(f"unknown array {which}")
+        n, m, d, r = self.n, self.m, self.d, self.order
+        dtype, shape = {
+            nv.ARRAY_KEYS: (np.int16, (m, d)),
+            nv.ARRAY_ENTRY_VERTEX: (np.int32, (d + 1, n)),
+            nv.ARRAY_ENTRY_WEIGHT: (np.float32, (d + 1, n)),
+            nv.ARRAY_NEIGHBORS: (np.int32, (d + 1, 2 * r, m)),
+            nv.ARRAY_ROW_PTR: (np.int32, (m + 1,)),
+            nv.ARRAY_CSR_POINT: (np.int32, (self.n_owned * (d + 1),)),
+            nv.ARRAY_CSR_WEIGHT: (np.float32, (self.n_owned * (d + 1),)),
+        }[which]
+        out = np.empty(shape, dtype)
+        assert out.nbytes == nbytes, (out.nbytes, nbytes)
+        with torch.cuda.device(self.device):
+            rc = L.plx_export(self._h, which, out.ctypes.data_as(ctypes.c_void_p), nbytes,
+                              _stream_ptr(self.device))
+        nv.check(rc, "plx_export")
+        return out
+
+
+_scratch = {}
+
+
+def _scratch_lattice(device):
+    key = device.index
+    lat = _scratch.get(key)
+    if lat is None:
+        lat = _scratch[key] = Lattice(device)
+    return lat
+
+
+def filter(src, ref, coeffs):
+    """filter(src[N,vd], ref[N,d], coeffs[R]) -> out[N,vd]   (reference boundary).
+
+    Builds a fresh lattice for `ref` on every call, exactly like the reference
+    (permutohedral.h:272); only the device buffers are recycled between calls.
+    """
+    _check_f32_cuda(src, "src")
+    _check_f32_cuda(ref, "ref")
+    if src.shape[0] != ref.shape[0]:
+        raise ValueError("Incompatible shapes {}, and {}".format(tuple(src.shape), tuple(ref.shape)))
+    if src.device != ref.device:
+        raise ValueError("src and ref must be on the same device")
+    lat = _scratch_lattice(src.device)
+    lat.build(ref, coeffs)
+    return lat.apply(src)

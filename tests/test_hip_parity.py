@@ -1,0 +1,232 @@
+"""HIP path vs the CPU oracle and the reference goldens (needs an MI355X).
+
+Everything goes through the C ABI (simplex_gp_amd._native -> libplx.so).
+Bars:
+  * structure (keys, vertex ids, weights, neighbour table, m): bit-exact against
+    the duplicate-free oracle (oracle exact_mode=False; the reference's
+    stale-bucket quirk, h:105 vs h:61-63, is documented in DESIGN.md);
+  * floating point: rel-L2 <= 1e-5 against the oracle stage by stage, and
+    <= 1e-4 against the reference's own output (north_star tolerance) wherever
+    the reference quirk itself stays below that.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle  # noqa: E402  (checker only)
+
+TOL_ORACLE = 1e-5      # HIP vs duplicate-free oracle, rel-L2
+TOL_REFERENCE = 1e-4   # HIP vs reference output, rel-L2 (BASELINE.json north_star)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    nb = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (nb if nb > 0 else 1.0)
+
+
+@pytest.fixture(scope="module")
+def plx():
+    import simplex_gp_amd as plx
+    assert torch.cuda.is_available()
+    return plx
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    z = np.load(os.path.join(golden_dir, "filter_small.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    return z, names
+
+
+def _clean_oracle(ref, taps):
+    oracle.set_exact_mode(False)
+    try:
+        return oracle.Lattice(ref, taps)
+    finally:
+        oracle.set_exact_mode(True)
+
+
+def test_structure_bit_exact(plx, small):
+    z, names = small
+    from simplex_gp_amd import _native as nv
+    lat = plx.Lattice()
+    for name in names:
+        ref, taps = z[f"{name}/ref"], z[f"{name}/taps"]
+        o = _clean_oracle(ref, taps)
+        lat.build(torch.from_numpy(ref).cuda(), taps)
+        assert lat.m == o.m, name
+        assert np.array_equal(lat.export(nv.ARRAY_KEYS), o.keys), name
+        assert np.array_equal(lat.export(nv.ARRAY_ENTRY_VERTEX), o.entry_vertex.T), name
+        assert np.array_equal(lat.export(nv.ARRAY_ENTRY_WEIGHT), o.entry_weight.T), name
+        assert np.array_equal(lat.export(nv.ARRAY_NEIGHBORS), o.neighbors()), name
+        # CSR is a permutation of the corners, grouped by vertex
+        row_ptr = lat.export(nv.ARRAY_ROW_PTR)
+        counts = np.bincount(o.entry_vertex.reshape(-1), minlength=o.m)
+        assert np.array_equal(np.diff(row_ptr), counts), name
+        o.close()
+    lat.close()
+
+
+def test_stages_match_oracle(plx, small):
+    z, names = small
+    lat = plx.Lattice()
+    for name in names:
+        ref, taps, src = z[f"{name}/ref"], z[f"{name}/taps"], z[f"{name}/src"]
+        o = _clean_oracle(ref, taps)
+        lat.build(torch.from_numpy(ref).cuda(), taps)
+        s = torch.from_numpy(src).cuda()
+        v0 = lat.splat(s)
+        o_v0 = o.splat(src)
+        assert rel_l2(v0.cpu().numpy(), o_v0) <= TOL_ORACLE, name
+        v1 = lat.blur(torch.from_numpy(o_v0).cuda())
+        o_v1 = o.blur(o_v0)
+        assert rel_l2(v1.cpu().numpy(), o_v1) <= TOL_ORACLE, name
+        out = lat.slice(torch.from_numpy(o_v1).cuda())
+        assert rel_l2(out.cpu().numpy(), o.slice(o_v1)) <= TOL_ORACLE, name
+        o.close()
+    lat.close()
+
+
+def test_filter_vs_reference_goldens(plx, small):
+    """End to end through the reference boundary filter(src, ref, coeffs)."""
+    z, names = small
+    worst = 0.0
+    for name in names:
+        ref, taps, src, gold = (z[f"{name}/{k}"] for k in ("ref", "taps", "src", "out"))
+        out = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(),
+                         torch.from_numpy(taps)).cpu().numpy()
+        oracle.set_exact_mode(False)
+        clean = oracle.filter(src, ref, taps)
+        oracle.set_exact_mode(True)
+        assert rel_l2(out, clean) <= TOL_ORACLE, name
+        quirk = rel_l2(clean, gold)          # what the reference's hash-growth quirk alone costs
+        err = rel_l2(out, gold)
+        worst = max(worst, err if quirk <= 2e-5 else 0.0)
+        assert err <= max(TOL_REFERENCE, quirk + TOL_ORACLE), (name, err, quirk)
+        if quirk <= 2e-5:
+            assert err <= TOL_REFERENCE, (name, err)
+    print("worst rel-L2 vs reference goldens:", worst)
+
+
+@pytest.mark.parametrize("name", ["n1e5_d4_ell1.0", "n1e5_d4_ell0.25", "n1e5_d4_vd11_ell1.0",
+                                  "n1e6_d8_ell1.0", "n1e6_d8_ell0.6931"])
+def test_large_vs_reference_probes(plx, golden_dir, name):
+    """BASELINE.json config-2/3 shapes against probes of the reference output."""
+    z = np.load(os.path.join(golden_dir, "filter_large.npz"))
+    n, d, vd = (int(v) for v in z[f"{name}/shape"])
+    g = torch.Generator().manual_seed(int(z[f"{name}/seed"]))
+    x = torch.randn(n, d, generator=g)
+    v = torch.randn(n, vd, generator=g)
+    ref = (x / float(z[f"{name}/ell"])).contiguous()
+    assert np.array_equal(ref[:8].numpy(), z[f"{name}/ref_head"])
+    lat = plx.Lattice().build(ref.cuda(), z[f"{name}/taps"])
+    out = lat.apply(v.cuda()).cpu().numpy()
+    m_ref = int(z[f"{name}/m"])
+    # the reference appends at most one duplicate vertex per table doubling (quirk)
+    assert 0 <= m_ref - lat.m <= 12, (lat.m, m_ref)
+    stride = int(z[f"{name}/stride"])
+    head, strided = z[f"{name}/out_head"], z[f"{name}/out_strided"]
+    scale = float(z[f"{name}/out_l2"]) / np.sqrt(n * vd)          # rms of the reference output
+    # probes: error relative to the rms output level
+    e_head = np.linalg.norm(out[:512] - head) / (scale * np.sqrt(head.size))
+    e_str = np.linalg.norm(out[::stride] - strided) / (scale * np.sqrt(strided.size))
+    l2 = np.linalg.norm(out.astype(np.float64))
+    print(name, "m", lat.m, "m_ref", m_ref, "probe err", e_head, e_str, "l2 ratio", l2 / float(z[f"{name}/out_l2"]))
+    # full output against the duplicate-free oracle (the lattice the HIP path builds)
+    oracle.set_exact_mode(False)
+    clean, m_clean = oracle.filter(v.numpy(), ref.numpy(), z[f"{name}/taps"], return_m=True)
+    oracle.set_exact_mode(True)
+    assert lat.m == m_clean
+    err_clean = rel_l2(out, clean)
+    print(name, "rel-L2 vs duplicate-free oracle", err_clean)
+    assert err_clean <= TOL_ORACLE
+    # against the reference itself: 1e-4, except where the reference's own hash-growth
+    # quirk (one orphaned vertex per doubling) moves its output by more than that --
+    # measured with the oracle in both modes: 1.56e-4 and 1.95e-4 on these two inputs.
+    tol = 3e-4 if name in ("n1e5_d4_ell0.25", "n1e6_d8_ell0.6931") else TOL_REFERENCE
+    assert e_head <= tol and e_str <= tol
+    assert abs(l2 / float(z[f"{name}/out_l2"]) - 1) <= tol
+    lat.close()
+
+
+def test_full_size_properties(plx):
+    """N=1e6, d=8 (BASELINE.json metric shape): size-independent properties."""
+    n, d = 1_000_000, 8
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(n, d, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    lat = plx.Lattice().build(x, taps)
+    a = torch.randn(n, 1, generator=g).cuda()
+    b = torch.randn(n, 1, generator=g).cuda()
+    Ka, Kb = lat.apply(a).clone(), lat.apply(b).clone()
+    # determinism: same lattice, same input -> same bits
+    assert torch.equal(lat.apply(a), Ka)
+    # linearity
+    Kab = lat.apply(2.0 * a - 3.0 * b)
+    assert rel_l2(Kab.cpu().numpy(), (2.0 * Ka - 3.0 * Kb).cpu().numpy()) <= 1e-5
+    # multi-column == column by column
+    Kcat = lat.apply(torch.cat([a, b], 1))
+    assert rel_l2(Kcat[:, :1].cpu().numpy(), Ka.cpu().numpy()) <= 1e-6
+    assert rel_l2(Kcat[:, 1:].cpu().numpy(), Kb.cpu().numpy()) <= 1e-6
+    # splat conserves mass: sum_v (S^T 1)_v = n  (barycentric weights sum to 1)
+    ones = torch.ones(n, 1, device="cuda")
+    assert abs(lat.splat(ones).double().sum().item() / n - 1) <= 1e-5
+    # approximate symmetry of K: <a, K b> ~ <K a, b>   (viz_mvm.ipynb:150 reports 2e-2 asymmetry)
+    lhs, rhs = (a * Kb).sum().item(), (Ka * b).sum().item()
+    assert abs(lhs - rhs) <= 0.05 * max(abs(lhs), abs(rhs))
+    # rebuilding on the same handle gives the same lattice and the same bits
+    m0 = lat.m
+    lat.build(x, taps)
+    assert lat.m == m0 and torch.equal(lat.apply(a), Ka)
+    lat.close()
+
+
+def test_boundary_errors(plx):
+    src = torch.randn(10, 2).cuda()
+    ref = torch.randn(10, 3).cuda()
+    taps = torch.tensor([0.5, 1.0, 0.5])
+    with pytest.raises(ValueError):
+        plx.filter(src[:5], ref, taps)                       # row mismatch (py:84-85)
+    with pytest.raises(TypeError):
+        plx.filter(src.double(), ref, taps)                  # CPU path is fp32 only (h:277-278)
+    with pytest.raises(ValueError):
+        plx.filter(src.cpu(), ref.cpu(), taps)               # no CPU fallback
+    with pytest.raises(ValueError):
+        plx.filter(src, ref, torch.tensor([0.5, 1.0]))       # even tap count
+    from simplex_gp_amd._native import PlxError
+    with pytest.raises(PlxError):
+        plx.filter(src, ref * 1e6, taps)                     # int16 key overflow is an error, not UB
+    with pytest.raises(PlxError):
+        plx.filter(src, torch.full_like(ref, float("nan")), taps)
+    # non-contiguous src is accepted (py:95 passes it as is)
+    big = torch.randn(10, 4).cuda()
+    out = plx.filter(big[:, ::2], ref, taps)
+    assert rel_l2(out.cpu().numpy(), oracle.filter(big[:, ::2].cpu().numpy(), ref.cpu().numpy(), taps.numpy())) <= 1e-5
+    # the handle survives an error
+    out2 = plx.filter(src, ref, taps)
+    assert torch.isfinite(out2).all()
+
+
+def test_orders_and_dims(plx):
+    """Every compiled dimension builds; taps of order 0..4."""
+    rng = np.random.default_rng(0)
+    for d in list(range(1, 33)):
+        n = 300
+        ref = rng.standard_normal((n, d)).astype(np.float32)
+        src = rng.standard_normal((n, 2)).astype(np.float32)
+        taps = np.array([0.3, 1.0, 0.3], np.float32)
+        out = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), taps).cpu().numpy()
+        assert rel_l2(out, oracle.filter(src, ref, taps)) <= TOL_ORACLE, d
+    ref = rng.standard_normal((500, 3)).astype(np.float32) * 2
+    src = rng.standard_normal((500, 5)).astype(np.float32)
+    for taps in ([1.0], [0.5, 1, 0.5], [0.1, 0.5, 1, 0.5, 0.1], [0.02, 0.17, 0.64, 1, 0.64, 0.17, 0.02],
+                 [0.01, 0.05, 0.2, 0.6, 1, 0.6, 0.2, 0.05, 0.01]):
+        taps = np.array(taps, np.float32)
+        out = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), taps).cpu().numpy()
+        assert rel_l2(out, oracle.filter(src, ref, taps)) <= TOL_ORACLE, len(taps)
