@@ -141,11 +141,22 @@ int plx_export(plx_lattice *lat, int which, void *h_dst, int64_t bytes, void *st
 /* size in bytes of an exportable array, or -1 */
 int64_t plx_export_bytes(const plx_lattice *lat, int which);
 
+/* Select a kernel variant by name (process-wide; for A/B measurements in one
+ * process -- the defaults are the shipped configuration).  Keys: "splat_impl"
+ * (0 row loop, 1 segmented scan), "blur_vpt" (vertices per thread at vd=1: 1, 2, 4),
+ * "slice_impl" (0 runtime loop, 1 unrolled). */
+int plx_tune(const char *key, int value);
+
 /* Per-stage device time of the last plx_build on this lattice, in ms, in the
  * order {embed, insert, number, ids, neighbours, csr}; 0 when timing is off.
  * plx_set_timing(lat, 1) turns hipEvent timing on (adds event records only). */
 int plx_set_timing(plx_lattice *lat, int on);
 int plx_build_times(const plx_lattice *lat, float *h_ms6);
+/* Per-launch device time of the last plx_apply (timing on), in ms, in launch
+ * order {splat, splat_fixup, blur axis 0..d, slice}: d+4 numbers.  Each is the
+ * hipEvent interval from the end of the previous launch to the end of this one
+ * on the apply stream.  Synchronises on the last event. */
+int plx_apply_times(plx_lattice *lat, float *h_ms, int cap, int *count);
 
 #ifdef __cplusplus
 }

@@ -46,8 +46,10 @@ _SIGNATURES = {
     "plx_filter": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32p, _i32, _vp, _vp]),
     "plx_export": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "plx_export_bytes": (_i64, [_vp, _i32]),
+    "plx_tune": (_i32, [ctypes.c_char_p, _i32]),
     "plx_set_timing": (_i32, [_vp, _i32]),
     "plx_build_times": (_i32, [_vp, _f32p]),
+    "plx_apply_times": (_i32, [_vp, _f32p, _i32, ctypes.POINTER(_i32)]),
 }
 
 

@@ -40,7 +40,7 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
     return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
             &L->sort_keys_in, &L->sort_keys_out, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_w, &L->row_ptr,
-            &L->chunk_first, &L->chunk_last, &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b};
+            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b};
 }
 
 struct DeviceGuard {
@@ -92,6 +92,8 @@ int plx_create(int device, plx_lattice **out)
     }
     for (auto &e : L->ev)
         if (hipEventCreate(&e) != hipSuccess) { set_error("plx_create: hipEventCreate failed"); return PLX_ERR_HIP; }
+    for (auto &e : L->tev)
+        if (hipEventCreate(&e) != hipSuccess) { set_error("plx_create: hipEventCreate failed"); return PLX_ERR_HIP; }
     *out = L;
     return PLX_OK;
 }
@@ -103,6 +105,7 @@ void plx_destroy(plx_lattice *L)
     for (DevBuf *b : all_bufs(L)) release(*b);
     if (L->h_pinned) (void)hipHostFree(L->h_pinned);
     for (auto &e : L->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : L->tev) if (e) (void)hipEventDestroy(e);
     delete L;
 }
 
@@ -190,6 +193,8 @@ int plx_apply(plx_lattice *L, const float *d_src, int vd, float *d_out, void *st
     PLX_TRY(ensure(L->val_a, (size_t)L->m * vd * 4));
     PLX_TRY(ensure(L->val_b, (size_t)L->m * vd * 4));
     hipStream_t s = (hipStream_t)stream;
+    L->tev_n = 0;
+    tmark(L, s);
     PLX_TRY(splat_impl(L, d_src, vd, L->val_a.as<float>(), s));
     int in_b = 0;
     PLX_TRY(blur_impl(L, L->val_a.as<float>(), L->val_b.as<float>(), vd, &in_b, s));
@@ -264,17 +269,45 @@ int plx_export(plx_lattice *L, int which, void *h_dst, int64_t bytes, void *stre
     case PLX_ARRAY_ENTRY_VERTEX: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->evid.p, bytes, hipMemcpyDeviceToHost, s)); break;
     case PLX_ARRAY_ENTRY_WEIGHT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->ew.p, bytes, hipMemcpyDeviceToHost, s)); break;
     case PLX_ARRAY_ROW_PTR: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->row_ptr.p, bytes, hipMemcpyDeviceToHost, s)); break;
-    case PLX_ARRAY_CSR_POINT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_pt.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    case PLX_ARRAY_CSR_POINT: {
+        PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_pt.p, bytes, hipMemcpyDeviceToHost, s));
+        PLX_HIP_TRY(hipStreamSynchronize(s));
+        int32_t *dst = (int32_t *)h_dst;   // strip the segment-head flag kept in the sign bit
+        for (int64_t i = 0; i < bytes / 4; ++i) dst[i] &= 0x7FFFFFFF;
+        return PLX_OK;
+    }
     case PLX_ARRAY_CSR_WEIGHT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_w.p, bytes, hipMemcpyDeviceToHost, s)); break;
     }
     PLX_HIP_TRY(hipStreamSynchronize(s));
     return PLX_OK;
 }
 
+int plx_tune(const char *key, int value)
+{
+    if (!key) return PLX_ERR_INVALID;
+    for (Tunable *t = tunables(); t->name; ++t)
+        if (strcmp(t->name, key) == 0) { *t->value = value; return PLX_OK; }
+    set_error("plx_tune: unknown key %s", key);
+    return PLX_ERR_INVALID;
+}
+
 int plx_set_timing(plx_lattice *L, int on)
 {
     if (!L) return PLX_ERR_INVALID;
     L->timing = on != 0;
+    return PLX_OK;
+}
+
+int plx_apply_times(plx_lattice *L, float *h_ms, int cap, int *count)
+{
+    if (!L || !h_ms || !count) return PLX_ERR_INVALID;
+    *count = 0;
+    if (!L->timing || L->tev_n < 2) return PLX_OK;
+    DeviceGuard g(L->device);
+    PLX_HIP_TRY(hipEventSynchronize(L->tev[L->tev_n - 1]));
+    const int k = L->tev_n - 1;
+    for (int i = 0; i < k && i < cap; ++i) PLX_HIP_TRY(hipEventElapsedTime(&h_ms[i], L->tev[i], L->tev[i + 1]));
+    *count = k < cap ? k : cap;
     return PLX_OK;
 }
 

@@ -430,24 +430,22 @@ __global__ __launch_bounds__(kBlock) void csr_finalize_kernel(const uint32_t *__
                                                               int own_begin, int nnz, int m,
                                                               int *__restrict__ csr_pt,
                                                               float *__restrict__ csr_w,
-                                                              int *__restrict__ row_ptr,
-                                                              int *__restrict__ chunk_first,
-                                                              int *__restrict__ chunk_last)
+                                                              int *__restrict__ row_ptr)
 {
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= nnz) return;
     const uint32_t v = skeys[k];
     const uint32_t idx = svals[k];
     const uint32_t r = idx / (uint32_t)n;
-    csr_pt[k] = (int)(idx - r * (uint32_t)n) - own_begin;
-    csr_w[k] = ew[idx];
     // row_ptr[u] = first k with skeys[k] >= u; rows no owned point touches are empty
     const int prev = (k == 0) ? -1 : (int)skeys[k - 1];
+    // sign bit of csr_pt marks the first entry of a vertex row (segment head)
+    const uint32_t head = (prev != (int)v) ? 0x80000000u : 0u;
+    csr_pt[k] = (int)(((idx - r * (uint32_t)n) - (uint32_t)own_begin) | head);
+    csr_w[k] = ew[idx];
     for (int u = prev + 1; u <= (int)v; ++u) row_ptr[u] = k;
     if (k == nnz - 1)
         for (int u = (int)v + 1; u <= m; ++u) row_ptr[u] = nnz;
-    if (k % kSplatChunk == 0) chunk_first[k / kSplatChunk] = (int)v;
-    if (k % kSplatChunk == kSplatChunk - 1 || k == nnz - 1) chunk_last[k / kSplatChunk] = (int)v;
 }
 
 // ----------------------------------------------------------------------------
@@ -532,10 +530,8 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4));
     PLX_TRY(ensure(L->nbr, (size_t)D1 * 2 * order * L->mstride * 4 + 4));
     PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
-    PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 4));
-    PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 4));
-    PLX_TRY(ensure(L->chunk_first, (size_t)L->nchunks * 4 + 4));
-    PLX_TRY(ensure(L->chunk_last, (size_t)L->nchunks * 4 + 4));
+    PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
+    PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
 
     assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->blockcnt.as<int>(),
                                                      L->eslot.as<uint32_t>(), L->ekeys.as<uint32_t>(), n,
@@ -570,7 +566,7 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
         csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
             L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
             (int)L->own_begin, (int)L->nnz, m, L->csr_pt.as<int>(), L->csr_w.as<float>(),
-            L->row_ptr.as<int>(), L->chunk_first.as<int>(), L->chunk_last.as<int>());
+            L->row_ptr.as<int>());
     } else {
         PLX_HIP_TRY(hipMemsetAsync(L->row_ptr.p, 0, (size_t)(m + 1) * 4, stream));
     }

@@ -67,7 +67,8 @@ struct plx_lattice {
     plx::DevBuf blockcnt;   // int32  [nblocks+1]    per-workgroup first-touch counts, then offsets
     plx::DevBuf table;      // uint32 [capacity]     slot -> min entry index, later slot -> vertex id
     plx::DevBuf counters;   // int32  [8]            {m, error flag, ...}
-    plx::DevBuf sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp;
+    plx::DevBuf sort_keys_in, sort_vals_in, sort_vals_out, sort_temp;
+    plx::DevBuf sort_keys_out;   // int32 [nnz] sorted vertex id of every owned corner (kept: splat reads it at row ends)
 
     // structure
     plx::DevBuf vkeys;      // uint32 [m][DW]        packed vertex keys, first-touch order
@@ -77,7 +78,6 @@ struct plx_lattice {
     plx::DevBuf csr_pt;     // int32  [nnz]          local (owned) point index, sorted by vertex
     plx::DevBuf csr_w;      // float  [nnz]
     plx::DevBuf row_ptr;    // int32  [m+1]
-    plx::DevBuf chunk_first, chunk_last;   // int32 [nchunks]
 
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
@@ -85,6 +85,9 @@ struct plx_lattice {
 
     int32_t *h_pinned = nullptr;   // pinned host staging for {m, err}
     hipEvent_t ev[8] = {};
+    // per-launch timing of plx_apply (timing on): events between consecutive launches
+    hipEvent_t tev[PLX_MAX_DIM + 8] = {};
+    int tev_n = 0;
 };
 
 namespace plx {
@@ -104,6 +107,17 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
 int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream);
+
+// record the next apply-timing event (no-op unless timing is on)
+inline void tmark(plx_lattice *L, hipStream_t stream)
+{
+    if (L->timing && L->tev_n < (int)(sizeof(L->tev) / sizeof(L->tev[0])))
+        (void)hipEventRecord(L->tev[L->tev_n++], stream);
+}
+
+// kernel-variant switches for in-process A/B runs (plx_tune); defaults are the shipped choice
+struct Tunable { const char *name; int *value; };
+Tunable *tunables();
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -116,6 +116,17 @@ class Lattice:
         nv.check(nv.lib().plx_build_times(self._h, buf), "plx_build_times")
         return dict(zip(("embed", "insert", "number", "ids", "neighbours", "csr"), list(buf)))
 
+    def apply_times_ms(self):
+        """Per-launch times of the last apply(): dict(splat, splat_fixup, blur=[d+1], slice)."""
+        cap = nv.MAX_DIM + 8
+        buf = (ctypes.c_float * cap)()
+        cnt = ctypes.c_int(0)
+        nv.check(nv.lib().plx_apply_times(self._h, buf, cap, ctypes.byref(cnt)), "plx_apply_times")
+        t = list(buf)[:cnt.value]
+        if len(t) != self.d + 4:
+            return None
+        return {"splat": t[0], "splat_fixup": t[1], "blur": t[2:2 + self.d + 1], "slice": t[-1]}
+
     # -- stages -----------------------------------------------------------
     def _src(self, src, rows):
         _check_f32_cuda(src, "src")
