@@ -5,5 +5,20 @@ RBFLattice, MaternLattice (+ BilateralKernel), plus the native boundary
 `filter(src, ref, coeffs)` and the staged `Lattice` handle.
 """
 from .lattice import Lattice, filter  # noqa: F401
+from .lattice_kernel import (  # noqa: F401
+    BilateralKernel,
+    LatticeAccelerated,
+    LatticeFilterGeneral,
+    MaternLattice,
+    RBFLattice,
+    RectangularLazyLattice,
+    SquareLazyLattice,
+    lattice_cache,
+)
+from .stencil import DiscretizedKernelFN, Matern, get_coeffs, matern, rbf  # noqa: F401
 
-__all__ = ["Lattice", "filter"]
+__all__ = [
+    "RBFLattice", "MaternLattice", "BilateralKernel", "LatticeAccelerated", "LatticeFilterGeneral",
+    "SquareLazyLattice", "RectangularLazyLattice", "DiscretizedKernelFN", "get_coeffs", "rbf", "matern",
+    "Matern", "Lattice", "filter", "lattice_cache",
+]

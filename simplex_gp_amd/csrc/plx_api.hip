@@ -166,6 +166,8 @@ static int check_apply(const plx_lattice *L, const void *a, const void *b, int v
 
 int plx_splat(plx_lattice *L, const float *d_src, int vd, float *d_values, void *stream)
 {
+    // a rank that owns no rows has no source block: only the accumulator is required
+    if (L && L->built && L->own_end == L->own_begin && !d_src) d_src = d_values;
     PLX_TRY(check_apply(L, d_src, d_values, vd, "plx_splat"));
     DeviceGuard g(L->device);
     return splat_impl(L, d_src, vd, d_values, (hipStream_t)stream);
@@ -181,6 +183,7 @@ int plx_blur(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *res
 
 int plx_slice(plx_lattice *L, const float *d_values, int vd, float *d_out, void *stream)
 {
+    if (L && L->built && L->own_end == L->own_begin && !d_out) d_out = const_cast<float *>(d_values);
     PLX_TRY(check_apply(L, d_values, d_out, vd, "plx_slice"));
     DeviceGuard g(L->device);
     return slice_impl(L, d_values, vd, d_out, (hipStream_t)stream);

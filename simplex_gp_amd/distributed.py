@@ -1,0 +1,93 @@
+"""Point-sharded K.v over the GPUs of one node (new work, the
+reference has no multi-GPU code).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The
+N points are split into contiguous row blocks, one per rank.
+
+    build   every rank builds the lattice from ALL positions (same vertex
+            numbering on every rank: ids are the deterministic first-touch
+            order), but its splat CSR / slice tables cover only its own rows
+    splat   own rows -> full-size vertex accumulator values[m, vd]
+    exchange ONE all-reduce (sum) of values over the group: the only collective
+            on the data path; message = m * vd * 4 bytes
+    blur    replicated on every rank
+    slice   own rows
+
+Output rows stay sharded; reductions over points (CG dot products) use
+`all_reduce_sum` below.  The lattice object is duck-typed (build / new_values /
+splat / blur / slice / m), so the choreography is testable on CPU with gloo.
+"""
+import torch
+import torch.distributed as dist
+
+from .lattice import Lattice
+
+
+def shard_bounds(n, world_size, rank):
+    """Contiguous near-equal row blocks: the first n % world ranks get one extra row."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_reduce_sum(t, group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class ShardedLatticeMVM:
+    """K(ref_all) @ v with v and the result sharded by rows over the group."""
+
+    def __init__(self, ref_all, coeffs, group=None, lattice=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n = ref_all.shape[0]
+        self.lo, self.hi = shard_bounds(self.n, self.world, self.rank)
+        self.lattice = lattice if lattice is not None else Lattice(ref_all.device)
+        self.lattice.build(ref_all, coeffs, own=(self.lo, self.hi))
+        self._vd = None
+        self._values = self._scratch = None
+
+    @property
+    def m(self):
+        return self.lattice.m
+
+    def local_rows(self, t):
+        """The rows of a full-size tensor that this rank owns."""
+        return t[self.lo:self.hi]
+
+    def _workspace(self, vd):
+        if self._vd != vd:
+            self._values = self.lattice.new_values(vd)
+            self._scratch = self.lattice.new_values(vd)
+            self._vd = vd
+        return self._values, self._scratch
+
+    def matmul(self, v_local, out=None):
+        if v_local.shape[0] != self.hi - self.lo:
+            raise ValueError(f"rank {self.rank} owns rows [{self.lo}, {self.hi}) but got {v_local.shape[0]} rows")
+        squeeze = v_local.dim() == 1
+        if squeeze:
+            v_local = v_local.unsqueeze(-1)
+        values, scratch = self._workspace(v_local.shape[1])
+        self.lattice.splat(v_local, values)
+        all_reduce_sum(values, self.group)               # the one exchange step
+        blurred = self.lattice.blur(values, scratch)
+        res = self.lattice.slice(blurred, out)
+        return res.squeeze(-1) if squeeze else res
+
+    __call__ = matmul
+
+    def gather_rows(self, t_local):
+        """All ranks' row blocks concatenated (for tests / small outputs)."""
+        if self.world == 1:
+            return t_local
+        rows = [hi - lo for lo, hi in (shard_bounds(self.n, self.world, r) for r in range(self.world))]
+        biggest = max(rows)          # all_gather wants equal shapes: pad the short blocks
+        padded = torch.zeros((biggest,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
+        padded[: t_local.shape[0]] = t_local
+        parts = [torch.empty_like(padded) for _ in rows]
+        dist.all_gather(parts, padded, group=self.group)
+        return torch.cat([p[:k] for p, k in zip(parts, rows)], 0)

@@ -1,0 +1,217 @@
+"""Operator surface: the autograd op and the GPyTorch-facing kernel classes.
+
+Mirrors gpytorch_lattice_kernel/bilateral_kernel.py (same names, constructor
+arguments, shapes and error behaviour):
+    LatticeFilterGeneral      py:59-124    forward = one filter, backward = one wider filter
+    SquareLazyLattice         py:127-140   RectangularLazyLattice   py:142-160
+    LatticeAccelerated        py:183-200
+    RBFLattice / BilateralKernel / MaternLattice   py:247-254
+
+What differs on purpose: the native call goes to libplx (HIP, gfx950) through
+the C ABI, and the lattice built for a given (positions, taps) pair is kept and
+reused by every later MVM on the same positions (all CG iterations call
+_matmul with the same x / lengthscale tensor), instead of being rebuilt inside
+every filter call (permutohedral.h:272).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from .gp_compat import Kernel, LazyTensor
+from .lattice import Lattice, _taps_array
+from .stencil import DiscretizedKernelFN, Matern, rbf
+
+
+class _LatticeCache:
+    """Small LRU of built lattices keyed on the position tensor and the taps.
+
+    An entry holds a reference to its position tensor, so the allocator cannot
+    hand the same address to different data while the entry lives; together
+    with tensor._version that makes (data_ptr, _version, shape, taps) a sound key.
+    """
+
+    def __init__(self, capacity=4):
+        self.capacity = capacity
+        self._entries = OrderedDict()
+        self.hits = 0
+        self.misses = 0
+
+    @staticmethod
+    def _key(ref, taps):
+        return (ref.device.index, ref.data_ptr(), ref._version, tuple(ref.shape), taps.tobytes())
+
+    def get(self, ref, coeffs):
+        taps = _taps_array(coeffs)
+        key = self._key(ref, taps)
+        hit = self._entries.get(key)
+        if hit is not None:
+            self._entries.move_to_end(key)
+            self.hits += 1
+            return hit[0]
+        self.misses += 1
+        if len(self._entries) >= self.capacity:
+            _, (old, _) = self._entries.popitem(last=False)
+            lat = old                      # recycle the device buffers of the evicted lattice
+        else:
+            lat = Lattice(ref.device)
+        lat.build(ref, taps)
+        self._entries[key] = (lat, ref)
+        return lat
+
+    def clear(self):
+        for lat, _ in self._entries.values():
+            lat.close()
+        self._entries.clear()
+
+
+_cache = _LatticeCache()
+
+
+def lattice_cache():
+    return _cache
+
+
+def cached_filter(src, ref, coeffs):
+    """filter(src, ref, coeffs) with the lattice for (ref, coeffs) reused when
+    the same position tensor comes back (the CG loop, the backward pass)."""
+    if not (isinstance(src, torch.Tensor) and src.is_cuda):
+        raise ValueError("simplex_gp_amd has no CPU path: tensors must live on an MI355X (cuda) device")
+    if src.dtype != torch.float32 or ref.dtype != torch.float32:
+        raise TypeError(f"float32 only (got src {src.dtype}, ref {ref.dtype}); the reference CPU path is fp32 (h:277-278)")
+    lat = _cache.get(ref.contiguous() if not ref.is_contiguous() else ref, coeffs)
+    return lat.apply(src)
+
+
+class LatticeFilterGeneral(Function):
+    """out = K(reference) @ source, K the lattice approximation of the kernel
+    whose taps come from `kernel_fn` (a DiscretizedKernelFN).
+
+    `method` is the native filter used, as in the reference (py:60, py:94-95):
+    None selects the HIP path; tests may install another callable with the
+    reference's filter(src, ref, coeffs) signature.
+    """
+
+    method = None
+
+    @staticmethod
+    def _filter():
+        return LatticeFilterGeneral.method if LatticeFilterGeneral.method is not None else cached_filter
+
+    @staticmethod
+    def forward(ctx, source, reference, kernel_fn):
+        assert source.shape[0] == reference.shape[0], \
+            "Incompatible shapes {}, and {}".format(source.shape, reference.shape)
+        coeffs = kernel_fn.get_coeffs()
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(source, reference)
+            ctx.coeffs = coeffs
+            ctx.deriv_coeffs = kernel_fn.get_deriv_coeffs()
+        return LatticeFilterGeneral._filter()(source, reference.contiguous(), coeffs)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        filt = LatticeFilterGeneral._filter()
+        grad_source = grad_reference = None
+        with torch.no_grad():
+            src, ref = ctx.saved_tensors
+            g = grad_output
+            L = src.shape[-1]
+            d = ref.shape[-1]
+            if ctx.needs_input_grad[0] and not ctx.needs_input_grad[1]:
+                # K is treated as symmetric (py:110-111)
+                grad_source = filt(g.contiguous(), ref.contiguous(), ctx.coeffs)
+            if ctx.needs_input_grad[1]:
+                # one filter with the derivative taps over [g, g (x) x, src, src (x) x]   (py:113-119)
+                gx = (g[..., None] * ref[..., None, :])          # n x L x d
+                sx = (src[..., None] * ref[..., None, :])
+                stacked = torch.cat([g, gx.reshape(gx.shape[:-2] + (L * d,)),
+                                     src, sx.reshape(sx.shape[:-2] + (L * d,))], dim=-1)
+                filtered = filt(stacked.contiguous(), ref.contiguous(), ctx.deriv_coeffs)
+                wg, wgx, ws, wsx = torch.split(filtered, [L, L * d, L, L * d], dim=-1)
+                wgx = wgx.reshape(-1, L, d)
+                wsx = wsx.reshape(-1, L, d)
+                # py:122
+                grad_reference = -2 * (sx * wg[..., None] - src[..., None] * wgx
+                                       + gx * ws[..., None] - g[..., None] * wsx).sum(-2)
+                if ctx.needs_input_grad[0]:
+                    grad_source = wg       # filtered with the derivative taps, as the reference does (py:123)
+        return grad_source, grad_reference, None
+
+
+class SquareLazyLattice(LazyTensor):
+    """K(x, x) known through matmul only (py:127-140)."""
+
+    def __init__(self, x, dkernel=None):
+        super().__init__(x, dkernel=dkernel)
+        self.x = x
+        self.dkernel = dkernel
+
+    def _matmul(self, V):
+        return LatticeFilterGeneral.apply(V, self.x, self.dkernel)
+
+    def _size(self):
+        return torch.Size((self.x.shape[-2], self.x.shape[-2]))
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def diag(self):
+        return torch.ones_like(self.x[..., 0])
+
+
+class RectangularLazyLattice(LazyTensor):
+    """K(xin, xout): one square filter over the union of the two point sets
+    with the right-hand side zero-padded (py:142-160)."""
+
+    def __init__(self, xin, xout, dkernel=None):
+        super().__init__(xin, xout, dkernel=dkernel)
+        self.xin = xin
+        self.xout = xout
+        self.dkernel = dkernel
+
+    def _matmul(self, V):
+        n = V.shape[-2]
+        assert n == self.xout.shape[-2], f"mismatched shapes? {V.shape, self.xout.shape}"
+        x_large = torch.cat([self.xout, self.xin], dim=-2)
+        V_large = torch.zeros(*V.shape[:-2], x_large.shape[-2], V.shape[-1], device=V.device, dtype=V.dtype)
+        V_large[..., :n, :] += V
+        return LatticeFilterGeneral.apply(V_large, x_large, self.dkernel)[..., n:, :]
+
+    def _size(self):
+        return torch.Size((*self.xin.shape[:-1], self.xout.shape[-2]))
+
+    def _transpose_nonbatch(self):
+        return RectangularLazyLattice(self.xout, self.xin, self.dkernel)
+
+
+class LatticeAccelerated(Kernel):
+    """A stationary kernel, given as a differentiable profile in squared
+    distance, evaluated through the permutohedral lattice (py:183-200)."""
+
+    has_lengthscale = True
+
+    def __init__(self, kernel_fn, *args, order=2, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.dkernel_fn = DiscretizedKernelFN(kernel_fn, order)
+
+    def forward(self, x1, x2, diag=False, **params):
+        if diag:
+            return torch.ones_like(x1[..., 0])
+        same = x1 is x2 or (x1.shape == x2.shape and (x1.data_ptr() == x2.data_ptr() or bool(x1.eq(x2).all())))
+        if same:
+            return SquareLazyLattice(x1.div(self.lengthscale), self.dkernel_fn)
+        return RectangularLazyLattice(x1.div(self.lengthscale), x2.div(self.lengthscale), self.dkernel_fn)
+
+
+def RBFLattice(*args, order=2, **kwargs):
+    return LatticeAccelerated(rbf, *args, order=order, **kwargs)
+
+
+def BilateralKernel(*args, **kwargs):
+    return RBFLattice(*args, **kwargs)
+
+
+def MaternLattice(*args, nu=1.5, order=3, **kwargs):
+    return LatticeAccelerated(lambda d2: Matern.apply(d2, nu), *args, order=order, **kwargs)

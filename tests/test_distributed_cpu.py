@@ -1,0 +1,80 @@
+"""The sharded MVM choreography under gloo, world_size 2 and 3, on CPU.
+
+The lattice engine is the oracle-backed adapter (tests/oracle_lattice_adapter.py);
+what is under test is simplex_gp_amd.distributed: row ownership, the single
+all-reduce of the vertex accumulators, replicated blur, row-sharded output.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from simplex_gp_amd.distributed import ShardedLatticeMVM, shard_bounds
+
+RBF1 = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, d, vd, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.oracle_lattice_adapter import OracleLattice
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(n, d, generator=g)
+        v = torch.randn(n, vd, generator=g)
+        op = ShardedLatticeMVM(x, RBF1, lattice=OracleLattice())
+        lo, hi = shard_bounds(n, world, rank)
+        assert (op.lo, op.hi) == (lo, hi)
+        out_local = op.matmul(v[lo:hi])
+        assert out_local.shape == (hi - lo, vd)
+        full = op.gather_rows(out_local)
+        # 1-D right-hand side takes the squeeze path
+        out1 = op.matmul(v[lo:hi, 0])
+        assert out1.shape == (hi - lo,) and torch.allclose(out1, out_local[:, 0])
+        with pytest.raises(ValueError):
+            op.matmul(v[: hi - lo + 1])
+        if rank == 0:
+            np.save(os.path.join(outdir, "out.npy"), full.numpy())
+            np.save(os.path.join(outdir, "m.npy"), np.array(op.m))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_mvm_matches_single_process(tmp_path, world):
+    from oracle import oracle
+    n, d, vd = 1001, 3, 2          # 1001 rows: uneven shards
+    mp.spawn(_worker, args=(world, _free_port(), n, d, vd, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, d, generator=g)
+    v = torch.randn(n, vd, generator=g)
+    oracle.set_exact_mode(False)
+    want, m = oracle.filter(v.numpy(), x.numpy(), RBF1, return_m=True)
+    oracle.set_exact_mode(True)
+    got = np.load(tmp_path / "out.npy")
+    assert int(np.load(tmp_path / "m.npy")) == m
+    assert got.shape == want.shape
+    # partial splats are summed in a different order than the single-process splat
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-6
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_bounds(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,189 @@
+"""Host-side logic on CPU: taps, autograd formulas, operator surface, C ABI.
+
+The native filter is replaced by the CPU oracle through the reference's own
+injection point (LatticeFilterGeneral.method, bilateral_kernel.py:60), so the
+Python mirror is checked against goldens captured from the reference's
+bilateral_kernel.py without a GPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import simplex_gp_amd as plx
+from simplex_gp_amd import _native, gp_compat
+from oracle import oracle
+
+
+def oracle_filter(src, ref, coeffs):
+    out = oracle.filter(src.detach().numpy(), ref.detach().numpy(), coeffs.detach().numpy())
+    return torch.from_numpy(out)
+
+
+@pytest.fixture
+def cpu_method():
+    plx.LatticeFilterGeneral.method = staticmethod(oracle_filter)
+    yield
+    plx.LatticeFilterGeneral.method = None
+
+
+@pytest.fixture(scope="module")
+def host(golden_dir):
+    return np.load(os.path.join(golden_dir, "host_side.npz"))
+
+
+PROFILES = {
+    "rbf": plx.rbf,
+    "matern15": lambda d2: plx.Matern.apply(d2, 1.5),
+    "matern25": lambda d2: plx.Matern.apply(d2, 2.5),
+}
+
+
+@pytest.mark.parametrize("pname", sorted(PROFILES))
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_taps_match_reference(host, pname, order):
+    k = plx.DiscretizedKernelFN(PROFILES[pname], order)
+    np.testing.assert_allclose(k.get_coeffs().numpy(), host[f"coeffs/{pname}_o{order}/fwd"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(k.get_deriv_coeffs().numpy(), host[f"coeffs/{pname}_o{order}/deriv"], rtol=0, atol=1e-6)
+
+
+def test_known_rbf_taps():
+    # notebooks/viz_mvm.ipynb:78 prints [0.3461, 1.0000, 0.3461] for RBF order 1
+    c = plx.get_coeffs(lambda d: plx.rbf(d ** 2), 1)
+    assert abs(float(c[0]) - 0.34608543) < 1e-6 and float(c[1]) == 1.0 and c.shape == (3,)
+
+
+def test_matern_profiles_agree_and_gradient():
+    d2 = torch.linspace(0.01, 9, 50, dtype=torch.float64, requires_grad=True)
+    for nu in (1.5, 2.5):
+        a = plx.Matern.apply(d2, nu)
+        b = plx.matern(d2, nu)
+        assert torch.allclose(a, b)
+        (ga,) = torch.autograd.grad(a.sum(), d2)
+        (gb,) = torch.autograd.grad(b.sum(), d2)
+        assert torch.allclose(ga, gb, atol=1e-10)
+    with pytest.raises(NotImplementedError):
+        plx.matern(d2, 0.7)
+
+
+CASES = {
+    "n50_d3_L2_rbf_o1": ("rbf", 1), "n200_d1_L1_rbf_o1": ("rbf", 1),
+    "n50_d3_L2_matern15_o3": ("matern15", 3), "n200_d1_L1_matern15_o3": ("matern15", 3),
+    "n300_d4_L3_rbf_o2": ("rbf", 2),
+}
+
+
+@pytest.mark.parametrize("cname", sorted(CASES))
+def test_autograd_matches_reference(host, cpu_method, cname):
+    pname, order = CASES[cname]
+    dk = plx.DiscretizedKernelFN(PROFILES[pname], order)
+    x = torch.from_numpy(host[f"autograd/{cname}/x"]).requires_grad_(True)
+    s = torch.from_numpy(host[f"autograd/{cname}/src"]).requires_grad_(True)
+    gout = torch.from_numpy(host[f"autograd/{cname}/grad_out"])
+    out = plx.LatticeFilterGeneral.apply(s, x, dk)
+    out.backward(gout)
+
+    def close(a, name, tol=2e-5):
+        b = host[f"autograd/{cname}/{name}"]
+        err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        assert err <= tol, (name, err)
+
+    close(out.detach().numpy(), "out")
+    close(s.grad.numpy(), "grad_src")
+    close(x.grad.numpy(), "grad_x")
+    s2 = s.detach().clone().requires_grad_(True)
+    plx.LatticeFilterGeneral.apply(s2, x.detach(), dk).backward(gout)
+    close(s2.grad.numpy(), "grad_src_only")
+
+
+def test_shape_assert(cpu_method):
+    dk = plx.DiscretizedKernelFN(plx.rbf, 1)
+    with pytest.raises(AssertionError, match="Incompatible shapes"):
+        plx.LatticeFilterGeneral.apply(torch.randn(4, 1), torch.randn(5, 2), dk)
+
+
+def test_operator_surface(cpu_method):
+    torch.manual_seed(0)
+    k = plx.RBFLattice(order=1)
+    assert isinstance(k, plx.LatticeAccelerated) and k.has_lengthscale
+    assert abs(float(k.lengthscale) - 0.6931) < 1e-3            # softplus(0), GPyTorch's default
+    x = torch.randn(40, 2)
+    K = k(x, x)
+    assert isinstance(K, plx.SquareLazyLattice)
+    assert K.size() == torch.Size((40, 40)) and K.shape == (40, 40)
+    assert K._transpose_nonbatch() is K
+    assert torch.equal(K.diag(), torch.ones(40))
+    assert torch.equal(k(x, x, diag=True), torch.ones(40))
+    V = torch.randn(40, 3)
+    want = oracle.filter(V.numpy(), (x / k.lengthscale).detach().numpy(), k.dkernel_fn.get_coeffs().numpy())
+    np.testing.assert_allclose(K.matmul(V).detach().numpy(), want, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose((K @ V[:, 0]).detach().numpy(), want[:, 0], rtol=1e-5, atol=1e-6)
+
+    # rectangular: pad + square filter over [xout; xin] + row slice (py:150-156)
+    xs = torch.randn(15, 2)
+    R = k(xs, x)
+    assert isinstance(R, plx.RectangularLazyLattice)
+    assert R.size() == torch.Size((15, 40))
+    Rt = R._transpose_nonbatch()
+    assert isinstance(Rt, plx.RectangularLazyLattice) and Rt.size() == torch.Size((40, 15))
+    ell = k.lengthscale.detach()
+    big_x = torch.cat([x / ell, xs / ell]).numpy()
+    big_v = np.concatenate([V.numpy(), np.zeros((15, 3), np.float32)])
+    want = oracle.filter(big_v, big_x, k.dkernel_fn.get_coeffs().numpy())[40:]
+    np.testing.assert_allclose(R.matmul(V).detach().numpy(), want, rtol=1e-5, atol=1e-6)
+    with pytest.raises(AssertionError, match="mismatched shapes"):
+        R.matmul(torch.randn(7, 3))
+
+
+def test_factories_defaults():
+    assert plx.RBFLattice().dkernel_fn.order == 2                        # py:247
+    assert plx.BilateralKernel(order=1).dkernel_fn.order == 1            # py:250-251
+    m = plx.MaternLattice()
+    assert m.dkernel_fn.order == 3                                       # py:253
+    k = plx.MaternLattice(nu=2.5, order=1, ard_num_dims=5)
+    assert k.lengthscale.shape[-1] == 5
+    k.lengthscale = 2.0
+    assert torch.allclose(k.lengthscale, torch.full((1, 5), 2.0), atol=1e-5)
+
+
+def test_lengthscale_gradient_flows(cpu_method):
+    k = plx.RBFLattice(order=1, ard_num_dims=2)
+    x = torch.randn(30, 2, generator=torch.Generator().manual_seed(1))
+    v = torch.randn(30, 1, generator=torch.Generator().manual_seed(2))
+    (v * k(x, x).matmul(v)).sum().backward()
+    g = k.raw_lengthscale.grad
+    assert g is not None and g.shape == (1, 2) and torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+def test_no_cpu_fallback():
+    """Without the test hook, CPU tensors are rejected loudly - never a silent CPU path."""
+    plx.LatticeFilterGeneral.method = None
+    dk = plx.DiscretizedKernelFN(plx.rbf, 1)
+    with pytest.raises(ValueError, match="no CPU path"):
+        plx.LatticeFilterGeneral.apply(torch.randn(4, 1), torch.randn(4, 2), dk)
+    with pytest.raises(ValueError):
+        plx.filter(torch.randn(4, 1), torch.randn(4, 2), torch.tensor([0.5, 1, 0.5]))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    lib = _native.lib()
+    declared = _native.declared_symbols()
+    assert len(declared) >= 20 and "plx_filter" in declared and "plx_build" in declared
+    for name in declared:
+        assert hasattr(lib, name), f"libplx.so does not export {name}"
+        assert name in _native._SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.plx_version().decode().startswith("libplx")
+    assert lib.plx_strerror(3).decode().startswith("lattice coordinate")
+    # argument validation happens before any GPU work
+    h = ctypes.c_void_p()
+    assert lib.plx_create(0, None) == 1
+    assert lib.plx_num_vertices(None) == -1
+    assert lib.plx_tune(b"no_such_key", 1) == 1 and b"no_such_key" in lib.plx_last_error()
+
+
+def test_gp_compat_fallback_is_explicit():
+    assert gp_compat.HAVE_GPYTORCH in (True, False)
+    if not gp_compat.HAVE_GPYTORCH:
+        assert plx.LatticeAccelerated.__mro__[1] is gp_compat._Kernel
