@@ -77,28 +77,30 @@ def time_region(fn, steps, sync, barrier):
 
 
 def kernel_times(lat, v, out, reps):
-    """Mean per-launch device time (ms) of each apply kernel, from plx_apply's own events."""
+    """Mean device time (ms) per LAUNCH of each apply kernel.  plx_apply records one
+    hipEvent pair per stage on its own stream; the blur stage is d+1 back-to-back
+    launches of one kernel, so stage / (d+1) is that kernel's mean launch time
+    (agrees with rocprofv3's per-kernel average to a few percent; per-launch
+    event pairs would add ~20 % of event overhead to a 25 us kernel)."""
     lat.set_timing(True)
-    acc = {"splat": [], "splat_fixup": [], "blur": [], "slice": []}
+    acc = {"splat": [], "blur": [], "slice": []}
     for _ in range(reps):
         lat.apply(v, out)
         t = lat.apply_times_ms()
-        acc["splat"].append(t["splat"])
-        acc["splat_fixup"].append(t["splat_fixup"])
-        acc["blur"].extend(t["blur"])
-        acc["slice"].append(t["slice"])
+        for k in acc:
+            acc[k].append(t[k])
     lat.set_timing(False)
-    return {k: float(np.mean(a)) for k, a in acc.items()}
+    return {"splat": float(np.mean(acc["splat"])), "blur": float(np.mean(acc["blur"])) / (lat.d + 1),
+            "slice": float(np.mean(acc["slice"]))}
 
 
 def roofline_for(kt, n, d, m, vd, r):
     ab = alg_bytes(n, d, m, vd, r)
-    per_mvm_ms = {"splat": kt["splat"] + kt["splat_fixup"], "blur_axis": kt["blur"] * (d + 1),
-                  "slice": kt["slice"]}
+    per_mvm_ms = {"splat": kt["splat"], "blur_axis": kt["blur"] * (d + 1), "slice": kt["slice"]}
     dom = max(per_mvm_ms, key=per_mvm_ms.get)
     launch_ms = {"splat": kt["splat"], "blur_axis": kt["blur"], "slice": kt["slice"]}[dom]
     achieved = ab[dom] / (launch_ms * 1e-3) / 1e9
-    kernel = {"splat": "splat_kernel", "blur_axis": "blur_axis_kernel", "slice": "slice_kernel"}[dom]
+    kernel = {"splat": "splat_scan_kernel (+fix-up)", "blur_axis": "blur_axis_v1_kernel", "slice": "slice_unrolled_kernel"}[dom]
     return {
         "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -144,13 +146,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=1_000_000, help="points per GPU")
+    ap.add_argument("--points", dest="n", type=int, default=1_000_000, help="points per GPU")
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--vd", type=int, default=1)
     ap.add_argument("--ell", type=float, default=1.0)
     ap.add_argument("--rebuild-every", type=int, default=50)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fine", action="store_true")
+    ap.add_argument("--skip-cpu-baseline", dest="no_cpu_baseline", action="store_true")
+    ap.add_argument("--skip-fine", dest="no_fine", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
+    ap.add_argument("--check", action="store_true", help="verify the (sharded) MVM against the CPU oracle (small --points only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,12 +163,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import simplex_gp_amd as plx
     from simplex_gp_amd import _native as nv
@@ -174,7 +183,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[dev_index]) if args.backend == "nccl" else dist.barrier()
 
     n_local, d, vd, r = args.n, args.d, args.vd, 1
     n_total = n_local * world
@@ -204,6 +213,15 @@ def main():
         if i % args.rebuild_every == 0:
             lat.build(ref, RBF1, own=(lo, hi))
         mvm()
+
+    if args.check:
+        from oracle import oracle
+        oracle.set_exact_mode(False)
+        want = oracle.filter(v_all.numpy(), (x / args.ell).numpy(), RBF1)[lo:hi]
+        mvm()
+        err = float(np.linalg.norm(out.cpu().numpy() - want) / np.linalg.norm(want))
+        log(f"rank {rank}: rows [{lo},{hi}) rel-L2 vs oracle {err:.2e} (m={m})")
+        assert err <= 1e-5, err
 
     for i in range(args.warmup):
         step(i)

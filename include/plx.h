@@ -152,10 +152,10 @@ int plx_tune(const char *key, int value);
  * plx_set_timing(lat, 1) turns hipEvent timing on (adds event records only). */
 int plx_set_timing(plx_lattice *lat, int on);
 int plx_build_times(const plx_lattice *lat, float *h_ms6);
-/* Per-launch device time of the last plx_apply (timing on), in ms, in launch
- * order {splat, splat_fixup, blur axis 0..d, slice}: d+4 numbers.  Each is the
- * hipEvent interval from the end of the previous launch to the end of this one
- * on the apply stream.  Synchronises on the last event. */
+/* Per-stage device time of the last plx_apply (timing on), in ms: {splat (scan +
+ * fix-up launch), blur (all d+1 launches), slice}.  One hipEvent pair per stage
+ * on the apply stream, so a stage time divided by its launch count is directly
+ * comparable with rocprofv3's per-kernel average.  Synchronises on the last event. */
 int plx_apply_times(plx_lattice *lat, float *h_ms, int cap, int *count);
 
 #ifdef __cplusplus

@@ -341,7 +341,6 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         case 2: splat_scan_kernel<2><<<grid, kBlock, 0, stream>>>(pt, w, vid, d_src, vd, nnz, d_values, hp, tp, g_splat_ablate); break;
         default: splat_scan_kernel<4><<<grid, kBlock, 0, stream>>>(pt, w, vid, d_src, vd, nnz, d_values, hp, tp, g_splat_ablate); break;
         }
-        tmark(L, stream);
         splat_scan_fixup_kernel<<<ceil_div((int64_t)nch * vd, kBlock), kBlock, 0, stream>>>(pt, vid, nch, nnz, vd, hp,
                                                                                               tp, d_values);
     } else {
@@ -354,7 +353,6 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         case 4: splat_rows_kernel<4><<<grid, kBlock, 0, stream>>>(pt, w, rp, vid, d_src, vd, nnz, d_values, hp, tp); break;
         default: splat_rows_kernel<8><<<grid, kBlock, 0, stream>>>(pt, w, rp, vid, d_src, vd, nnz, d_values, hp, tp); break;
         }
-        tmark(L, stream);
         splat_rows_fixup_kernel<<<ceil_div((int64_t)nch * vd, kBlock), kBlock, 0, stream>>>(rp, vid, nch, nnz, vd, hp,
                                                                                               tp, d_values);
     }
@@ -493,9 +491,9 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             default: blur_axis_kernel<0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, L->mstride, vd, logvt, order, L->taps); break;
             }
         }
-        tmark(L, stream);
         float *t = cur; cur = nxt; nxt = t;
     }
+    tmark(L, stream);
     *result_in_scratch = (cur == d_scratch) ? 1 : 0;
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;

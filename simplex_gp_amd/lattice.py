@@ -117,15 +117,15 @@ class Lattice:
         return dict(zip(("embed", "insert", "number", "ids", "neighbours", "csr"), list(buf)))
 
     def apply_times_ms(self):
-        """Per-launch times of the last apply(): dict(splat, splat_fixup, blur=[d+1], slice)."""
-        cap = nv.MAX_DIM + 8
+        """Stage times of the last apply(): dict(splat, blur, slice) in ms (blur = all d+1 launches)."""
+        cap = 8
         buf = (ctypes.c_float * cap)()
         cnt = ctypes.c_int(0)
         nv.check(nv.lib().plx_apply_times(self._h, buf, cap, ctypes.byref(cnt)), "plx_apply_times")
         t = list(buf)[:cnt.value]
-        if len(t) != self.d + 4:
+        if len(t) != 3:
             return None
-        return {"splat": t[0], "splat_fixup": t[1], "blur": t[2:2 + self.d + 1], "slice": t[-1]}
+        return {"splat": t[0], "blur": t[1], "slice": t[2]}
 
     # -- stages -----------------------------------------------------------
     def _src(self, src, rows):
