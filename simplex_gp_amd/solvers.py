@@ -1,0 +1,178 @@
+"""The caller of the hot path: batched CG + stochastic Lanczos log-det + GP
+marginal likelihood, written against the operator surface only (`matmul`).
+
+GPyTorch (ExactGP, ExactMarginalLogLikelihood, mBCG) is third-party and not
+installed in the build image; this module is the minimal harness that drives
+the lattice operator the way the reference's scripts do:
+    tests/train_snelson.py:48-76            (config 1: Snelson, 100 Adam steps)
+    experiments/train_simplexgp.py:29-57    (config 3/5: CG-based MLL training)
+Every CG iteration is one K.v MVM with vd = 1 + num_probes on a lattice that is
+built once per hyper-parameter setting (lattice_kernel.cached_filter).
+
+For sharded operators pass `reduce=distributed.all_reduce_sum` so that the dot
+products are summed over ranks.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .lattice_kernel import LatticeAccelerated
+
+
+def _colsum(a, b, reduce=None):
+    s = (a * b).sum(0)
+    return reduce(s) if reduce is not None else s
+
+
+def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False):
+    """Solve A X = B for all columns of B at once (A symmetric positive definite,
+    known through `matmul`).  Stops when every column's residual norm is below
+    `tol` x its right-hand-side norm, or after max_iter iterations.
+
+    Returns (X, info); with want_tridiag, info["tridiag"] holds the per-column
+    Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
+    """
+    X = torch.zeros_like(B)
+    R = B.clone()
+    P = R.clone()
+    rs = _colsum(R, R, reduce)
+    b_norm = rs.sqrt().clamp_min(1e-30)
+    alphas, betas = [], []
+    active = torch.ones_like(rs, dtype=torch.bool)
+    it = 0
+    for it in range(1, max_iter + 1):
+        AP = matmul(P)
+        pAp = _colsum(P, AP, reduce)
+        alpha = torch.where(active, rs / pAp.clamp_min(1e-30), torch.zeros_like(rs))
+        X = X + P * alpha
+        R = R - AP * alpha
+        rs_new = _colsum(R, R, reduce)
+        beta = torch.where(active, rs_new / rs.clamp_min(1e-30), torch.zeros_like(rs))
+        if want_tridiag:
+            alphas.append(alpha)
+            betas.append(beta)
+        P = R + P * beta
+        rs = rs_new
+        active = active & (rs.sqrt() / b_norm > tol)
+        if not bool(active.any()):
+            break
+    info = {"iterations": it, "residual": (rs.sqrt() / b_norm)}
+    if want_tridiag:
+        k = len(alphas)
+        a = torch.stack(alphas, 0).double()           # [k, t]
+        b = torch.stack(betas, 0).double()
+        # a column that converged early has alpha = 0 afterwards: freeze its tridiagonal there
+        valid = a > 0
+        inv_a = torch.where(valid, 1.0 / a.clamp_min(1e-300), torch.zeros_like(a))
+        t = B.shape[1]
+        T = torch.zeros(t, k, k, dtype=torch.float64, device=B.device)
+        for i in range(k):
+            diag = inv_a[i] + (b[i - 1] * inv_a[i - 1] if i > 0 else 0.0)
+            T[:, i, i] = torch.where(valid[i], diag, torch.ones_like(diag))
+            if i + 1 < k:
+                off = torch.where(valid[i + 1], b[i].clamp_min(0).sqrt() * inv_a[i], torch.zeros_like(diag))
+                T[:, i, i + 1] = off
+                T[:, i + 1, i] = off
+        info["tridiag"] = T
+    return X, info
+
+
+def slq_logdet(tridiag, n):
+    """Stochastic Lanczos quadrature: logdet(A) ~ n * mean_i e1^T log(T_i) e1 for
+    probes with ||z||^2 = n."""
+    evals, evecs = torch.linalg.eigh(tridiag)
+    w = evecs[:, 0, :] ** 2
+    return float(n) * (w * evals.clamp_min(1e-30).log()).sum(-1).mean()
+
+
+class LatticeGP(nn.Module):
+    """Constant mean + outputscale * LatticeKernel + Gaussian noise >= min_noise:
+    the model of tests/train_snelson.py:11-23 / experiments/train_simplexgp.py:13-26."""
+
+    def __init__(self, kernel, min_noise=1e-4):
+        super().__init__()
+        assert isinstance(kernel, LatticeAccelerated)
+        self.kernel = kernel
+        self.mean = nn.Parameter(torch.zeros(()))
+        self.raw_outputscale = nn.Parameter(torch.zeros(()))
+        self.raw_noise = nn.Parameter(torch.zeros(()))
+        self.min_noise = min_noise
+
+    @property
+    def outputscale(self):
+        return F.softplus(self.raw_outputscale)
+
+    @property
+    def noise(self):
+        return F.softplus(self.raw_noise) + self.min_noise
+
+    def khat_matmul(self, x):
+        """V -> (s K(x,x) + sigma^2 I) V as a differentiable closure."""
+        K = self.kernel(x, x)
+
+        def mm(V):
+            return self.outputscale * K.matmul(V) + self.noise * V
+        return mm
+
+
+def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, reduce=None,
+                            n_total=None):
+    """Per-datapoint log marginal likelihood (the quantity GPyTorch's
+    ExactMarginalLogLikelihood returns) of a LatticeGP, differentiable with
+    respect to every hyper-parameter.
+
+    Value: CG solve for K^-1 (y - mean) + SLQ log-det from the same CG run over
+    Rademacher probes.  Gradient: the usual surrogate
+        S = -u^T r + 1/2 u^T K u - 1/(2t) sum_i w_i^T K z_i,   u = K^-1 r, w_i = K^-1 z_i (detached)
+    whose gradient equals that of the MLL; it costs one more MVM (vd = 1 + t)
+    and its backward (one wide filter, py:113-122).
+    """
+    n_local = y.shape[0]
+    n = n_local if n_total is None else n_total
+    r = (y - model.mean).reshape(-1, 1)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    Z = (torch.randint(0, 2, (n_local, num_probes), generator=g).float() * 2 - 1).to(y.device)
+    mm = model.khat_matmul(x)
+    with torch.no_grad():
+        rhs = torch.cat([r.detach(), Z], 1)
+        sol, info = batched_cg(mm, rhs, max_iter=max_cg_iter, tol=cg_tol, reduce=reduce, want_tridiag=True)
+        u, W = sol[:, :1], sol[:, 1:]
+        quad = _colsum(r.detach(), u, reduce).sum()
+        logdet = slq_logdet(info["tridiag"][1:], n)
+        value = -0.5 * quad - 0.5 * logdet - 0.5 * n * math.log(2 * math.pi)
+    KV = mm(torch.cat([u, Z], 1))                                # differentiable MVM
+    s_quad = -(u * r).sum() + 0.5 * (u * KV[:, :1]).sum()
+    s_logdet = -0.5 * (W * KV[:, 1:]).sum() / num_probes
+    surrogate = s_quad + s_logdet
+    if reduce is not None:
+        surrogate = surrogate  # gradients of sharded parameters are summed by the caller's all-reduce
+    out = (value.to(surrogate.dtype) + (surrogate - surrogate.detach())) / n
+    out.cg_info = info
+    return out
+
+
+# ----------------------------------------------------------------------------
+# dense exact GP (the ExactModel of tests/train_snelson.py:26-46), for config 1
+
+class ExactRBFGP(nn.Module):
+    def __init__(self, min_noise=1e-4):
+        super().__init__()
+        self.mean = nn.Parameter(torch.zeros(()))
+        self.raw_outputscale = nn.Parameter(torch.zeros(()))
+        self.raw_lengthscale = nn.Parameter(torch.zeros(()))
+        self.raw_noise = nn.Parameter(torch.zeros(()))
+        self.min_noise = min_noise
+
+    def mll(self, x, y):
+        """Per-datapoint exact log marginal likelihood with K = s exp(-|x-x'|^2 / (2 l^2)) + sigma^2 I."""
+        n = y.shape[0]
+        ell = F.softplus(self.raw_lengthscale)
+        d2 = torch.cdist(x / ell, x / ell).pow(2)
+        K = F.softplus(self.raw_outputscale) * torch.exp(-0.5 * d2)
+        K = K + (F.softplus(self.raw_noise) + self.min_noise) * torch.eye(n, dtype=x.dtype, device=x.device)
+        Lc = torch.linalg.cholesky(K)
+        r = (y - self.mean).reshape(-1, 1)
+        alpha = torch.cholesky_solve(r, Lc)
+        return (-0.5 * (r * alpha).sum() - Lc.diagonal().log().sum() - 0.5 * n * math.log(2 * math.pi)) / n

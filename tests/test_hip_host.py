@@ -141,3 +141,48 @@ def test_sharded_mvm_single_process(plx):
     taps = np.array([0.5, 1.0, 0.5], np.float32)
     op = ShardedLatticeMVM(x, taps)
     assert torch.equal(op.matmul(v), plx.Lattice().build(x, taps).apply(v))
+
+
+def test_snelson_config1_on_gpu(plx, golden_dir):
+    """BASELINE.json config 1 on the HIP path: |MLL_lattice - MLL_exact| < 0.1 (tests/train_snelson.py:96)."""
+    from simplex_gp_amd import solvers
+    sn = np.loadtxt(os.path.join(golden_dir, "snelson.csv"), delimiter=",", skiprows=1).astype(np.float32)
+    x, y = torch.from_numpy(sn[:, :1].copy()).cuda(), torch.from_numpy(sn[:, 1].copy()).cuda()
+    torch.manual_seed(0)
+    exact = solvers.ExactRBFGP().cuda()
+    opt = torch.optim.Adam(exact.parameters(), lr=0.1)
+    for _ in range(100):
+        opt.zero_grad()
+        (-exact.mll(x, y)).backward()
+        opt.step()
+    exact_mll = float(exact.mll(x, y))
+    model = solvers.LatticeGP(plx.RBFLattice(order=1)).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=0.1)
+    for i in range(100):
+        opt.zero_grad()
+        (-solvers.marginal_log_likelihood(model, x, y, num_probes=10, cg_tol=1e-4, max_cg_iter=500, seed=i)).backward()
+        opt.step()
+    with torch.no_grad():
+        lattice_mll = float(solvers.marginal_log_likelihood(model, x, y, num_probes=50, cg_tol=1e-5, max_cg_iter=1000, seed=999))
+    print("snelson exact", exact_mll, "lattice", lattice_mll)
+    assert abs(lattice_mll - exact_mll) < 0.1
+
+
+def test_cg_config3_small(plx):
+    """Config 3 at reduced N: 50 CG iterations on (s K + sigma^2 I) with [y | 10 probes]; residual falls, one lattice build."""
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(1234)
+    n, d = 100_000, 8
+    x = torch.randn(n, d, generator=g).cuda()
+    y = torch.randn(n, generator=g).cuda()
+    model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).cuda()
+    cache = plx.lattice_cache()
+    cache.clear()
+    with torch.no_grad():
+        mm = model.khat_matmul(x)
+        Z = (torch.randint(0, 2, (n, 10), generator=g).float() * 2 - 1).cuda()
+        rhs = torch.cat([y[:, None], Z], 1)
+        sol, info = solvers.batched_cg(mm, rhs, max_iter=50, tol=1e-8)
+        resid = (mm(sol) - rhs).norm(dim=0) / rhs.norm(dim=0)
+    assert info["iterations"] == 50 and cache.misses == 1
+    assert float(resid.max()) < 0.05

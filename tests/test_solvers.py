@@ -1,0 +1,96 @@
+"""CG / SLQ / marginal-likelihood harness on CPU (oracle-backed filter via the
+reference's injection point), including BASELINE.json config 1: Snelson-1D,
+RBFLattice(order=1) reaches the exact GP's train MLL within 0.1
+(tests/train_snelson.py:96)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import simplex_gp_amd as plx
+from simplex_gp_amd import solvers
+from oracle import oracle
+
+
+def oracle_filter(src, ref, coeffs):
+    return torch.from_numpy(oracle.filter(src.detach().numpy(), ref.detach().numpy(), coeffs.detach().numpy()))
+
+
+@pytest.fixture
+def cpu_method():
+    plx.LatticeFilterGeneral.method = staticmethod(oracle_filter)
+    yield
+    plx.LatticeFilterGeneral.method = None
+
+
+def test_batched_cg_and_slq_on_dense_spd():
+    g = torch.Generator().manual_seed(0)
+    n = 120
+    Q = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = Q @ Q.T / n + 0.5 * torch.eye(n, dtype=torch.float64)
+    B = torch.randn(n, 4, generator=g, dtype=torch.float64)
+    X, info = solvers.batched_cg(lambda V: A @ V, B, max_iter=500, tol=1e-10, want_tridiag=True)
+    assert torch.allclose(X, torch.linalg.solve(A, B), atol=1e-7)
+    assert info["iterations"] < 200 and info["tridiag"].shape[0] == 4
+    # SLQ with many Rademacher probes approaches the exact log-determinant
+    Z = (torch.randint(0, 2, (n, 64), generator=g).double() * 2 - 1)
+    _, info = solvers.batched_cg(lambda V: A @ V, Z, max_iter=500, tol=1e-10, want_tridiag=True)
+    est = float(solvers.slq_logdet(info["tridiag"], n))
+    exact = float(torch.logdet(A))
+    assert abs(est - exact) < 0.05 * abs(exact) + 1.0
+
+
+def test_mll_gradient_matches_dense_autograd(cpu_method):
+    """Surrogate gradient of the CG/SLQ MLL vs autograd through a dense evaluation of the same operator."""
+    torch.manual_seed(0)
+    n = 60
+    x = torch.randn(n, 2)
+    y = torch.sin(x[:, 0]) + 0.1 * torch.randn(n)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1))
+    mll = solvers.marginal_log_likelihood(model, x, y, num_probes=n, cg_tol=1e-7, seed=1)
+    mll.backward()
+    got = {k: p.grad.clone() for k, p in model.named_parameters()}
+    # exact gradient of the quadratic-form part wrt mean / noise / outputscale using the dense lattice matrix
+    with torch.no_grad():
+        Kd = model.kernel(x, x).evaluate()
+        Kd = 0.5 * (Kd + Kd.T)
+    s = model.raw_outputscale.detach().clone().requires_grad_(True)
+    nz = model.raw_noise.detach().clone().requires_grad_(True)
+    mu = model.mean.detach().clone().requires_grad_(True)
+    Khat = torch.nn.functional.softplus(s) * Kd + (torch.nn.functional.softplus(nz) + model.min_noise) * torch.eye(n)
+    r = (y - mu).reshape(-1, 1)
+    dense = (-0.5 * (r * torch.linalg.solve(Khat, r)).sum() - 0.5 * torch.logdet(Khat) - 0.5 * n * np.log(2 * np.pi)) / n
+    dense.backward()
+    assert abs(float(mll) - float(dense)) < 0.05
+    assert abs(float(got["mean"]) - float(mu.grad)) < 2e-2 * (1 + abs(float(mu.grad)))
+    assert abs(float(got["raw_noise"]) - float(nz.grad)) < 5e-2 * (1 + abs(float(nz.grad)))
+    assert abs(float(got["raw_outputscale"]) - float(s.grad)) < 5e-2 * (1 + abs(float(s.grad)))
+    assert torch.isfinite(got["kernel.raw_lengthscale"]).all()
+
+
+def test_snelson_mll_matches_exact_gp(cpu_method, golden_dir):
+    """Config 1 (tests/train_snelson.py): 100 Adam(lr=0.1) steps each, |MLL_lattice - MLL_exact| < 0.1."""
+    sn = np.loadtxt(os.path.join(golden_dir, "snelson.csv"), delimiter=",", skiprows=1).astype(np.float32)
+    x, y = torch.from_numpy(sn[:, :1].copy()), torch.from_numpy(sn[:, 1].copy())
+    torch.manual_seed(0)
+    exact = solvers.ExactRBFGP()
+    opt = torch.optim.Adam(exact.parameters(), lr=0.1)
+    for _ in range(100):
+        opt.zero_grad()
+        loss = -exact.mll(x, y)
+        loss.backward()
+        opt.step()
+    exact_mll = float(exact.mll(x, y))
+
+    model = solvers.LatticeGP(plx.RBFLattice(order=1))
+    opt = torch.optim.Adam(model.parameters(), lr=0.1)
+    for i in range(100):
+        opt.zero_grad()
+        mll = solvers.marginal_log_likelihood(model, x, y, num_probes=10, cg_tol=1e-4, max_cg_iter=500, seed=i)
+        (-mll).backward()
+        opt.step()
+    with torch.no_grad():
+        lattice_mll = float(solvers.marginal_log_likelihood(model, x, y, num_probes=50, cg_tol=1e-5, max_cg_iter=1000, seed=999))
+    print("exact", exact_mll, "lattice", lattice_mll)
+    assert abs(lattice_mll - exact_mll) < 0.1
