@@ -194,7 +194,7 @@ def main():
     out = torch.empty_like(v)
 
     lat = plx.Lattice(dev)
-    lat.build(ref, RBF1, own=(lo, hi))
+    lat.build(ref, RBF1, shard=(rank, world))
     m = lat.m
     values = scratch = None
     if world > 1:
@@ -206,12 +206,12 @@ def main():
         else:
             lat.splat(v, values)
             dist.all_reduce(values)            # RCCL sum over xGMI: the one exchange of the path
-            res = lat.blur(values, scratch)
-            lat.slice(res, out)
+            res = lat.blur(values, scratch, vd=vd)
+            lat.slice(res, out, vd=vd)
 
     def step(i):
         if i % args.rebuild_every == 0:
-            lat.build(ref, RBF1, own=(lo, hi))
+            lat.build(ref, RBF1, shard=(rank, world))
         mvm()
 
     if args.check:

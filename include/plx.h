@@ -60,7 +60,9 @@ enum {
     PLX_ARRAY_NEIGHBORS = 3,     /* int32  [d+1][2r][m]  blur neighbour ids, -1 absent (h:539-544)  */
     PLX_ARRAY_ROW_PTR = 4,       /* int32  [m+1]         splat CSR row pointers (owned points)      */
     PLX_ARRAY_CSR_POINT = 5,     /* int32  [nnz]         splat CSR point index                      */
-    PLX_ARRAY_CSR_WEIGHT = 6     /* float  [nnz]         splat CSR weight                           */
+    PLX_ARRAY_CSR_WEIGHT = 6,    /* float  [nnz]         splat CSR weight                           */
+    PLX_ARRAY_POINT_PERM = 7     /* uint32 [n]           caller's row of the i-th point in lattice order;
+                                    ENTRY_* and CSR_POINT are indexed in lattice order             */
 };
 
 const char *plx_strerror(int code);
@@ -82,28 +84,39 @@ void plx_destroy(plx_lattice *lat);
  * Replaces: PermutohedralLattice ctor (h:346-392), the structural half of
  * splat() (h:395-475, 482-484: embedding, hashed vertex creation, replay
  * entries), and every hashTable.lookup() of blur() (h:541-545), which becomes a
- * neighbour table.  Vertex ids are the reference's first-touch ids.
+ * neighbour table.
  *
- * [own_begin, own_end) is the range of points this process splats and slices
- * (0, n for a single GPU).  Every rank of a sharded job passes the SAME d_ref
- * and gets the same vertex numbering; only the splat CSR and the slice tables
- * are restricted to the owned rows.
+ * Internally the points are visited in "lattice order" (shard by shard, inside a
+ * shard lexicographically by their rounded lattice coordinates) so that points
+ * sharing simplices are adjacent in memory; vertex ids are the reference's
+ * first-touch numbering (h:73-79) applied to that order.  The order is an
+ * implementation detail: d_src / d_out rows are always in the caller's order.
+ *
+ * Sharded jobs: the n rows are split into n_shards contiguous near-equal blocks
+ * (the first n % n_shards blocks have one extra row); this process splats and
+ * slices block `shard_index` only.  Every rank passes the SAME d_ref and
+ * n_shards and obtains the same vertex numbering without communication.  A single
+ * GPU uses shard_index = 0, n_shards = 1.
  */
 int plx_build(plx_lattice *lat, const float *d_ref, int64_t n, int d,
               const float *h_taps, int ntaps,
-              int64_t own_begin, int64_t own_end, void *stream);
+              int shard_index, int n_shards, void *stream);
 
 int64_t plx_num_points(const plx_lattice *lat);    /* n                              */
-int64_t plx_num_owned(const plx_lattice *lat);     /* own_end - own_begin            */
+int64_t plx_num_owned(const plx_lattice *lat);     /* rows of this shard             */
 int64_t plx_num_vertices(const plx_lattice *lat);  /* m = hashTable.size(), h:44     */
 int plx_dim(const plx_lattice *lat);               /* d                              */
 int plx_order(const plx_lattice *lat);             /* (ntaps-1)/2                    */
+/* Floats per vertex row of a values buffer for vd value columns: 1 for vd = 1,
+ * otherwise vd rounded up to a multiple of 4 (rows are whole 16-byte vectors;
+ * the padding columns hold zeros).  d_values / d_scratch below are [m][stride]. */
+int plx_values_stride(int vd);
 /* bytes of device memory currently held by the lattice */
 int64_t plx_device_bytes(const plx_lattice *lat);
 
 /*
- * Stage 1 -- splat (h:478-479): d_values[m][vd] = S^T d_src, where d_src holds
- * the OWNED rows only, [own_end-own_begin][vd].  Every row of d_values is
+ * Stage 1 -- splat (h:478-479): d_values[m][stride] = S^T d_src, where d_src holds
+ * this shard's rows only, [plx_num_owned][vd], in the caller's row order.  Every row of d_values is
  * written (vertices no owned point touches get 0).  Deterministic: no float
  * atomics.
  */
@@ -111,15 +124,15 @@ int plx_splat(plx_lattice *lat, const float *d_src, int vd, float *d_values, voi
 
 /*
  * Stage 2 -- blur (h:513-572): d+1 Jacobi passes over the neighbour table,
- * ping-ponging between d_values and d_scratch (both [m][vd]).  On return
+ * ping-ponging between d_values and d_scratch (both [m][stride]).  On return
  * *result_in_scratch tells which of the two holds the result (d+1 odd => 1).
  */
 int plx_blur(plx_lattice *lat, float *d_values, float *d_scratch, int vd,
              int *result_in_scratch, void *stream);
 
 /*
- * Stage 3 -- slice (h:497-510): d_out[own][vd] = S d_values / (1 + 2^-d) for
- * the owned rows.
+ * Stage 3 -- slice (h:497-510): d_out[plx_num_owned][vd] = S d_values / (1 + 2^-d)
+ * for this shard's rows, in the caller's row order.
  */
 int plx_slice(plx_lattice *lat, const float *d_values, int vd, float *d_out, void *stream);
 
@@ -142,13 +155,13 @@ int plx_export(plx_lattice *lat, int which, void *h_dst, int64_t bytes, void *st
 int64_t plx_export_bytes(const plx_lattice *lat, int which);
 
 /* Select a kernel variant by name (process-wide; for A/B measurements in one
- * process -- the defaults are the shipped configuration).  Keys: "splat_impl"
- * (0 row loop, 1 segmented scan), "blur_vpt" (vertices per thread at vd=1: 1, 2, 4),
- * "slice_impl" (0 runtime loop, 1 unrolled). */
+ * process -- the defaults are the shipped configuration).  Keys: "sort_points"
+ * (0 keeps the caller's point order), "blur_vpt" (vertices per thread at vd=1:
+ * 2 or 4; anything else selects the general kernel), "splat_ablate" (diagnostics). */
 int plx_tune(const char *key, int value);
 
 /* Per-stage device time of the last plx_build on this lattice, in ms, in the
- * order {embed, insert, number, ids, neighbours, csr}; 0 when timing is off.
+ * order {order+embed, insert, number, ids, neighbours, csr}; 0 when timing is off.
  * plx_set_timing(lat, 1) turns hipEvent timing on (adds event records only). */
 int plx_set_timing(plx_lattice *lat, int on);
 int plx_build_times(const plx_lattice *lat, float *h_ms6);

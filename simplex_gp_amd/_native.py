@@ -13,7 +13,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "plx.h")
 
 PLX_OK = 0
 ARRAY_KEYS, ARRAY_ENTRY_VERTEX, ARRAY_ENTRY_WEIGHT, ARRAY_NEIGHBORS = 0, 1, 2, 3
-ARRAY_ROW_PTR, ARRAY_CSR_POINT, ARRAY_CSR_WEIGHT = 4, 5, 6
+ARRAY_ROW_PTR, ARRAY_CSR_POINT, ARRAY_CSR_WEIGHT, ARRAY_POINT_PERM = 4, 5, 6, 7
 MAX_DIM, MAX_ORDER = 32, 8
 
 
@@ -32,13 +32,14 @@ _SIGNATURES = {
     "plx_version": (ctypes.c_char_p, []),
     "plx_create": (_i32, [_i32, ctypes.POINTER(_vp)]),
     "plx_destroy": (None, [_vp]),
-    "plx_build": (_i32, [_vp, _vp, _i64, _i32, _f32p, _i32, _i64, _i64, _vp]),
+    "plx_build": (_i32, [_vp, _vp, _i64, _i32, _f32p, _i32, _i32, _i32, _vp]),
     "plx_num_points": (_i64, [_vp]),
     "plx_num_owned": (_i64, [_vp]),
     "plx_num_vertices": (_i64, [_vp]),
     "plx_dim": (_i32, [_vp]),
     "plx_order": (_i32, [_vp]),
     "plx_device_bytes": (_i64, [_vp]),
+    "plx_values_stride": (_i32, [_i32]),
     "plx_splat": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "plx_blur": (_i32, [_vp, _vp, _vp, _i32, ctypes.POINTER(_i32), _vp]),
     "plx_slice": (_i32, [_vp, _vp, _i32, _vp, _vp]),

@@ -40,7 +40,8 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
     return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
             &L->sort_keys_in, &L->sort_keys_out, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_w, &L->row_ptr,
-            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b};
+            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->perm, &L->iota,
+            &L->sortkey_in, &L->sortkey_out};
 }
 
 struct DeviceGuard {
@@ -110,16 +111,15 @@ void plx_destroy(plx_lattice *L)
 }
 
 int plx_build(plx_lattice *L, const float *d_ref, int64_t n, int d, const float *h_taps, int ntaps,
-              int64_t own_begin, int64_t own_end, void *stream)
+              int shard_index, int n_shards, void *stream)
 {
     if (!L || !d_ref || !h_taps) { set_error("plx_build: NULL argument"); return PLX_ERR_INVALID; }
     if (n <= 0) { set_error("plx_build: n = %lld must be positive", (long long)n); return PLX_ERR_INVALID; }
     if (d < 1 || d > PLX_MAX_DIM) { set_error("plx_build: d = %d outside 1..%d", d, PLX_MAX_DIM); return PLX_ERR_DIM; }
     if (ntaps < 1 || (ntaps % 2) == 0) { set_error("plx_build: tap count %d must be odd", ntaps); return PLX_ERR_INVALID; }
     if (ntaps / 2 > PLX_MAX_ORDER) { set_error("plx_build: order %d > %d", ntaps / 2, PLX_MAX_ORDER); return PLX_ERR_DIM; }
-    if (own_begin < 0 || own_end < own_begin || own_end > n) {
-        set_error("plx_build: owned range [%lld, %lld) outside [0, %lld)", (long long)own_begin,
-                  (long long)own_end, (long long)n);
+    if (n_shards < 1 || n_shards > 256 || shard_index < 0 || shard_index >= n_shards) {
+        set_error("plx_build: shard %d of %d is not a valid shard (1..256 shards)", shard_index, n_shards);
         return PLX_ERR_INVALID;
     }
     if (n * (int64_t)(d + 1) >= (1ll << 31) - 1024) {
@@ -130,7 +130,8 @@ int plx_build(plx_lattice *L, const float *d_ref, int64_t n, int d, const float 
     if (!g.ok) { set_error("plx_build: cannot select device %d", L->device); return PLX_ERR_HIP; }
     L->built = false;
     L->n = n; L->d = d; L->ntaps = ntaps; L->order = ntaps / 2;
-    L->own_begin = own_begin; L->own_end = own_end;
+    L->shard_index = shard_index; L->n_shards = n_shards;
+    shard_range(n, n_shards, shard_index, &L->own_begin, &L->own_end);
     memset(&L->taps, 0, sizeof(L->taps));
     for (int i = 0; i < ntaps; ++i) L->taps.c[i] = h_taps[i];
     int rc = build_impl(L, d_ref, (hipStream_t)stream);
@@ -143,6 +144,8 @@ int64_t plx_num_owned(const plx_lattice *L) { return L ? L->own_end - L->own_beg
 int64_t plx_num_vertices(const plx_lattice *L) { return (L && L->built) ? L->m : -1; }
 int plx_dim(const plx_lattice *L) { return L ? L->d : -1; }
 int plx_order(const plx_lattice *L) { return L ? L->order : -1; }
+
+int plx_values_stride(int vd) { return vd >= 1 ? values_stride(vd) : -1; }
 
 int64_t plx_device_bytes(const plx_lattice *L)
 {
@@ -157,7 +160,8 @@ static int check_apply(const plx_lattice *L, const void *a, const void *b, int v
     if (!L || !a || !b) { set_error("%s: NULL argument", who); return PLX_ERR_INVALID; }
     if (!L->built) { set_error("%s: lattice not built", who); return PLX_ERR_STATE; }
     if (vd < 1) { set_error("%s: vd = %d must be positive", who, vd); return PLX_ERR_INVALID; }
-    if ((int64_t)L->m * vd >= (1ll << 31) || (int64_t)(L->own_end - L->own_begin) * vd >= (1ll << 31)) {
+    if ((int64_t)L->m * values_stride(vd) >= (1ll << 31) ||
+        (int64_t)(L->own_end - L->own_begin) * values_stride(vd) >= (1ll << 31)) {
         set_error("%s: m*vd or n*vd exceeds 2^31 elements; split the columns", who);
         return PLX_ERR_TOO_LARGE;
     }
@@ -193,8 +197,8 @@ int plx_apply(plx_lattice *L, const float *d_src, int vd, float *d_out, void *st
 {
     PLX_TRY(check_apply(L, d_src, d_out, vd, "plx_apply"));
     DeviceGuard g(L->device);
-    PLX_TRY(ensure(L->val_a, (size_t)L->m * vd * 4));
-    PLX_TRY(ensure(L->val_b, (size_t)L->m * vd * 4));
+    PLX_TRY(ensure(L->val_a, (size_t)L->m * values_stride(vd) * 4));
+    PLX_TRY(ensure(L->val_b, (size_t)L->m * values_stride(vd) * 4));
     hipStream_t s = (hipStream_t)stream;
     L->tev_n = 0;
     tmark(L, s);
@@ -213,7 +217,7 @@ int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref, int
         if (hipGetDevice(&dev) != hipSuccess) { set_error("plx_filter: hipGetDevice failed"); return PLX_ERR_HIP; }
         PLX_TRY(plx_create(dev, &L));
     }
-    int rc = plx_build(L, d_ref, n, d, h_taps, ntaps, 0, n, stream);
+    int rc = plx_build(L, d_ref, n, d, h_taps, ntaps, 0, 1, stream);
     if (rc == PLX_OK) rc = plx_apply(L, d_src, vd, d_out, stream);
     if (!scratch) {
         (void)hipStreamSynchronize((hipStream_t)stream);
@@ -234,6 +238,7 @@ int64_t plx_export_bytes(const plx_lattice *L, int which)
     case PLX_ARRAY_ROW_PTR: return (m + 1) * 4;
     case PLX_ARRAY_CSR_POINT: return L->nnz * 4;
     case PLX_ARRAY_CSR_WEIGHT: return L->nnz * 4;
+    case PLX_ARRAY_POINT_PERM: return n * 4;
     default: return -1;
     }
 }
@@ -280,6 +285,7 @@ int plx_export(plx_lattice *L, int which, void *h_dst, int64_t bytes, void *stre
         return PLX_OK;
     }
     case PLX_ARRAY_CSR_WEIGHT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_w.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    case PLX_ARRAY_POINT_PERM: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->perm.p, bytes, hipMemcpyDeviceToHost, s)); break;
     }
     PLX_HIP_TRY(hipStreamSynchronize(s));
     return PLX_OK;

@@ -1,18 +1,21 @@
-// plx_apply.hip -- the per-MVM kernels: splat, blur, slice.
+// plx_apply.hip -- the per-MVM kernels: gather-in, splat, blur, slice.
 //
 // Reference: cpp/permutohedral.h ("h") splat value accumulation h:478-479,
 // blur h:513-572, slice h:497-510.  The reference's CUDA path does the splat
 // with one float atomicAdd per (point, corner, channel) and re-hashes every
 // neighbour in every blur pass; here
-//   splat = segmented reduction over simplex corners sorted by vertex (no
-//           atomics, bitwise reproducible),
-//   blur  = d+1 gather-accumulate passes over a precomputed neighbour table,
-//   slice = per-point gather through SoA (vertex id, weight) planes.
-// All three are HBM/cache-bandwidth bound gather stencils; no MFMA.
+//   gather-in  right-hand side rows into lattice point order (and, for vd > 1,
+//              into rows padded to whole 16-byte vectors),
+//   splat      segmented scan over simplex corners sorted by vertex (no
+//              atomics, bitwise reproducible),
+//   blur       d+1 gather-accumulate passes over a precomputed neighbour table,
+//   slice      per-point gather through SoA (vertex id, weight) planes, result
+//              scattered back to the caller's row order.
+// All are HBM/cache-bandwidth bound gather stencils; no MFMA.
 //
-// Column tiling for vd > 1: a work item is (row, column) with the column
-// fastest, VT = 2^logvt columns per tile and blockIdx.y selecting the tile, so
-// the vd values of one vertex/point row are read by adjacent lanes.
+// Value rows: vd = 1 -> one float per vertex; vd > 1 -> vdp = roundup4(vd)
+// floats, i.e. nch = vdp/4 float4 "chunks", and every access of the vector
+// kernels is one aligned 16-byte load/store per lane.
 
 #include "plx_internal.h"
 
@@ -20,47 +23,92 @@
 
 namespace plx {
 
-static int g_splat_impl = 1;   // 0 row loop (first version), 1 segmented scan
-static int g_blur_vpt = 4;     // vertices per thread in the vd = 1 blur
-static int g_slice_impl = 1;   // 0 runtime loop, 1 unrolled per dimension
+static int g_blur_vpt = 4;     // vertices per thread in the vd = 1 blur (2 or 4)
 static int g_splat_ablate = 0; // diagnostics only: 1 no value gather, 2 no stores, 4 no row-id loads
+extern int g_sort_points;
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"splat_impl", &g_splat_impl}, {"blur_vpt", &g_blur_vpt},
-                          {"slice_impl", &g_slice_impl}, {"splat_ablate", &g_splat_ablate}, {nullptr, nullptr}};
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"blur_vpt", &g_blur_vpt},
+                          {"splat_ablate", &g_splat_ablate}, {nullptr, nullptr}};
     return t;
 }
 
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_scale(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float4 f4_sel(bool c, float4 a, float4 b) { return c ? a : b; }
+__device__ __forceinline__ float4 f4_shfl_up(float4 a, int off)
+{
+    return make_float4(__shfl_up(a.x, off), __shfl_up(a.y, off), __shfl_up(a.z, off), __shfl_up(a.w, off));
+}
+
 // ----------------------------------------------------------------------------
-// splat, version 1: segmented scan.
+// gather-in: ssrc[i][0..vdp) = src[perm[own_begin + i] - own_begin][0..vd), zero padded
+
+__global__ __launch_bounds__(kBlock) void gather_in_kernel(const float *__restrict__ src,
+                                                           const uint32_t *__restrict__ perm, int own_begin,
+                                                           int n_own, int vd, int vdp, float *__restrict__ ssrc)
+{
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= (int64_t)n_own * vdp) return;
+    const int i = (int)(item / vdp), col = (int)(item - (int64_t)i * vdp);
+    const int row = (int)perm[own_begin + i] - own_begin;
+    ssrc[item] = (col < vd) ? src[(size_t)row * vd + col] : 0.f;
+}
+
+// ----------------------------------------------------------------------------
+// splat: segmented scan.
 //
 // The corners of the owned points are sorted by vertex (csr_pt / csr_w; the sign
 // bit of csr_pt marks the first corner of each vertex row).  A workgroup takes
-// kSplatChunk consecutive corners, 4 per thread, forms w * src[point] in
+// kSplatChunk consecutive corners, 4 per thread, forms w * ssrc[point] in
 // registers and runs one segmented inclusive scan over the chunk (in-thread,
 // then wave shuffles, then four wave totals through LDS).  A thread whose
 // corner closes a row stores the row sum; the row ids (csr_vid) are read only
 // at row ends.  Rows that cross a chunk edge leave head / tail partial sums for
 // splat_fixup_kernel.  The scan tree is fixed, so results are reproducible.
+//
+// Scan element: (heads seen, sum since the last head);
+//   combine(left, right) = (l.cnt + r.cnt, r.cnt ? r.sum : l.sum + r.sum).
+//
+// V = float (vd = 1, NCH = 1) or float4 with NCH chunks held per corner.
 
-template <int VT>
+template <class V> struct VecOps;
+template <> struct VecOps<float> {
+    static __device__ __forceinline__ float zero() { return 0.f; }
+    static __device__ __forceinline__ float add(float a, float b) { return a + b; }
+    static __device__ __forceinline__ float scale(float s, float a) { return s * a; }
+    static __device__ __forceinline__ float sel(bool c, float a, float b) { return c ? a : b; }
+    static __device__ __forceinline__ float shfl_up(float a, int off) { return __shfl_up(a, off); }
+};
+template <> struct VecOps<float4> {
+    static __device__ __forceinline__ float4 zero() { return f4_zero(); }
+    static __device__ __forceinline__ float4 add(float4 a, float4 b) { return f4_add(a, b); }
+    static __device__ __forceinline__ float4 scale(float s, float4 a) { return f4_scale(s, a); }
+    static __device__ __forceinline__ float4 sel(bool c, float4 a, float4 b) { return f4_sel(c, a, b); }
+    static __device__ __forceinline__ float4 shfl_up(float4 a, int off) { return f4_shfl_up(a, off); }
+};
+
+// rowlen = V-elements per value row (1 for float, nch for float4); tile0 = first
+// chunk of this workgroup's column tile (blockIdx.y * NCH)
+template <class V, int NCH>
 __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restrict__ csr_pt,
                                                             const float *__restrict__ csr_w,
                                                             const int *__restrict__ csr_vid,
-                                                            const float *__restrict__ src, int vd, int nnz,
-                                                            float *__restrict__ values,
-                                                            float *__restrict__ head_partial,
-                                                            float *__restrict__ tail_partial, int ablate)
+                                                            const V *__restrict__ ssrc, int rowlen, int nnz,
+                                                            V *__restrict__ values, V *__restrict__ head_partial,
+                                                            V *__restrict__ tail_partial, int ablate)
 {
+    using O = VecOps<V>;
     constexpr int EPT = kSplatChunk / kBlock;   // corners per thread
     static_assert(EPT == 4, "vector loads below assume 4 corners per thread");
     __shared__ int wave_cnt[kBlock / 64];
-    __shared__ float wave_sum[kBlock / 64][VT];
+    __shared__ V wave_sum[kBlock / 64][NCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x;
-    const int col0 = blockIdx.y * VT;
+    const int tile0 = blockIdx.y * NCH;
     const int k0 = c * kSplatChunk;
     const int kb = k0 + tid * EPT;
 
@@ -90,76 +138,78 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
         row_ends[j] = (kb + j + 1 >= nnz) ? true : (pt[j + 1] < 0);
     }
     // second round, all independent: value gathers and the row ids needed at row ends
-    float p[EPT][VT];
+    V p[EPT][NCH];
     int vrow[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         const int q = pt[j] & 0x7FFFFFFF;
 #pragma unroll
-        for (int cc = 0; cc < VT; ++cc)
-            p[j][cc] = (col0 + cc < vd) ? w[j] * ((ablate & 1) ? 1.0f : src[(size_t)q * vd + col0 + cc]) : 0.f;
+        for (int cc = 0; cc < NCH; ++cc) {
+            const bool in = tile0 + cc < rowlen;
+            p[j][cc] = in ? O::scale(w[j], (ablate & 1) ? O::zero() : ssrc[(size_t)q * rowlen + tile0 + cc]) : O::zero();
+        }
         vrow[j] = (row_ends[j] && kb + j < nnz) ? ((ablate & 4) ? (kb + j) & 1023 : csr_vid[kb + j]) : 0;
     }
 
     // in-thread: heads, and the sum since the last head (or of all four)
     int cnt = 0;
-    float run[VT];
+    V run[NCH];
 #pragma unroll
-    for (int cc = 0; cc < VT; ++cc) run[cc] = 0.f;
+    for (int cc = 0; cc < NCH; ++cc) run[cc] = O::zero();
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
         cnt += head[j] ? 1 : 0;
 #pragma unroll
-        for (int cc = 0; cc < VT; ++cc) run[cc] = head[j] ? p[j][cc] : run[cc] + p[j][cc];
+        for (int cc = 0; cc < NCH; ++cc) run[cc] = O::sel(head[j], p[j][cc], O::add(run[cc], p[j][cc]));
     }
 
-    // wave inclusive scan of (cnt, run): combine(left, right) = (l.cnt + r.cnt, r.cnt ? r.sum : l.sum + r.sum)
+    // wave inclusive scan
     int icnt = cnt;
-    float isum[VT];
+    V isum[NCH];
 #pragma unroll
-    for (int cc = 0; cc < VT; ++cc) isum[cc] = run[cc];
+    for (int cc = 0; cc < NCH; ++cc) isum[cc] = run[cc];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int ocnt = __shfl_up(icnt, off);
-        float osum[VT];
+        V osum[NCH];
 #pragma unroll
-        for (int cc = 0; cc < VT; ++cc) osum[cc] = __shfl_up(isum[cc], off);
+        for (int cc = 0; cc < NCH; ++cc) osum[cc] = O::shfl_up(isum[cc], off);
         if (lane >= off) {
 #pragma unroll
-            for (int cc = 0; cc < VT; ++cc) isum[cc] = (icnt > 0) ? isum[cc] : osum[cc] + isum[cc];
+            for (int cc = 0; cc < NCH; ++cc) isum[cc] = O::sel(icnt > 0, isum[cc], O::add(osum[cc], isum[cc]));
             icnt += ocnt;
         }
     }
     if (lane == 63) {
         wave_cnt[wave] = icnt;
 #pragma unroll
-        for (int cc = 0; cc < VT; ++cc) wave_sum[wave][cc] = isum[cc];
+        for (int cc = 0; cc < NCH; ++cc) wave_sum[wave][cc] = isum[cc];
     }
     // exclusive value inside the wave
     int xcnt = __shfl_up(icnt, 1);
-    float xsum[VT];
+    V xsum[NCH];
 #pragma unroll
-    for (int cc = 0; cc < VT; ++cc) xsum[cc] = __shfl_up(isum[cc], 1);
+    for (int cc = 0; cc < NCH; ++cc) xsum[cc] = O::shfl_up(isum[cc], 1);
     if (lane == 0) {
         xcnt = 0;
 #pragma unroll
-        for (int cc = 0; cc < VT; ++cc) xsum[cc] = 0.f;
+        for (int cc = 0; cc < NCH; ++cc) xsum[cc] = O::zero();
     }
     __syncthreads();
     // fold the totals of the waves before this one, left to right
     int pcnt = 0;
-    float psum[VT];
+    V psum[NCH];
 #pragma unroll
-    for (int cc = 0; cc < VT; ++cc) psum[cc] = 0.f;
+    for (int cc = 0; cc < NCH; ++cc) psum[cc] = O::zero();
     for (int wv = 0; wv < wave; ++wv) {
         const int wc = wave_cnt[wv];
 #pragma unroll
-        for (int cc = 0; cc < VT; ++cc) psum[cc] = (wc > 0) ? wave_sum[wv][cc] : psum[cc] + wave_sum[wv][cc];
+        for (int cc = 0; cc < NCH; ++cc) psum[cc] = O::sel(wc > 0, wave_sum[wv][cc], O::add(psum[cc], wave_sum[wv][cc]));
         pcnt += wc;
     }
     int hc = pcnt + xcnt;                 // heads in the chunk before this thread's corners
 #pragma unroll
-    for (int cc = 0; cc < VT; ++cc) run[cc] = (xcnt > 0) ? xsum[cc] : psum[cc] + xsum[cc];
+    for (int cc = 0; cc < NCH; ++cc) run[cc] = O::sel(xcnt > 0, xsum[cc], O::add(psum[cc], xsum[cc]));
 
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -167,24 +217,17 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
         if (k >= nnz) break;
         if (head[j]) ++hc;
 #pragma unroll
-        for (int cc = 0; cc < VT; ++cc) run[cc] = head[j] ? p[j][cc] : run[cc] + p[j][cc];
+        for (int cc = 0; cc < NCH; ++cc) run[cc] = O::sel(head[j], p[j][cc], O::add(run[cc], p[j][cc]));
         const bool chunk_ends = (j == EPT - 1 && tid == kBlock - 1);
-        if ((ablate & 2) && run[0] != 12345.678f) continue;
-        if (row_ends[j]) {
-            if (hc == 0) {
+        if (ablate & 2) continue;
+        if (row_ends[j] || chunk_ends) {
+            V *dst;
+            size_t base;
+            if (row_ends[j] && hc > 0) { dst = values; base = (size_t)vrow[j] * rowlen; }
+            else { dst = (hc == 0) ? head_partial : tail_partial; base = (size_t)c * rowlen; }
 #pragma unroll
-                for (int cc = 0; cc < VT; ++cc)
-                    if (col0 + cc < vd) head_partial[(size_t)c * vd + col0 + cc] = run[cc];
-            } else {
-#pragma unroll
-                for (int cc = 0; cc < VT; ++cc)
-                    if (col0 + cc < vd) values[(size_t)vrow[j] * vd + col0 + cc] = run[cc];
-            }
-        } else if (chunk_ends) {
-            float *dst = (hc == 0) ? head_partial : tail_partial;
-#pragma unroll
-            for (int cc = 0; cc < VT; ++cc)
-                if (col0 + cc < vd) dst[(size_t)c * vd + col0 + cc] = run[cc];
+            for (int cc = 0; cc < NCH; ++cc)
+                if (tile0 + cc < rowlen) dst[base + tile0 + cc] = run[cc];
         }
     }
 }
@@ -196,166 +239,66 @@ __device__ __forceinline__ bool chunk_has_head(const int *__restrict__ csr_pt, c
 }
 
 // A vertex row that starts inside chunk c and runs past its end: add the head
-// partials of the chunks it covers, in chunk order.
-__global__ __launch_bounds__(kBlock) void splat_scan_fixup_kernel(const int *__restrict__ csr_pt,
-                                                                  const int *__restrict__ csr_vid,
-                                                                  int nchunks, int nnz, int vd,
-                                                                  const float *__restrict__ head_partial,
-                                                                  const float *__restrict__ tail_partial,
-                                                                  float *__restrict__ values)
+// partials of the chunks it covers, in chunk order.  One thread per (chunk, float).
+__global__ __launch_bounds__(kBlock) void splat_fixup_kernel(const int *__restrict__ csr_pt,
+                                                             const int *__restrict__ csr_vid, int nchunks,
+                                                             int nnz, int vdp,
+                                                             const float *__restrict__ head_partial,
+                                                             const float *__restrict__ tail_partial,
+                                                             float *__restrict__ values)
 {
     const int it = blockIdx.x * kBlock + threadIdx.x;
-    if (it >= nchunks * vd) return;
-    const int c = it / vd, col = it - c * vd;
+    if (it >= nchunks * vdp) return;
+    const int c = it / vdp, col = it - c * vdp;
     const int k0 = c * kSplatChunk, k1 = min(k0 + kSplatChunk, nnz);
     if (k1 >= nnz || csr_pt[k1] < 0 || !chunk_has_head(csr_pt, csr_vid, k0, k1)) return;
-    float total = tail_partial[(size_t)c * vd + col];
+    float total = tail_partial[(size_t)c * vdp + col];
     for (int c2 = c + 1; c2 < nchunks; ++c2) {
-        total += head_partial[(size_t)c2 * vd + col];
+        total += head_partial[(size_t)c2 * vdp + col];
         const int a = c2 * kSplatChunk, b = min(a + kSplatChunk, nnz);
         if (b >= nnz || csr_pt[b] < 0 || chunk_has_head(csr_pt, csr_vid, a, b)) break;
     }
-    values[(size_t)csr_vid[k1 - 1] * vd + col] = total;
-}
-
-// ----------------------------------------------------------------------------
-// splat, version 0 (kept for A/B): stage products in LDS, one work item per row.
-
-template <int VT>
-__device__ __forceinline__ void splat_emit(int v, int col, float s, int ra, int rb, int k0, int k1, int c,
-                                           int vd, float *__restrict__ values,
-                                           float *__restrict__ head_partial,
-                                           float *__restrict__ tail_partial)
-{
-    if (col >= vd) return;
-    const bool started_before = ra < k0, ends_after = rb > k1;
-    if (!started_before && !ends_after) values[(size_t)v * vd + col] = s;
-    else if (started_before) head_partial[(size_t)c * vd + col] = s;
-    else tail_partial[(size_t)c * vd + col] = s;
-}
-
-template <int VT>
-__global__ __launch_bounds__(kBlock) void splat_rows_kernel(const int *__restrict__ csr_pt,
-                                                            const float *__restrict__ csr_w,
-                                                            const int *__restrict__ row_ptr,
-                                                            const int *__restrict__ csr_vid,
-                                                            const float *__restrict__ src, int vd, int nnz,
-                                                            float *__restrict__ values,
-                                                            float *__restrict__ head_partial,
-                                                            float *__restrict__ tail_partial)
-{
-    __shared__ float prod[kSplatChunk * VT];
-    __shared__ int long_rows[kSplatChunk / 32 + 2];
-    __shared__ int n_long;
-    const int tid = threadIdx.x;
-    const int c = blockIdx.x;
-    const int col0 = blockIdx.y * VT;
-    const int k0 = c * kSplatChunk;
-    const int k1 = min(k0 + kSplatChunk, nnz);
-    const int len = k1 - k0;
-    if (tid == 0) n_long = 0;
-
-    for (int it = tid; it < len * VT; it += kBlock) {
-        const int i = it / VT, cc = it % VT, col = col0 + cc;
-        const int pt = csr_pt[k0 + i] & 0x7FFFFFFF;
-        const float w = csr_w[k0 + i];
-        prod[it] = (col < vd) ? w * src[(size_t)pt * vd + col] : 0.f;
-    }
-    __syncthreads();
-
-    const int vf = csr_vid[k0], vl = csr_vid[k1 - 1];
-    const int nrows = vl - vf + 1;
-    for (int it = tid; it < nrows * VT; it += kBlock) {
-        const int v = vf + it / VT, cc = it % VT;
-        const int ra = row_ptr[v], rb = row_ptr[v + 1];
-        const int a = max(ra, k0), b = min(rb, k1);
-        if (b - a > 32) {
-            if (cc == 0) long_rows[atomicAdd(&n_long, 1)] = v;
-            continue;
-        }
-        float s = 0.f;
-        for (int k = a; k < b; ++k) s += prod[(k - k0) * VT + cc];
-        splat_emit<VT>(v, col0 + cc, s, ra, rb, k0, k1, c, vd, values, head_partial, tail_partial);
-    }
-    __syncthreads();
-
-    const int wave = tid >> 6, lane = tid & 63;
-    constexpr int EP = 64 / VT;
-    for (int q = wave; q < n_long; q += kBlock / 64) {
-        const int v = long_rows[q];
-        const int ra = row_ptr[v], rb = row_ptr[v + 1];
-        const int a = max(ra, k0), b = min(rb, k1);
-        const int cc = lane % VT, eo = lane / VT;
-        float s = 0.f;
-        for (int k = a + eo; k < b; k += EP) s += prod[(k - k0) * VT + cc];
-#pragma unroll
-        for (int off = 32; off >= VT; off >>= 1) s += __shfl_xor(s, off);
-        if (lane < VT)
-            splat_emit<VT>(v, col0 + lane, s, ra, rb, k0, k1, c, vd, values, head_partial, tail_partial);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void splat_rows_fixup_kernel(const int *__restrict__ row_ptr,
-                                                                  const int *__restrict__ csr_vid,
-                                                                  int nchunks, int nnz, int vd,
-                                                                  const float *__restrict__ head_partial,
-                                                                  const float *__restrict__ tail_partial,
-                                                                  float *__restrict__ values)
-{
-    const int it = blockIdx.x * kBlock + threadIdx.x;
-    if (it >= nchunks * vd) return;
-    const int c = it / vd, col = it - c * vd;
-    const int k0 = c * kSplatChunk, k1 = min(k0 + kSplatChunk, nnz);
-    const int v = csr_vid[k1 - 1];
-    const int ra = row_ptr[v], rb = row_ptr[v + 1];
-    if (ra < k0 || rb <= k1) return;
-    float total = tail_partial[(size_t)c * vd + col];
-    for (int c2 = c + 1; c2 < nchunks; ++c2) {
-        total += head_partial[(size_t)c2 * vd + col];
-        if (rb <= min((c2 + 1) * kSplatChunk, nnz)) break;
-    }
-    values[(size_t)v * vd + col] = total;
+    values[(size_t)csr_vid[k1 - 1] * vdp + col] = total;
 }
 
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream)
 {
     const int64_t m = L->m;
+    const int vdp = values_stride(vd);
+    const int n_own = (int)(L->own_end - L->own_begin);
     if (L->nnz == 0) {
-        PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vd * 4, stream));
+        PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));
         return PLX_OK;
     }
-    const bool all_rows_touched = (L->own_begin == 0 && L->own_end == L->n);
-    if (!all_rows_touched) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vd * 4, stream));
-    PLX_TRY(ensure(L->head_partial, (size_t)L->nchunks * vd * 4));
-    PLX_TRY(ensure(L->tail_partial, (size_t)L->nchunks * vd * 4));
+    const bool all_rows_touched = (L->n_shards == 1);
+    if (!all_rows_touched) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));
+    PLX_TRY(ensure(L->head_partial, (size_t)L->nchunks * vdp * 4));
+    PLX_TRY(ensure(L->tail_partial, (size_t)L->nchunks * vdp * 4));
+    PLX_TRY(ensure(L->ssrc, (size_t)n_own * vdp * 4));
+    gather_in_kernel<<<ceil_div((int64_t)n_own * vdp, kBlock), kBlock, 0, stream>>>(
+        d_src, L->perm.as<uint32_t>(), (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());
     const int *pt = L->csr_pt.as<int>();
     const float *w = L->csr_w.as<float>();
     const int *vid = L->sort_keys_out.as<int>();   // sorted vertex id of every corner
     float *hp = L->head_partial.as<float>(), *tp = L->tail_partial.as<float>();
-    const int nnz = (int)L->nnz, nch = (int)L->nchunks;
-    if (g_splat_impl == 1) {
-        const int vt = vd == 1 ? 1 : vd == 2 ? 2 : 4;
-        dim3 grid((unsigned)nch, (unsigned)ceil_div(vd, vt));
-        switch (vt) {
-        case 1: splat_scan_kernel<1><<<grid, kBlock, 0, stream>>>(pt, w, vid, d_src, vd, nnz, d_values, hp, tp, g_splat_ablate); break;
-        case 2: splat_scan_kernel<2><<<grid, kBlock, 0, stream>>>(pt, w, vid, d_src, vd, nnz, d_values, hp, tp, g_splat_ablate); break;
-        default: splat_scan_kernel<4><<<grid, kBlock, 0, stream>>>(pt, w, vid, d_src, vd, nnz, d_values, hp, tp, g_splat_ablate); break;
-        }
-        splat_scan_fixup_kernel<<<ceil_div((int64_t)nch * vd, kBlock), kBlock, 0, stream>>>(pt, vid, nch, nnz, vd, hp,
-                                                                                              tp, d_values);
+    const float *ss = L->ssrc.as<float>();
+    const int nnz = (int)L->nnz, nch_total = vdp / 4, nchunks = (int)L->nchunks;
+    if (vd == 1) {
+        splat_scan_kernel<float, 1><<<nchunks, kBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, g_splat_ablate);
     } else {
-        const int vt = vd == 1 ? 1 : vd == 2 ? 2 : vd <= 4 ? 4 : 8;
-        dim3 grid((unsigned)nch, (unsigned)ceil_div(vd, vt));
-        const int *rp = L->row_ptr.as<int>();
-        switch (vt) {
-        case 1: splat_rows_kernel<1><<<grid, kBlock, 0, stream>>>(pt, w, rp, vid, d_src, vd, nnz, d_values, hp, tp); break;
-        case 2: splat_rows_kernel<2><<<grid, kBlock, 0, stream>>>(pt, w, rp, vid, d_src, vd, nnz, d_values, hp, tp); break;
-        case 4: splat_rows_kernel<4><<<grid, kBlock, 0, stream>>>(pt, w, rp, vid, d_src, vd, nnz, d_values, hp, tp); break;
-        default: splat_rows_kernel<8><<<grid, kBlock, 0, stream>>>(pt, w, rp, vid, d_src, vd, nnz, d_values, hp, tp); break;
+        const float4 *s4 = reinterpret_cast<const float4 *>(ss);
+        float4 *v4 = reinterpret_cast<float4 *>(d_values), *h4 = reinterpret_cast<float4 *>(hp), *t4 = reinterpret_cast<float4 *>(tp);
+        // up to 3 chunks (12 columns) per workgroup in registers; wider rows take more column tiles
+        const int nch = nch_total <= 3 ? nch_total : (nch_total % 3 == 0 ? 3 : (nch_total % 2 == 0 ? 2 : 3));
+        dim3 grid((unsigned)nchunks, (unsigned)ceil_div(nch_total, nch));
+        switch (nch) {
+        case 1: splat_scan_kernel<float4, 1><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate); break;
+        case 2: splat_scan_kernel<float4, 2><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate); break;
+        default: splat_scan_kernel<float4, 3><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate); break;
         }
-        splat_rows_fixup_kernel<<<ceil_div((int64_t)nch * vd, kBlock), kBlock, 0, stream>>>(rp, vid, nch, nnz, vd, hp,
-                                                                                              tp, d_values);
     }
+    splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, nnz, vdp, hp, tp,
+                                                                                         d_values);
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -365,35 +308,6 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
 // blur: one Jacobi pass along one lattice axis,
 //   out[i] = sum_{nid=-r..r} c[nid+r] * old[nbr(i, nid)]      (h:539-549)
 // accumulated from zero in tap order like the reference.
-
-template <int ORDER>   // 0 = runtime order
-__global__ __launch_bounds__(kBlock) void blur_axis_kernel(const float *__restrict__ old,
-                                                           float *__restrict__ out,
-                                                           const int *__restrict__ nbr, int m,
-                                                           int64_t mstride, int vd, int logvt,
-                                                           int order_rt, TapArgs taps)
-{
-    const int order = ORDER > 0 ? ORDER : order_rt;
-    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int i = (int)(item >> logvt);
-    const int col = (blockIdx.y << logvt) + (int)(item & ((1 << logvt) - 1));
-    if (i >= m || col >= vd) return;
-    float acc = 0.f;
-#pragma unroll
-    for (int s = 0; s < order; ++s) {
-        const int nb = nbr[s * mstride + i];
-        const float val = nb >= 0 ? old[(size_t)nb * vd + col] : 0.f;
-        acc += taps.c[s] * val;
-    }
-    acc += taps.c[order] * old[(size_t)i * vd + col];
-#pragma unroll
-    for (int s = 0; s < order; ++s) {
-        const int nb = nbr[(order + s) * mstride + i];
-        const float val = nb >= 0 ? old[(size_t)nb * vd + col] : 0.f;
-        acc += taps.c[order + 1 + s] * val;
-    }
-    out[(size_t)i * vd + col] = acc;
-}
 
 // vd == 1: VPT consecutive vertices per thread, 4*VPT-byte loads from every plane
 template <int ORDER, int VPT>
@@ -454,7 +368,33 @@ __global__ __launch_bounds__(kBlock) void blur_axis_v1_kernel(const float *__res
     }
 }
 
-static inline int pick_logvt(int vd) { return vd == 1 ? 0 : vd == 2 ? 1 : vd <= 4 ? 2 : vd <= 8 ? 3 : 4; }
+// general: one thread per (vertex, value element).  V = float handles any order at
+// vd = 1; V = float4 handles vd > 1 with rowlen = vdp/4 chunks per vertex (lanes of
+// one vertex read the same neighbour id and adjacent 16-byte chunks).
+template <class V, int ORDER>   // ORDER 0 = runtime order
+__global__ __launch_bounds__(kBlock) void blur_axis_kernel(const V *__restrict__ old, V *__restrict__ out,
+                                                           const int *__restrict__ nbr, int m, int64_t mstride,
+                                                           int rowlen, int order_rt, TapArgs taps)
+{
+    using O = VecOps<V>;
+    const int order = ORDER > 0 ? ORDER : order_rt;
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= (int64_t)m * rowlen) return;
+    const int i = (int)(item / rowlen), ch = (int)(item - (int64_t)i * rowlen);
+    V acc = O::zero();
+#pragma unroll
+    for (int s = 0; s < order; ++s) {
+        const int nb = nbr[s * mstride + i];
+        if (nb >= 0) acc = O::add(acc, O::scale(taps.c[s], old[(size_t)nb * rowlen + ch]));
+    }
+    acc = O::add(acc, O::scale(taps.c[order], old[item]));
+#pragma unroll
+    for (int s = 0; s < order; ++s) {
+        const int nb = nbr[(order + s) * mstride + i];
+        if (nb >= 0) acc = O::add(acc, O::scale(taps.c[order + 1 + s], old[(size_t)nb * rowlen + ch]));
+    }
+    out[item] = acc;
+}
 
 template <int ORDER>
 static void launch_blur_v1(const float *cur, float *nxt, const int *nb, int m, int64_t mstride, const TapArgs &taps,
@@ -466,30 +406,39 @@ static void launch_blur_v1(const float *cur, float *nxt, const int *nb, int m, i
         blur_axis_v1_kernel<ORDER, 2><<<ceil_div(ceil_div(m, 2), kBlock), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps);
 }
 
+template <class V>
+static void launch_blur_general(const V *cur, V *nxt, const int *nb, int m, int64_t mstride, int rowlen, int order,
+                                const TapArgs &taps, hipStream_t stream)
+{
+    const int grid = ceil_div((int64_t)m * rowlen, kBlock);
+    switch (order) {
+    case 1: blur_axis_kernel<V, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps); break;
+    case 2: blur_axis_kernel<V, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps); break;
+    case 3: blur_axis_kernel<V, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps); break;
+    default: blur_axis_kernel<V, 0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps); break;
+    }
+}
+
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream)
 {
     const int m = (int)L->m, d1 = L->d + 1, order = L->order;
-    const int logvt = pick_logvt(vd);
-    const int vt = 1 << logvt;
-    dim3 grid((unsigned)ceil_div((int64_t)m * vt, kBlock), (unsigned)ceil_div(vd, vt));
-    const bool vec = (vd == 1 && order >= 1 && order <= 3 && g_blur_vpt > 1);
+    const int vdp = values_stride(vd);
+    const bool v1 = (vd == 1 && order >= 1 && order <= 3 && (g_blur_vpt == 2 || g_blur_vpt == 4));
     float *cur = d_values, *nxt = d_scratch;
     for (int axis = 0; axis < d1; ++axis) {
         const int *nb = L->nbr.as<int>() + (size_t)axis * 2 * order * L->mstride;
-        if (vec) {
+        if (v1) {
             switch (order) {
             case 1: launch_blur_v1<1>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             case 2: launch_blur_v1<2>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             default: launch_blur_v1<3>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             }
+        } else if (vd == 1) {
+            launch_blur_general<float>(cur, nxt, nb, m, L->mstride, 1, order, L->taps, stream);
         } else {
-            switch (order) {
-            case 1: blur_axis_kernel<1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, L->mstride, vd, logvt, order, L->taps); break;
-            case 2: blur_axis_kernel<2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, L->mstride, vd, logvt, order, L->taps); break;
-            case 3: blur_axis_kernel<3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, L->mstride, vd, logvt, order, L->taps); break;
-            default: blur_axis_kernel<0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, L->mstride, vd, logvt, order, L->taps); break;
-            }
+            launch_blur_general<float4>(reinterpret_cast<const float4 *>(cur), reinterpret_cast<float4 *>(nxt), nb, m,
+                                        L->mstride, vdp / 4, order, L->taps, stream);
         }
         float *t = cur; cur = nxt; nxt = t;
     }
@@ -500,40 +449,19 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
 }
 
 // ----------------------------------------------------------------------------
-// slice: out[p][c] = sum_r w_r * values[v_r][c] / (1 + 2^-d)     (h:502-509)
+// slice: out[row(p)][c] = sum_r w_r * values[v_r][c] / (1 + 2^-d)     (h:502-509)
+// p runs in lattice order; the result is scattered to the caller's row order.
 
-__global__ __launch_bounds__(kBlock) void slice_kernel(const int *__restrict__ evid,
-                                                       const float *__restrict__ ew, int n, int own_begin,
-                                                       int n_own, int d1, const float *__restrict__ values,
-                                                       int vd, int logvt, float denom,
-                                                       float *__restrict__ out)
-{
-    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int pl = (int)(item >> logvt);
-    const int col = (blockIdx.y << logvt) + (int)(item & ((1 << logvt) - 1));
-    if (pl >= n_own || col >= vd) return;
-    const int p = own_begin + pl;
-    float acc = 0.f;
-    for (int r = 0; r < d1; ++r) {
-        const int v = evid[(size_t)r * n + p];
-        const float w = ew[(size_t)r * n + p];
-        acc += w * values[(size_t)v * vd + col] / denom;
-    }
-    out[(size_t)pl * vd + col] = acc;
-}
-
-// all d+1 (id, weight) loads first, then all gathers, then the ordered sum
+// vd == 1: all d+1 (id, weight) loads first, then all gathers, then the ordered sum
 template <int D1>
-__global__ __launch_bounds__(kBlock) void slice_unrolled_kernel(const int *__restrict__ evid,
-                                                                const float *__restrict__ ew, int n,
-                                                                int own_begin, int n_own,
-                                                                const float *__restrict__ values, int vd,
-                                                                int logvt, float denom, float *__restrict__ out)
+__global__ __launch_bounds__(kBlock) void slice_v1_kernel(const int *__restrict__ evid,
+                                                          const float *__restrict__ ew,
+                                                          const uint32_t *__restrict__ perm, int n, int own_begin,
+                                                          int n_own, const float *__restrict__ values, float denom,
+                                                          float *__restrict__ out)
 {
-    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int pl = (int)(item >> logvt);
-    const int col = (blockIdx.y << logvt) + (int)(item & ((1 << logvt) - 1));
-    if (pl >= n_own || col >= vd) return;
+    const int pl = blockIdx.x * kBlock + threadIdx.x;
+    if (pl >= n_own) return;
     const int p = own_begin + pl;
     int v[D1];
     float w[D1], g[D1];
@@ -542,28 +470,59 @@ __global__ __launch_bounds__(kBlock) void slice_unrolled_kernel(const int *__res
         v[r] = evid[(size_t)r * n + p];
         w[r] = ew[(size_t)r * n + p];
     }
+    const int row = (int)perm[p] - own_begin;
 #pragma unroll
-    for (int r = 0; r < D1; ++r) g[r] = values[(size_t)v[r] * vd + col];
+    for (int r = 0; r < D1; ++r) g[r] = values[v[r]];
     float acc = 0.f;
 #pragma unroll
     for (int r = 0; r < D1; ++r) acc += w[r] * g[r] / denom;
-    out[(size_t)pl * vd + col] = acc;
+    out[row] = acc;
+}
+
+// vd > 1: one thread per (point, 16-byte chunk)
+__global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict__ evid,
+                                                           const float *__restrict__ ew,
+                                                           const uint32_t *__restrict__ perm, int n, int own_begin,
+                                                           int n_own, int d1, const float4 *__restrict__ values,
+                                                           int nch, int vd, float denom, float *__restrict__ out)
+{
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= (int64_t)n_own * nch) return;
+    const int pl = (int)(item / nch), ch = (int)(item - (int64_t)pl * nch);
+    const int p = own_begin + pl;
+    float4 acc = f4_zero();
+    for (int r = 0; r < d1; ++r) {
+        const int v = evid[(size_t)r * n + p];
+        const float w = ew[(size_t)r * n + p];
+        const float4 g = values[(size_t)v * nch + ch];
+        acc.x += w * g.x / denom; acc.y += w * g.y / denom; acc.z += w * g.z / denom; acc.w += w * g.w / denom;
+    }
+    const size_t row = (size_t)((int)perm[p] - own_begin);
+    float *o = out + row * vd + 4 * ch;
+    const int left = vd - 4 * ch;
+    if (left >= 4 && (vd & 3) == 0) {
+        *reinterpret_cast<float4 *>(o) = acc;
+    } else {
+        o[0] = acc.x;
+        if (left > 1) o[1] = acc.y;
+        if (left > 2) o[2] = acc.z;
+        if (left > 3) o[3] = acc.w;
+    }
 }
 
 int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream)
 {
     const int n_own = (int)(L->own_end - L->own_begin);
     if (n_own == 0) return PLX_OK;
-    const int logvt = pick_logvt(vd);
-    const int vt = 1 << logvt;
-    dim3 grid((unsigned)ceil_div((int64_t)n_own * vt, kBlock), (unsigned)ceil_div(vd, vt));
     const int *evid = L->evid.as<int>();
     const float *ew = L->ew.as<float>();
+    const uint32_t *perm = L->perm.as<uint32_t>();
     const int n = (int)L->n, ob = (int)L->own_begin;
-    if (g_slice_impl == 1) {
+    if (vd == 1) {
+        const int grid = ceil_div(n_own, kBlock);
         switch (L->d + 1) {
 #define PLX_CASE(D1) \
-    case D1: slice_unrolled_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, n, ob, n_own, d_values, vd, logvt, L->slice_denom, d_out); break;
+    case D1: slice_v1_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, d_values, L->slice_denom, d_out); break;
             PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9)
             PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17)
             PLX_CASE(18) PLX_CASE(19) PLX_CASE(20) PLX_CASE(21) PLX_CASE(22) PLX_CASE(23) PLX_CASE(24) PLX_CASE(25)
@@ -571,8 +530,10 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
 #undef PLX_CASE
         }
     } else {
-        slice_kernel<<<grid, kBlock, 0, stream>>>(evid, ew, n, ob, n_own, L->d + 1, d_values, vd, logvt,
-                                                  L->slice_denom, d_out);
+        const int nch = values_stride(vd) / 4;
+        slice_vec_kernel<<<ceil_div((int64_t)n_own * nch, kBlock), kBlock, 0, stream>>>(
+            evid, ew, perm, n, ob, n_own, L->d + 1, reinterpret_cast<const float4 *>(d_values), nch, vd,
+            L->slice_denom, d_out);
     }
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());

@@ -50,7 +50,9 @@ struct plx_lattice {
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
 
     // problem
-    int64_t n = 0, own_begin = 0, own_end = 0;
+    int64_t n = 0;
+    int shard_index = 0, n_shards = 1;
+    int64_t own_begin = 0, own_end = 0;   // rows of this shard; identical in original and sorted order
     int d = 0, order = 0, ntaps = 0;
     plx::TapArgs taps;
     float slice_denom = 1.f;       // 1 + 2^-d, h:507
@@ -59,6 +61,11 @@ struct plx_lattice {
     int64_t nnz = 0;               // owned CSR entries = n_own * (d+1)
     int64_t nchunks = 0;           // ceil(nnz / kSplatChunk)
     uint32_t table_mask = 0;       // capacity - 1
+
+    // point order: perm[i] = original row of the i-th point in lattice order (shard-major, then
+    // lexicographic in the rounded lattice coordinates); every per-point array below is in that order
+    plx::DevBuf perm;         // uint32 [n]
+    plx::DevBuf sortkey_in, sortkey_out, iota;   // uint64 [n], uint64 [n], uint32 [n]
 
     // build scratch
     plx::DevBuf ekeys;      // uint32 [d+1][n][DW]   packed int16 keys of every simplex corner
@@ -81,7 +88,8 @@ struct plx_lattice {
 
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
-    plx::DevBuf val_a, val_b;                 // float [m][vd]
+    plx::DevBuf val_a, val_b;                 // float [m][vdp]   (vdp = value row stride, plx_values_stride)
+    plx::DevBuf ssrc;                         // float [n_own][vdp] right-hand side in lattice order
 
     int32_t *h_pinned = nullptr;   // pinned host staging for {m, err}
     hipEvent_t ev[8] = {};
@@ -102,6 +110,9 @@ int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit,
                hipStream_t stream);
+int sort_pairs64_temp_bytes(int64_t n, int end_bit, size_t *bytes);
+int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
+                 const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit, hipStream_t stream);
 // plx_apply.hip
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream);
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
@@ -118,6 +129,18 @@ inline void tmark(plx_lattice *L, hipStream_t stream)
 // kernel-variant switches for in-process A/B runs (plx_tune); defaults are the shipped choice
 struct Tunable { const char *name; int *value; };
 Tunable *tunables();
+
+// value-row stride in floats: 1 for a single column, else the column count rounded up to 4 so
+// that every row is a whole number of 16-byte vectors
+inline int values_stride(int vd) { return vd == 1 ? 1 : (vd + 3) & ~3; }
+
+// contiguous near-equal row blocks: the first n % shards blocks get one extra row
+inline void shard_range(int64_t n, int shards, int index, int64_t *lo, int64_t *hi)
+{
+    const int64_t base = n / shards, extra = n % shards;
+    *lo = index * base + (index < extra ? index : extra);
+    *hi = *lo + base + (index < extra ? 1 : 0);
+}
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

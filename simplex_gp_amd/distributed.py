@@ -6,7 +6,8 @@ N points are split into contiguous row blocks, one per rank.
 
     build   every rank builds the lattice from ALL positions (same vertex
             numbering on every rank: ids are the deterministic first-touch
-            order), but its splat CSR / slice tables cover only its own rows
+            order of the shard-major lattice order), but its splat CSR / slice
+            tables cover only its own rows
     splat   own rows -> full-size vertex accumulator values[m, vd]
     exchange ONE all-reduce (sum) of values over the group: the only collective
             on the data path; message = m * vd * 4 bytes
@@ -46,7 +47,7 @@ class ShardedLatticeMVM:
         self.n = ref_all.shape[0]
         self.lo, self.hi = shard_bounds(self.n, self.world, self.rank)
         self.lattice = lattice if lattice is not None else Lattice(ref_all.device)
-        self.lattice.build(ref_all, coeffs, own=(self.lo, self.hi))
+        self.lattice.build(ref_all, coeffs, shard=(self.rank, self.world))
         self._vd = None
         self._values = self._scratch = None
 
@@ -71,11 +72,12 @@ class ShardedLatticeMVM:
         squeeze = v_local.dim() == 1
         if squeeze:
             v_local = v_local.unsqueeze(-1)
-        values, scratch = self._workspace(v_local.shape[1])
+        vd = v_local.shape[1]
+        values, scratch = self._workspace(vd)
         self.lattice.splat(v_local, values)
         all_reduce_sum(values, self.group)               # the one exchange step
-        blurred = self.lattice.blur(values, scratch)
-        res = self.lattice.slice(blurred, out)
+        blurred = self.lattice.blur(values, scratch, vd=vd)
+        res = self.lattice.slice(blurred, out, vd=vd)
         return res.squeeze(-1) if squeeze else res
 
     __call__ = matmul

@@ -69,16 +69,18 @@ class Lattice:
             pass
 
     # -- structure --------------------------------------------------------
-    def build(self, ref, coeffs, own=None):
+    def build(self, ref, coeffs, shard=None):
+        """shard = (index, count): this process splats / slices block `index` of the
+        `count` contiguous near-equal row blocks (distributed.shard_bounds); None = all rows."""
         _check_f32_cuda(ref, "ref")
         ref = ref.contiguous()
         taps = _taps_array(coeffs)
         n, d = ref.shape
-        lo, hi = (0, n) if own is None else own
+        index, count = (0, 1) if shard is None else shard
         with torch.cuda.device(self.device):
             rc = nv.lib().plx_build(self._h, ctypes.c_void_p(ref.data_ptr()), n, d,
                                     taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), taps.size,
-                                    lo, hi, _stream_ptr(self.device))
+                                    index, count, _stream_ptr(self.device))
         nv.check(rc, "plx_build")
         self._ref = ref
         self.taps = taps
@@ -134,8 +136,14 @@ class Lattice:
             raise ValueError(f"Incompatible shapes {tuple(src.shape)}, expected {rows} rows")
         return src.contiguous()
 
+    @staticmethod
+    def values_stride(vd):
+        """Floats per vertex row of a values buffer (vd rounded up to 4 when vd > 1)."""
+        return int(nv.lib().plx_values_stride(vd))
+
     def new_values(self, vd):
-        return torch.empty((self.m, vd), dtype=torch.float32, device=self.device)
+        """Vertex accumulator [m, values_stride(vd)]; columns >= vd are zero padding."""
+        return torch.empty((self.m, self.values_stride(vd)), dtype=torch.float32, device=self.device)
 
     def splat(self, src, values=None):
         src = self._src(src, self.n_owned)
@@ -148,10 +156,12 @@ class Lattice:
         nv.check(rc, "plx_splat")
         return values
 
-    def blur(self, values, scratch=None):
-        """Returns the tensor holding the blurred values (either `values` or `scratch`)."""
+    def blur(self, values, scratch=None, vd=None):
+        """Returns the tensor holding the blurred values (either `values` or `scratch`).
+        `values` is [m, values_stride(vd)]; vd defaults to its width."""
         _check_f32_cuda(values, "values")
-        vd = values.shape[1]
+        vd = values.shape[1] if vd is None else vd
+        assert values.shape[1] == self.values_stride(vd) and values.is_contiguous()
         if scratch is None:
             scratch = torch.empty_like(values)
         flag = ctypes.c_int(0)
@@ -162,9 +172,10 @@ class Lattice:
         nv.check(rc, "plx_blur")
         return scratch if flag.value else values
 
-    def slice(self, values, out=None):
+    def slice(self, values, out=None, vd=None):
         _check_f32_cuda(values, "values")
-        vd = values.shape[1]
+        vd = values.shape[1] if vd is None else vd
+        assert values.shape[1] == self.values_stride(vd) and values.is_contiguous()
         if out is None:
             out = torch.empty((self.n_owned, vd), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
@@ -200,6 +211,7 @@ class Lattice:
             nv.ARRAY_ROW_PTR: (np.int32, (m + 1,)),
             nv.ARRAY_CSR_POINT: (np.int32, (self.n_owned * (d + 1),)),
             nv.ARRAY_CSR_WEIGHT: (np.float32, (self.n_owned * (d + 1),)),
+            nv.ARRAY_POINT_PERM: (np.uint32, (n,)),
         }[which]
         out = np.empty(shape, dtype)
         assert out.nbytes == nbytes, (out.nbytes, nbytes)

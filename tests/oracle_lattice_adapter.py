@@ -11,14 +11,15 @@ class OracleLattice:
     def __init__(self, device=None):
         self._o = None
 
-    def build(self, ref, coeffs, own=None):
+    def build(self, ref, coeffs, shard=None):
         oracle.set_exact_mode(False)      # the duplicate-free lattice, like the HIP path
         try:
             self._o = oracle.Lattice(ref.numpy(), np.asarray(coeffs, np.float32))
         finally:
             oracle.set_exact_mode(True)
         self.n = ref.shape[0]
-        self.lo, self.hi = (0, self.n) if own is None else own
+        from simplex_gp_amd.distributed import shard_bounds
+        self.lo, self.hi = (0, self.n) if shard is None else shard_bounds(self.n, shard[1], shard[0])
         return self
 
     @property
@@ -37,13 +38,13 @@ class OracleLattice:
         values.copy_(res)
         return values
 
-    def blur(self, values, scratch=None):
+    def blur(self, values, scratch=None, vd=None):
         res = torch.from_numpy(self._o.blur(values.numpy()))
         target = scratch if scratch is not None else values     # d+1 odd/even does not matter here
         target.copy_(res)
         return target
 
-    def slice(self, values, out=None):
+    def slice(self, values, out=None, vd=None):
         res = torch.from_numpy(self._o.slice(values.numpy())[self.lo:self.hi].copy())
         if out is None:
             return res

@@ -112,24 +112,28 @@ def test_owned_ranges_compose(plx, shards):
     lats = []
     for r in range(shards):
         lo, hi = shard_bounds(n, shards, r)
-        lat = plx.Lattice().build(x, taps, own=(lo, hi))
+        lat = plx.Lattice().build(x, taps, shard=(r, shards))
         assert lat.m == full.m and lat.n_owned == hi - lo
         part = lat.splat(v[lo:hi])
         total = part.clone() if total is None else total + part
         lats.append((lat, lo, hi))
-    assert rel_l2(total.cpu().numpy(), full.splat(v).cpu().numpy()) <= 1e-6
+    # NB: a sharded build orders points shard by shard, so its vertex numbering differs from the
+    # single-shard lattice `full`; all shards of ONE job agree with each other (checked via keys).
+    from simplex_gp_amd import _native as nv
+    keys0 = lats[0][0].export(nv.ARRAY_KEYS)
+    assert all(np.array_equal(keys0, lat.export(nv.ARRAY_KEYS)) for lat, _, _ in lats[1:])
     got = torch.empty_like(want)
     for lat, lo, hi in lats:
-        blurred = lat.blur(total.clone())
-        got[lo:hi] = lat.slice(blurred)
+        blurred = lat.blur(total.clone(), vd=vd)
+        got[lo:hi] = lat.slice(blurred, vd=vd)
     assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) <= 1e-6
     oracle.set_exact_mode(False)
     ref = oracle.filter(v.cpu().numpy(), x.cpu().numpy(), taps)
     oracle.set_exact_mode(True)
     assert rel_l2(got.cpu().numpy(), ref) <= 1e-5
-    # an empty shard is legal
-    empty = plx.Lattice().build(x, taps, own=(5, 5))
-    assert empty.n_owned == 0 and float(empty.splat(v[5:5]).abs().sum()) == 0.0
+    # an empty shard is legal (more shards than rows)
+    tiny = plx.Lattice().build(x[:2].contiguous(), taps, shard=(2, 3))
+    assert tiny.n_owned == 0 and float(tiny.splat(v[:0]).abs().sum()) == 0.0
 
 
 def test_sharded_mvm_single_process(plx):

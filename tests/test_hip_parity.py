@@ -52,7 +52,24 @@ def _clean_oracle(ref, taps):
         oracle.set_exact_mode(True)
 
 
+def _relabel(lat, o):
+    """Map HIP vertex ids (first touch in lattice point order) to oracle ids (first
+    touch in the caller's order) through the vertex keys, which must be the same set."""
+    from simplex_gp_amd import _native as nv
+    hip_keys = lat.export(nv.ARRAY_KEYS)
+    okeys = o.keys
+    assert hip_keys.shape == okeys.shape
+    lookup = {k.tobytes(): i for i, k in enumerate(okeys)}
+    assert len(lookup) == len(okeys)                       # oracle keys are unique
+    to_oracle = np.array([lookup[k.tobytes()] for k in hip_keys], np.int64)
+    assert len(set(to_oracle.tolist())) == len(to_oracle)  # bijection: no duplicate vertices
+    return to_oracle
+
+
 def test_structure_bit_exact(plx, small):
+    """Keys, per-point simplex corners, barycentric weights, neighbour table and CSR
+    against the duplicate-free oracle, bit for bit, modulo the (checked) relabelling
+    of vertices and the (exported) reordering of points."""
     z, names = small
     from simplex_gp_amd import _native as nv
     lat = plx.Lattice()
@@ -61,36 +78,83 @@ def test_structure_bit_exact(plx, small):
         o = _clean_oracle(ref, taps)
         lat.build(torch.from_numpy(ref).cuda(), taps)
         assert lat.m == o.m, name
-        assert np.array_equal(lat.export(nv.ARRAY_KEYS), o.keys), name
-        assert np.array_equal(lat.export(nv.ARRAY_ENTRY_VERTEX), o.entry_vertex.T), name
-        assert np.array_equal(lat.export(nv.ARRAY_ENTRY_WEIGHT), o.entry_weight.T), name
-        assert np.array_equal(lat.export(nv.ARRAY_NEIGHBORS), o.neighbors()), name
-        # CSR is a permutation of the corners, grouped by vertex
+        to_oracle = _relabel(lat, o)
+        perm = lat.export(nv.ARRAY_POINT_PERM).astype(np.int64)
+        assert np.array_equal(np.sort(perm), np.arange(lat.n)), name
+        ev = lat.export(nv.ARRAY_ENTRY_VERTEX)             # [d+1, n] in lattice order
+        assert np.array_equal(to_oracle[ev], o.entry_vertex[perm].T), name
+        assert np.array_equal(lat.export(nv.ARRAY_ENTRY_WEIGHT), o.entry_weight[perm].T), name
+        nbr = lat.export(nv.ARRAY_NEIGHBORS)               # [d+1, 2r, m] hip ids
+        onbr = o.neighbors()
+        mapped = np.where(nbr >= 0, to_oracle[np.maximum(nbr, 0)], -1)
+        assert np.array_equal(mapped, onbr[:, :, to_oracle]), name
+        # CSR: row lengths are the vertex degrees; every corner appears once
         row_ptr = lat.export(nv.ARRAY_ROW_PTR)
         counts = np.bincount(o.entry_vertex.reshape(-1), minlength=o.m)
-        assert np.array_equal(np.diff(row_ptr), counts), name
+        assert np.array_equal(np.diff(row_ptr), counts[to_oracle]), name
+        csr_pt = lat.export(nv.ARRAY_CSR_POINT)
+        assert np.array_equal(np.bincount(csr_pt, minlength=lat.n), np.full(lat.n, lat.d + 1)), name
         o.close()
     lat.close()
 
 
 def test_stages_match_oracle(plx, small):
     z, names = small
+    from simplex_gp_amd import _native as nv
     lat = plx.Lattice()
     for name in names:
         ref, taps, src = z[f"{name}/ref"], z[f"{name}/taps"], z[f"{name}/src"]
+        vd = src.shape[1]
         o = _clean_oracle(ref, taps)
         lat.build(torch.from_numpy(ref).cuda(), taps)
+        to_oracle = _relabel(lat, o)
+        stride = lat.values_stride(vd)
+
+        def to_hip(ovals):          # oracle-numbered [m, vd] -> hip-numbered, padded [m, stride]
+            buf = np.zeros((lat.m, stride), np.float32)
+            buf[:, :vd] = ovals[to_oracle]
+            return torch.from_numpy(buf).cuda()
+
+        def from_hip(t):            # back to oracle numbering, padding stripped
+            out = np.empty((lat.m, vd), np.float32)
+            out[to_oracle] = t.cpu().numpy()[:, :vd]
+            return out
+
         s = torch.from_numpy(src).cuda()
         v0 = lat.splat(s)
+        assert v0.shape == (lat.m, stride)
+        assert float(v0[:, vd:].abs().sum()) == 0.0
         o_v0 = o.splat(src)
-        assert rel_l2(v0.cpu().numpy(), o_v0) <= TOL_ORACLE, name
-        v1 = lat.blur(torch.from_numpy(o_v0).cuda())
+        assert rel_l2(from_hip(v0), o_v0) <= TOL_ORACLE, name
+        v1 = lat.blur(to_hip(o_v0), vd=vd)
         o_v1 = o.blur(o_v0)
-        assert rel_l2(v1.cpu().numpy(), o_v1) <= TOL_ORACLE, name
-        out = lat.slice(torch.from_numpy(o_v1).cuda())
+        assert rel_l2(from_hip(v1), o_v1) <= TOL_ORACLE, name
+        out = lat.slice(to_hip(o_v1), vd=vd)
+        assert out.shape == (lat.n, vd)
         assert rel_l2(out.cpu().numpy(), o.slice(o_v1)) <= TOL_ORACLE, name
         o.close()
     lat.close()
+
+
+def test_point_order_is_an_implementation_detail(plx):
+    """Same output rows with and without the internal spatial sort (plx_tune sort_points)."""
+    from simplex_gp_amd import _native as nv
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(30000, 5, generator=g).cuda()
+    v = torch.randn(30000, 3, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    try:
+        nv.check(nv.lib().plx_tune(b"sort_points", 0), "plx_tune")
+        a = plx.Lattice().build(x, taps)
+        perm = a.export(nv.ARRAY_POINT_PERM)
+        assert np.array_equal(perm, np.arange(30000))
+        out_a = a.apply(v).clone()
+    finally:
+        nv.check(nv.lib().plx_tune(b"sort_points", 1), "plx_tune")
+    b = plx.Lattice().build(x, taps)
+    assert not np.array_equal(b.export(nv.ARRAY_POINT_PERM), np.arange(30000))
+    assert b.m == a.m
+    assert rel_l2(b.apply(v).cpu().numpy(), out_a.cpu().numpy()) <= 1e-6
 
 
 def test_filter_vs_reference_goldens(plx, small):

@@ -17,7 +17,17 @@ def morton(q, bits):
 def orders(x, ell):
     r = x / ell
     out = {"original": np.arange(len(x))}
-    for cell in (1.0, 2.0, 4.0):
+    # lattice-coordinate key: rounded zero-colour vertex of every point (from the CPU oracle)
+    from oracle import oracle
+    oracle.set_exact_mode(False)
+    o = oracle.Lattice(r.astype(np.float32), RBF1)
+    gr = o.greedy.astype(np.int64) // (x.shape[1] + 1)
+    gr -= gr.min(0)
+    out["lex greedy"] = np.lexsort(gr.T[::-1])
+    ev = o.entry_vertex
+    out["by corner-0 vertex id"] = np.argsort(ev[:, 0], kind="stable")
+    o.close(); oracle.set_exact_mode(True)
+    for cell in (0.25, 0.5, 1.0):
         q = np.floor(r / cell).astype(np.int64)
         q -= q.min(0)
         out[f"lex cell={cell}"] = np.lexsort(q.T[::-1])
@@ -31,7 +41,7 @@ def main():
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(n, d, generator=g).numpy()
     v = torch.randn(n, 1, generator=g)
-    for ell in (1.0, 0.25):
+    for ell in (1.0, 0.6931):
         for name, perm in orders(x, ell).items():
             xs = torch.from_numpy(np.ascontiguousarray(x[perm] / ell)).cuda()
             vs = v[perm].contiguous().cuda()
