@@ -25,12 +25,14 @@ namespace plx {
 
 static int g_blur_vpt = 4;     // vertices per thread in the vd = 1 blur (2 or 4)
 static int g_splat_ablate = 0; // diagnostics only: 1 no value gather, 2 no stores, 4 no row-id loads
+static int g_blur_ablate = 0;  // diagnostics only: 1 no neighbour gathers, 2 no neighbour-id loads either
 extern int g_sort_points;
+extern int g_csr_point_major;
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"blur_vpt", &g_blur_vpt},
-                          {"splat_ablate", &g_splat_ablate}, {nullptr, nullptr}};
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"blur_vpt", &g_blur_vpt},
+                          {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
 
@@ -314,7 +316,7 @@ template <int ORDER, int VPT>
 __global__ __launch_bounds__(kBlock) void blur_axis_v1_kernel(const float *__restrict__ old,
                                                               float *__restrict__ out,
                                                               const int *__restrict__ nbr, int m,
-                                                              int64_t mstride, TapArgs taps)
+                                                              int64_t mstride, TapArgs taps, int ablate)
 {
     using ivec = typename std::conditional<VPT == 4, int4, int2>::type;
     using fvec = typename std::conditional<VPT == 4, float4, float2>::type;
@@ -324,7 +326,9 @@ __global__ __launch_bounds__(kBlock) void blur_axis_v1_kernel(const float *__res
         int nb[2 * ORDER][VPT];
 #pragma unroll
         for (int s = 0; s < 2 * ORDER; ++s) {
-            const ivec v = *reinterpret_cast<const ivec *>(nbr + s * mstride + i0);
+            ivec v;
+            if (ablate & 2) { int *q = reinterpret_cast<int *>(&v); for (int j = 0; j < VPT; ++j) q[j] = i0 + j; }
+            else v = *reinterpret_cast<const ivec *>(nbr + s * mstride + i0);
             const int *pv = reinterpret_cast<const int *>(&v);
 #pragma unroll
             for (int j = 0; j < VPT; ++j) nb[s][j] = pv[j];
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void blur_axis_v1_kernel(const float *__res
 #pragma unroll
         for (int s = 0; s < 2 * ORDER; ++s)
 #pragma unroll
-            for (int j = 0; j < VPT; ++j) g[s][j] = nb[s][j] >= 0 ? old[nb[s][j]] : 0.f;
+            for (int j = 0; j < VPT; ++j) g[s][j] = nb[s][j] >= 0 ? ((ablate & 1) ? (float)nb[s][j] : old[nb[s][j]]) : 0.f;
         fvec res;
         float *pr = reinterpret_cast<float *>(&res);
 #pragma unroll
@@ -401,9 +405,9 @@ static void launch_blur_v1(const float *cur, float *nxt, const int *nb, int m, i
                            hipStream_t stream)
 {
     if (g_blur_vpt == 4)
-        blur_axis_v1_kernel<ORDER, 4><<<ceil_div(ceil_div(m, 4), kBlock), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps);
+        blur_axis_v1_kernel<ORDER, 4><<<ceil_div(ceil_div(m, 4), kBlock), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate);
     else
-        blur_axis_v1_kernel<ORDER, 2><<<ceil_div(ceil_div(m, 2), kBlock), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps);
+        blur_axis_v1_kernel<ORDER, 2><<<ceil_div(ceil_div(m, 2), kBlock), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate);
 }
 
 template <class V>

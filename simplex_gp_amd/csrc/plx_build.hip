@@ -39,6 +39,7 @@
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
+int g_csr_point_major = 1;   // corners of one vertex row ordered by point (1) or by corner index then point (0)
 
 // ----------------------------------------------------------------------------
 // small device helpers
@@ -472,13 +473,13 @@ __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__rest
 
 __global__ __launch_bounds__(kBlock) void csr_keys_kernel(const int *__restrict__ evid, int n, int own_begin,
                                                           int n_own, uint32_t *__restrict__ keys,
-                                                          uint32_t *__restrict__ vals)
+                                                          uint32_t *__restrict__ vals, int g_csr_point_major)
 {
     const int pl = blockIdx.x * kBlock + threadIdx.x;
     if (pl >= n_own) return;
     const int r = blockIdx.y;
     const size_t src = (size_t)r * n + own_begin + pl;
-    const size_t dst = (size_t)r * n_own + pl;
+    const size_t dst = g_csr_point_major ? ((size_t)pl * gridDim.y + r) : ((size_t)r * n_own + pl);
     keys[dst] = (uint32_t)evid[src];
     vals[dst] = (uint32_t)src;
 }
@@ -645,7 +646,7 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
         PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
         csr_keys_kernel<<<dim3(ceil_div(n_own, kBlock), D1), kBlock, 0, stream>>>(
             L->evid.as<int>(), n, (int)L->own_begin, n_own, L->sort_keys_in.as<uint32_t>(),
-            L->sort_vals_in.as<uint32_t>());
+            L->sort_vals_in.as<uint32_t>(), g_csr_point_major);
         PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(),
                            L->sort_keys_out.as<uint32_t>(), L->sort_vals_in.as<uint32_t>(),
                            L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, stream));

@@ -1,9 +1,7 @@
 #!/usr/bin/env python3
-"""A/B the apply-kernel variants in ONE process (interleaved rounds), N=1e6 d=8.
+"""Stage times of the apply kernels, N=1e6 d=8, for plx_tune variants, in ONE process.
 
-Usage: python tools/ab_apply.py [--ell 1.0 0.25] [--vd 1] [--rounds 5]
-Prints per-stage device time (torch events around 20 back-to-back launches) for
-every value of every tunable, and checks that variants agree.
+Usage: python tools/ab_apply.py [--ell 1.0 0.25] [--vd 1] [--rounds 3]
 """
 import argparse
 import os
@@ -41,49 +39,36 @@ def main():
     ap.add_argument("--vd", type=int, default=1)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--sort", type=int, nargs="+", default=[0, 1])
     args = ap.parse_args()
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(args.n, args.d, generator=g)
     v = torch.randn(args.n, args.vd, generator=g).cuda()
-    variants = {"splat": [("splat_impl", 0), ("splat_impl", 1)],
-                "blur": [("blur_vpt", 1), ("blur_vpt", 2), ("blur_vpt", 4)],
-                "slice": [("slice_impl", 0), ("slice_impl", 1)]}
     for ell in args.ell:
-        lat = plx.Lattice().build((x / ell).contiguous().cuda(), RBF1)
-        m = lat.m
-        vals = lat.new_values(args.vd)
-        scratch = lat.new_values(args.vd)
-        out = torch.empty_like(v)
-        print(f"--- ell={ell} m={m} vd={args.vd}")
-        stage_fn = {"splat": lambda: lat.splat(v, vals), "blur": lambda: lat.blur(vals, scratch),
-                    "slice": lambda: lat.slice(vals, out)}
-        for stage, vs in variants.items():
-            res = {kv: [] for kv in vs}
-            outs = {}
-            for _ in range(args.rounds):
-                for kv in vs:
-                    tune(*kv)
-                    res[kv].append(timeit(stage_fn[stage]))
-            for kv in vs:
-                tune(*kv)
-                lat.splat(v, vals)
-                if stage == "splat":
-                    outs[kv] = vals.clone()
-                elif stage == "blur":
-                    outs[kv] = lat.blur(vals, scratch).clone()
-                else:
-                    outs[kv] = lat.slice(vals, out).clone()
-            base = outs[vs[0]]
-            for kv in vs:
-                t = res[kv]
-                err = (outs[kv] - base).norm().item() / base.norm().item()
-                print(f"{stage:6s} {kv[0]}={kv[1]}: median {np.median(t):8.2f} us  min {min(t):8.2f} us   rel diff vs first {err:.2e}")
-        # restore shipped defaults
-        tune("splat_impl", 1); tune("blur_vpt", 4); tune("slice_impl", 1)
-        full = timeit(lambda: lat.apply(v, out))
-        print(f"apply (defaults): {full:.2f} us  -> {1e6 / full:.0f} MVM/s")
-        lat.close()
+        ref = (x / ell).contiguous().cuda()
+        base = None
+        for sort in args.sort:
+            tune("sort_points", sort)
+            lat = plx.Lattice()
+            lat.set_timing(True)
+            lat.build(ref, RBF1)
+            bt = lat.build_times_ms()
+            lat.set_timing(False)
+            vals, scratch, out = lat.new_values(args.vd), lat.new_values(args.vd), torch.empty_like(v)
+            lat.splat(v, vals)
+            ts = min(timeit(lambda: lat.splat(v, vals)) for _ in range(args.rounds))
+            tb = min(timeit(lambda: lat.blur(vals, scratch, vd=args.vd)) for _ in range(args.rounds))
+            tl = min(timeit(lambda: lat.slice(vals, out, vd=args.vd)) for _ in range(args.rounds))
+            ta = min(timeit(lambda: lat.apply(v, out)) for _ in range(args.rounds))
+            res = lat.apply(v).clone()
+            base = res if base is None else base
+            err = (res - base).norm().item() / base.norm().item()
+            print(f"ell={ell} vd={args.vd} m={lat.m} sort={sort}: splat {ts:7.2f} blur {tb:7.2f} slice {tl:7.2f} "
+                  f"apply {ta:7.2f} us ({1e6 / ta:.0f} MVM/s) diff {err:.1e} | build "
+                  + " ".join(f"{k}={t:.3f}" for k, t in bt.items()) + f" total={sum(bt.values()):.3f} ms", flush=True)
+            lat.close()
+        tune("sort_points", 1)
 
 
 if __name__ == "__main__":
