@@ -107,6 +107,14 @@ int64_t plx_num_owned(const plx_lattice *lat);     /* rows of this shard        
 int64_t plx_num_vertices(const plx_lattice *lat);  /* m = hashTable.size(), h:44     */
 int plx_dim(const plx_lattice *lat);               /* d                              */
 int plx_order(const plx_lattice *lat);             /* (ntaps-1)/2                    */
+/* Row order of d_src / d_out for plx_splat / plx_slice / plx_apply on this lattice:
+ * 0 (default) the caller's order -- rows are permuted into lattice order on the way
+ * in and back on the way out; 1 the rows ARE in lattice order (row i of this shard
+ * = caller row PLX_ARRAY_POINT_PERM[own_begin + i] - own_begin), no permutation
+ * work per MVM.  A CG solve permutes its right-hand side once, iterates in
+ * lattice order and permutes the solution back once. */
+int plx_set_row_order(plx_lattice *lat, int lattice_order);
+
 /* Floats per vertex row of a values buffer for vd value columns: 1 for vd = 1,
  * otherwise vd rounded up to a multiple of 4 (rows are whole 16-byte vectors;
  * the padding columns hold zeros).  d_values / d_scratch below are [m][stride]. */

@@ -40,7 +40,7 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
     return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
             &L->sort_keys_in, &L->sort_keys_out, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_w, &L->row_ptr,
-            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->perm, &L->iota,
+            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids,
             &L->sortkey_in, &L->sortkey_out};
 }
 
@@ -86,7 +86,7 @@ int plx_create(int device, plx_lattice **out)
     if (!g.ok) { set_error("plx_create: cannot select device %d", device); return PLX_ERR_HIP; }
     plx_lattice *L = new plx_lattice();
     L->device = device;
-    if (hipHostMalloc((void **)&L->h_pinned, 64, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void **)&L->h_pinned, 256, hipHostMallocDefault) != hipSuccess) {
         set_error("plx_create: hipHostMalloc failed");
         delete L;
         return PLX_ERR_HIP;
@@ -144,6 +144,13 @@ int64_t plx_num_owned(const plx_lattice *L) { return L ? L->own_end - L->own_beg
 int64_t plx_num_vertices(const plx_lattice *L) { return (L && L->built) ? L->m : -1; }
 int plx_dim(const plx_lattice *L) { return L ? L->d : -1; }
 int plx_order(const plx_lattice *L) { return L ? L->order : -1; }
+
+int plx_set_row_order(plx_lattice *L, int lattice_order)
+{
+    if (!L) { set_error("plx_set_row_order: NULL lattice"); return PLX_ERR_INVALID; }
+    L->lattice_rows = lattice_order != 0;
+    return PLX_OK;
+}
 
 int plx_values_stride(int vd) { return vd >= 1 ? values_stride(vd) : -1; }
 

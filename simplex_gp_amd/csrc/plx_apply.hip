@@ -28,10 +28,11 @@ static int g_splat_ablate = 0; // diagnostics only: 1 no value gather, 2 no stor
 static int g_blur_ablate = 0;  // diagnostics only: 1 no neighbour gathers, 2 no neighbour-id loads either
 extern int g_sort_points;
 extern int g_csr_point_major;
+extern int g_compact_nbr;
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"blur_vpt", &g_blur_vpt},
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"blur_vpt", &g_blur_vpt},
                           {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
@@ -55,8 +56,16 @@ __global__ __launch_bounds__(kBlock) void gather_in_kernel(const float *__restri
     const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (item >= (int64_t)n_own * vdp) return;
     const int i = (int)(item / vdp), col = (int)(item - (int64_t)i * vdp);
-    const int row = (int)perm[own_begin + i] - own_begin;
+    const int row = perm ? (int)perm[own_begin + i] - own_begin : i;   // perm == nullptr: rows already in lattice order
     ssrc[item] = (col < vd) ? src[(size_t)row * vd + col] : 0.f;
+}
+
+__global__ __launch_bounds__(kBlock) void gather_in_v1_kernel(const float *__restrict__ src,
+                                                              const uint32_t *__restrict__ perm, int own_begin,
+                                                              int n_own, float *__restrict__ ssrc)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_own) ssrc[i] = src[(int)perm[own_begin + i] - own_begin];
 }
 
 // ----------------------------------------------------------------------------
@@ -277,13 +286,20 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     PLX_TRY(ensure(L->head_partial, (size_t)L->nchunks * vdp * 4));
     PLX_TRY(ensure(L->tail_partial, (size_t)L->nchunks * vdp * 4));
     PLX_TRY(ensure(L->ssrc, (size_t)n_own * vdp * 4));
-    gather_in_kernel<<<ceil_div((int64_t)n_own * vdp, kBlock), kBlock, 0, stream>>>(
-        d_src, L->perm.as<uint32_t>(), (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());
+    const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
+    const float *ss = L->ssrc.as<float>();
+    if (L->lattice_rows && vd == 1)
+        ss = d_src;                       // already in lattice order and unpadded: read it in place
+    else if (vd == 1)
+        gather_in_v1_kernel<<<ceil_div(n_own, kBlock), kBlock, 0, stream>>>(d_src, perm, (int)L->own_begin, n_own,
+                                                                            L->ssrc.as<float>());
+    else
+        gather_in_kernel<<<ceil_div((int64_t)n_own * vdp, kBlock), kBlock, 0, stream>>>(
+            d_src, perm, (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());
     const int *pt = L->csr_pt.as<int>();
     const float *w = L->csr_w.as<float>();
     const int *vid = L->sort_keys_out.as<int>();   // sorted vertex id of every corner
     float *hp = L->head_partial.as<float>(), *tp = L->tail_partial.as<float>();
-    const float *ss = L->ssrc.as<float>();
     const int nnz = (int)L->nnz, nch_total = vdp / 4, nchunks = (int)L->nchunks;
     if (vd == 1) {
         splat_scan_kernel<float, 1><<<nchunks, kBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, g_splat_ablate);
@@ -372,6 +388,75 @@ __global__ __launch_bounds__(kBlock) void blur_axis_v1_kernel(const float *__res
     }
 }
 
+// vd == 1 on a sparse lattice: the same pass over the COMPACTED neighbour table.  A thread
+// owns a quad of 4 vertices; its existing neighbour ids start at
+//   cbase[wave] + (sum of popcount(mask) over the lower lanes of the wave)
+// so a wave reads one contiguous run of ids instead of 2r full planes that are mostly -1.
+template <int ORDER>
+__global__ __launch_bounds__(kBlock) void blur_axis_compact_kernel(const float *__restrict__ old,
+                                                                   float *__restrict__ out,
+                                                                   const uint32_t *__restrict__ cmask,
+                                                                   const uint32_t *__restrict__ cbase,
+                                                                   const int *__restrict__ cids, int m,
+                                                                   int64_t nquads, TapArgs taps)
+{
+    constexpr int T2 = 2 * ORDER;
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t mask = (q < nquads) ? cmask[q] : 0u;
+    const int cnt = __popc(mask);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (q >= nquads) return;
+    int pos = (int)cbase[q >> 6] + (incl - cnt);
+    const int i0 = (int)(q * 4);
+    // ids of the existing neighbours, in (vertex, tap) bit order
+    int nb[4][T2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < T2; ++s) {
+            const bool has = (mask >> (j * T2 + s)) & 1u;
+            nb[j][s] = has ? cids[pos] : -1;
+            pos += has ? 1 : 0;
+        }
+    float g[4][T2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < T2; ++s) g[j][s] = nb[j][s] >= 0 ? old[nb[j][s]] : 0.f;
+    float c[4];
+    if (i0 + 4 <= m) {
+        const float4 cv = *reinterpret_cast<const float4 *>(old + i0);
+        c[0] = cv.x; c[1] = cv.y; c[2] = cv.z; c[3] = cv.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = (i0 + j < m) ? old[i0 + j] : 0.f;
+    }
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < ORDER; ++s) acc += taps.c[s] * g[j][s];
+        acc += taps.c[ORDER] * c[j];
+#pragma unroll
+        for (int s = 0; s < ORDER; ++s) acc += taps.c[ORDER + 1 + s] * g[j][ORDER + s];
+        r[j] = acc;
+    }
+    if (i0 + 4 <= m) {
+        *reinterpret_cast<float4 *>(out + i0) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < m) out[i0 + j] = r[j];
+    }
+}
+
 // general: one thread per (vertex, value element).  V = float handles any order at
 // vd = 1; V = float4 handles vd > 1 with rowlen = vdp/4 chunks per vertex (lanes of
 // one vertex read the same neighbour id and adjacent 16-byte chunks).
@@ -432,7 +517,17 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
     float *cur = d_values, *nxt = d_scratch;
     for (int axis = 0; axis < d1; ++axis) {
         const int *nb = L->nbr.as<int>() + (size_t)axis * 2 * order * L->mstride;
-        if (v1) {
+        if (v1 && L->use_compact) {
+            const uint32_t *cm = L->cmask.as<uint32_t>() + (size_t)axis * L->nquads;
+            const uint32_t *cb = L->cbase.as<uint32_t>() + (size_t)axis * (L->nqwaves + 1);
+            const int *ci = L->cids.as<int>() + L->compact_off[axis];
+            const int grid = ceil_div(L->nqwaves * 64, kBlock);
+            switch (order) {
+            case 1: blur_axis_compact_kernel<1><<<grid, kBlock, 0, stream>>>(cur, nxt, cm, cb, ci, m, L->nquads, L->taps); break;
+            case 2: blur_axis_compact_kernel<2><<<grid, kBlock, 0, stream>>>(cur, nxt, cm, cb, ci, m, L->nquads, L->taps); break;
+            default: blur_axis_compact_kernel<3><<<grid, kBlock, 0, stream>>>(cur, nxt, cm, cb, ci, m, L->nquads, L->taps); break;
+            }
+        } else if (v1) {
             switch (order) {
             case 1: launch_blur_v1<1>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             case 2: launch_blur_v1<2>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
@@ -474,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void slice_v1_kernel(const int *__restrict_
         v[r] = evid[(size_t)r * n + p];
         w[r] = ew[(size_t)r * n + p];
     }
-    const int row = (int)perm[p] - own_begin;
+    const int row = perm ? (int)perm[p] - own_begin : pl;
 #pragma unroll
     for (int r = 0; r < D1; ++r) g[r] = values[v[r]];
     float acc = 0.f;
@@ -501,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict
         const float4 g = values[(size_t)v * nch + ch];
         acc.x += w * g.x / denom; acc.y += w * g.y / denom; acc.z += w * g.z / denom; acc.w += w * g.w / denom;
     }
-    const size_t row = (size_t)((int)perm[p] - own_begin);
+    const size_t row = perm ? (size_t)((int)perm[p] - own_begin) : (size_t)pl;
     float *o = out + row * vd + 4 * ch;
     const int left = vd - 4 * ch;
     if (left >= 4 && (vd & 3) == 0) {
@@ -520,7 +615,7 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
     if (n_own == 0) return PLX_OK;
     const int *evid = L->evid.as<int>();
     const float *ew = L->ew.as<float>();
-    const uint32_t *perm = L->perm.as<uint32_t>();
+    const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
     const int n = (int)L->n, ob = (int)L->own_begin;
     if (vd == 1) {
         const int grid = ceil_div(n_own, kBlock);

@@ -39,7 +39,9 @@
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
-int g_csr_point_major = 1;   // corners of one vertex row ordered by point (1) or by corner index then point (0)
+int g_compact_nbr = 1;        // 0 never, 1 when under half of the neighbour slots exist, 2 always (A/B)
+int g_csr_point_major = 0;   // corners of one vertex row ordered by corner index then point (0, coalesced key
+                             // writes) or by point (1; measured: no gain in splat, 5x slower key kernel)
 
 // ----------------------------------------------------------------------------
 // small device helpers
@@ -469,6 +471,91 @@ __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__rest
 }
 
 // ----------------------------------------------------------------------------
+// compaction of the neighbour table for sparse lattices.  A "quad" is 4 consecutive
+// vertices (what one blur thread handles); bit j*2r+s of its mask says neighbour s
+// of vertex j exists.  Ids are stored densely in (quad, bit) order; a wave of the
+// blur kernel finds its ids at cbase[wave] + (prefix of popcounts over its lanes).
+
+__device__ __forceinline__ uint32_t quad_mask(const int *__restrict__ nbr_axis, int64_t mstride, int taps2,
+                                              int i0, int m)
+{
+    uint32_t mask = 0;
+    for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j;
+        if (i >= m) break;
+        for (int s = 0; s < taps2; ++s)
+            if (nbr_axis[s * mstride + i] >= 0) mask |= 1u << (j * taps2 + s);
+    }
+    return mask;
+}
+
+__global__ __launch_bounds__(kBlock) void compact_count_kernel(const int *__restrict__ nbr, int m, int64_t mstride,
+                                                               int taps2, int64_t nquads, int64_t nqwaves,
+                                                               uint32_t *__restrict__ cmask,
+                                                               uint32_t *__restrict__ cbase)
+{
+    const int axis = blockIdx.y;
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int *nb = nbr + (size_t)axis * taps2 * mstride;
+    uint32_t mask = 0;
+    if (q < nquads) {
+        mask = quad_mask(nb, mstride, taps2, (int)(q * 4), m);
+        cmask[(size_t)axis * nquads + q] = mask;
+    }
+    int cnt = __popc(mask);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+    const int64_t w = q >> 6;
+    if ((threadIdx.x & 63) == 0 && w < nqwaves) cbase[(size_t)axis * (nqwaves + 1) + w] = (uint32_t)cnt;
+}
+
+// exclusive scan of the wave counts of every axis (one workgroup per axis); totals -> counters[2 + axis]
+__global__ __launch_bounds__(kBlock) void compact_scan_kernel(uint32_t *__restrict__ cbase, int64_t nqwaves,
+                                                              int *__restrict__ counters)
+{
+    uint32_t *base = cbase + (size_t)blockIdx.x * (nqwaves + 1);
+    int carry = 0;
+    for (int64_t b = 0; b < nqwaves; b += kBlock) {
+        const int64_t i = b + threadIdx.x;
+        const int v = (i < nqwaves) ? (int)base[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        if (i < nqwaves) base[i] = (uint32_t)(carry + ex);
+        carry += total;
+    }
+    if (threadIdx.x == 0) { base[nqwaves] = (uint32_t)carry; counters[2 + blockIdx.x] = carry; }
+}
+
+struct AxisOffsets { long long off[PLX_MAX_DIM + 2]; };
+
+__global__ __launch_bounds__(kBlock) void compact_fill_kernel(const int *__restrict__ nbr, int m, int64_t mstride,
+                                                              int taps2, int64_t nquads, int64_t nqwaves,
+                                                              const uint32_t *__restrict__ cmask,
+                                                              const uint32_t *__restrict__ cbase, AxisOffsets ao,
+                                                              int *__restrict__ cids)
+{
+    const int axis = blockIdx.y;
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int *nb = nbr + (size_t)axis * taps2 * mstride;
+    const uint32_t mask = (q < nquads) ? cmask[(size_t)axis * nquads + q] : 0u;
+    int incl = __popc(mask);
+    const int cnt = incl;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (q >= nquads) return;
+    const int64_t w = q >> 6;
+    int64_t pos = ao.off[axis] + cbase[(size_t)axis * (nqwaves + 1) + w] + (incl - cnt);
+    const int i0 = (int)(q * 4);
+    for (int j = 0; j < 4; ++j)
+        for (int s = 0; s < taps2; ++s)
+            if (mask & (1u << (j * taps2 + s))) cids[pos++] = nb[s * mstride + i0 + j];
+}
+
+// ----------------------------------------------------------------------------
 // csr: corners of the owned points sorted (stably) by vertex id
 
 __global__ __launch_bounds__(kBlock) void csr_keys_kernel(const int *__restrict__ evid, int n, int own_begin,
@@ -577,9 +664,9 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
     PLX_TRY(ensure(L->flagmask, (size_t)n * 8));
     PLX_TRY(ensure(L->blockcnt, (size_t)(nblocks + 1) * 4));
     PLX_TRY(ensure(L->table, (size_t)cap * 4));
-    PLX_TRY(ensure(L->counters, 64));
+    PLX_TRY(ensure(L->counters, 256));
 
-    PLX_HIP_TRY(hipMemsetAsync(L->counters.p, 0, 64, stream));
+    PLX_HIP_TRY(hipMemsetAsync(L->counters.p, 0, 256, stream));
     PLX_HIP_TRY(hipMemsetAsync(L->table.p, 0xFF, (size_t)cap * 4, stream));
 
     mark();
@@ -631,6 +718,32 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
         neighbor_kernel<D><<<dim3(ceil_div(m, kBlock), D1), kBlock, 0, stream>>>(
             L->vkeys.as<uint32_t>(), m, L->mstride, order, L->table.as<uint32_t>(), L->table_mask,
             L->nbr.as<int>());
+    // compacted copy for sparse lattices (used by the vd = 1 blur when under half the neighbours exist)
+    L->use_compact = false;
+    if (order >= 1 && order <= 3 && g_compact_nbr != 0) {
+        const int taps2 = 2 * order;
+        L->nquads = ((int64_t)m + 3) / 4;
+        L->nqwaves = (L->nquads + 63) / 64;
+        PLX_TRY(ensure(L->cmask, (size_t)D1 * L->nquads * 4));
+        PLX_TRY(ensure(L->cbase, (size_t)D1 * (L->nqwaves + 1) * 4));
+        dim3 cgrid((unsigned)ceil_div(L->nqwaves * 64, kBlock), D1);
+        compact_count_kernel<<<cgrid, kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, taps2, L->nquads,
+                                                           L->nqwaves, L->cmask.as<uint32_t>(), L->cbase.as<uint32_t>());
+        compact_scan_kernel<<<D1, kBlock, 0, stream>>>(L->cbase.as<uint32_t>(), L->nqwaves, L->counters.as<int>());
+        PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned, L->counters.p, 4 * (2 + D1), hipMemcpyDeviceToHost, stream));
+        PLX_HIP_TRY(hipStreamSynchronize(stream));
+        AxisOffsets ao;
+        int64_t total = 0;
+        for (int a = 0; a < D1; ++a) { ao.off[a] = total; L->compact_off[a] = total; total += L->h_pinned[2 + a]; }
+        const double fill = (double)total / ((double)m * taps2 * D1);
+        if (g_compact_nbr == 2 || fill < 0.5) {
+            PLX_TRY(ensure(L->cids, (size_t)total * 4 + 64));
+            compact_fill_kernel<<<cgrid, kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, taps2, L->nquads,
+                                                              L->nqwaves, L->cmask.as<uint32_t>(),
+                                                              L->cbase.as<uint32_t>(), ao, L->cids.as<int>());
+            L->use_compact = true;
+        }
+    }
     mark();
 
     // splat CSR over the owned points

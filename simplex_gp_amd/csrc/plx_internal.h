@@ -47,6 +47,7 @@ struct plx_lattice {
     int device = 0;
     bool built = false;
     bool timing = false;
+    bool lattice_rows = false;   // d_src / d_out rows are in lattice order (plx_set_row_order)
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
 
     // problem
@@ -82,6 +83,15 @@ struct plx_lattice {
     plx::DevBuf ew;         // float  [d+1][n]       barycentric weights
     plx::DevBuf evid;       // int32  [d+1][n]       vertex ids
     plx::DevBuf nbr;        // int32  [d+1][2r][mstride]
+    // compacted neighbour table (vd = 1 blur on sparse lattices): per axis, per quad of 4
+    // vertices a bit mask of the existing neighbours, per wave (256 vertices) the offset of
+    // its first id, and the existing ids only, in (vertex, tap) order
+    bool use_compact = false;
+    int64_t nquads = 0, nqwaves = 0;             // ceil(m/4), ceil(nquads/64)
+    int64_t compact_off[PLX_MAX_DIM + 2] = {};   // first id of each axis in cids
+    plx::DevBuf cmask;      // uint32 [d+1][nquads]
+    plx::DevBuf cbase;      // uint32 [d+1][nqwaves + 1]
+    plx::DevBuf cids;       // int32  [total existing neighbours]
     plx::DevBuf csr_pt;     // int32  [nnz]          local (owned) point index, sorted by vertex
     plx::DevBuf csr_w;      // float  [nnz]
     plx::DevBuf row_ptr;    // int32  [m+1]

@@ -55,6 +55,9 @@ class Lattice:
         nv.check(nv.lib().plx_create(self.device.index, ctypes.byref(self._h)), "plx_create")
         self._ref = None          # keeps the positions alive while kernels may still read them
         self.taps = None
+        self._perm_cache = None
+        self._own_begin = 0
+        self.lattice_rows = False
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -84,6 +87,9 @@ class Lattice:
         nv.check(rc, "plx_build")
         self._ref = ref
         self.taps = taps
+        self._perm_cache = None
+        base, extra = divmod(n, count)
+        self._own_begin = index * base + min(index, extra)
         return self
 
     @property
@@ -109,6 +115,30 @@ class Lattice:
     @property
     def device_bytes(self):
         return int(nv.lib().plx_device_bytes(self._h))
+
+    # -- row order ----------------------------------------------------------
+    def shard_perm(self):
+        """int64 tensor: caller row (within this shard) of the i-th row in lattice order."""
+        if self._perm_cache is None:
+            perm = torch.from_numpy(self.export(nv.ARRAY_POINT_PERM).astype(np.int64))
+            n_own = self.n_owned
+            # rows of this shard occupy the same index range in both orders
+            begin = self._own_begin
+            self._perm_cache = (perm[begin:begin + n_own] - begin).to(self.device)
+        return self._perm_cache
+
+    def set_lattice_row_order(self, on=True):
+        """on: splat/slice/apply take and return rows in lattice order (no per-MVM permutation)."""
+        nv.check(nv.lib().plx_set_row_order(self._h, 1 if on else 0), "plx_set_row_order")
+        self.lattice_rows = bool(on)
+
+    def to_lattice_order(self, t):
+        return t.index_select(0, self.shard_perm())
+
+    def from_lattice_order(self, t):
+        out = torch.empty_like(t)
+        out.index_copy_(0, self.shard_perm(), t)
+        return out
 
     def set_timing(self, on=True):
         nv.check(nv.lib().plx_set_timing(self._h, 1 if on else 0), "plx_set_timing")

@@ -116,6 +116,26 @@ class LatticeGP(nn.Module):
             return self.outputscale * K.matmul(V) + self.noise * V
         return mm
 
+    def khat_solve(self, x, rhs, **cg_args):
+        """(s K + sigma^2 I)^-1 rhs by batched CG, no gradients.  On the HIP path the
+        iteration runs in lattice row order: the right-hand side is permuted once, every
+        MVM skips its two row permutations, the solution is permuted back once (dot
+        products do not care about row order)."""
+        from . import lattice_kernel as lk
+        with torch.no_grad():
+            if lk.LatticeFilterGeneral.method is not None or not x.is_cuda:
+                return batched_cg(self.khat_matmul(x), rhs, **cg_args)
+            ref = x.div(self.kernel.lengthscale).contiguous()
+            lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
+            s, noise = self.outputscale, self.noise
+            lat.set_lattice_row_order(True)
+            try:
+                sol, info = batched_cg(lambda V: s * lat.apply(V.contiguous()) + noise * V,
+                                       lat.to_lattice_order(rhs), **cg_args)
+            finally:
+                lat.set_lattice_row_order(False)
+            return lat.from_lattice_order(sol), info
+
 
 def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, reduce=None,
                             n_total=None):
@@ -137,7 +157,7 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     mm = model.khat_matmul(x)
     with torch.no_grad():
         rhs = torch.cat([r.detach(), Z], 1)
-        sol, info = batched_cg(mm, rhs, max_iter=max_cg_iter, tol=cg_tol, reduce=reduce, want_tridiag=True)
+        sol, info = model.khat_solve(x, rhs, max_iter=max_cg_iter, tol=cg_tol, reduce=reduce, want_tridiag=True)
         u, W = sol[:, :1], sol[:, 1:]
         quad = _colsum(r.detach(), u, reduce).sum()
         logdet = slq_logdet(info["tridiag"][1:], n)
@@ -145,9 +165,7 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     KV = mm(torch.cat([u, Z], 1))                                # differentiable MVM
     s_quad = -(u * r).sum() + 0.5 * (u * KV[:, :1]).sum()
     s_logdet = -0.5 * (W * KV[:, 1:]).sum() / num_probes
-    surrogate = s_quad + s_logdet
-    if reduce is not None:
-        surrogate = surrogate  # gradients of sharded parameters are summed by the caller's all-reduce
+    surrogate = s_quad + s_logdet       # sharded runs: the caller all-reduces the parameter gradients
     out = (value.to(surrogate.dtype) + (surrogate - surrogate.detach())) / n
     out.cg_info = info
     return out

@@ -191,3 +191,26 @@ def test_cg_config3_small(plx):
         resid = (mm(sol) - rhs).norm(dim=0) / rhs.norm(dim=0)
     assert info["iterations"] == 50 and cache.misses == misses0 + 1
     assert float(resid.max()) < 0.05
+
+
+def test_lattice_row_order_mode(plx):
+    """plx_set_row_order: rows in lattice order in and out == permuted caller-order result."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(20000, 4, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    lat = plx.Lattice().build(x, taps)
+    for vd in (1, 3):
+        v = torch.randn(20000, vd, generator=g).cuda()
+        want = lat.apply(v).clone()
+        lat.set_lattice_row_order(True)
+        got_l = lat.apply(lat.to_lattice_order(v).contiguous())
+        lat.set_lattice_row_order(False)
+        assert torch.equal(lat.from_lattice_order(got_l), want)
+    # the solver's lattice-order CG gives the same solution as the caller-order CG
+    from simplex_gp_amd import solvers
+    model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=4)).cuda()
+    rhs = torch.randn(20000, 3, generator=g).cuda()
+    with torch.no_grad():
+        a, _ = model.khat_solve(x, rhs, max_iter=30, tol=1e-10)
+        b, _ = solvers.batched_cg(model.khat_matmul(x), rhs, max_iter=30, tol=1e-10)
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
