@@ -156,6 +156,15 @@ int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref,
                int64_t n, int d, int vd, const float *h_taps, int ntaps,
                float *d_out, void *stream);
 
+/*
+ * Column-wise dot products of two row-major device matrices, d_out[c] = sum_r
+ * a[r][c] * b[r][c]: the reduction a batched-CG caller needs per iteration
+ * (GPyTorch's mBCG does it with torch ops).  Deterministic (fixed reduction
+ * order).  d_work: plx_coldot_work_floats(vd) floats of device scratch.
+ */
+int plx_coldot(const float *d_a, const float *d_b, int64_t n, int vd, float *d_out, float *d_work, void *stream);
+int64_t plx_coldot_work_floats(int vd);
+
 /* Copy one structure array to host memory (parity tests, debugging).
  * h_dst must hold `bytes` bytes, which must equal the array's size. */
 int plx_export(plx_lattice *lat, int which, void *h_dst, int64_t bytes, void *stream);

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "plx_slice": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "plx_apply": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "plx_filter": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32p, _i32, _vp, _vp]),
+    "plx_coldot": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "plx_coldot_work_floats": (_i64, [_i32]),
     "plx_export": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "plx_export_bytes": (_i64, [_vp, _i32]),
     "plx_tune": (_i32, [ctypes.c_char_p, _i32]),

@@ -1,0 +1,71 @@
+// plx_linalg.hip -- the one dense reduction the CG caller needs next to the MVM:
+// column-wise dot products of two row-major [n][vd] matrices (vd = 1 + probes is
+// small, n is large), deterministic.  torch's (a*b).sum(0) takes 1.3 ms on
+// [1e6][11]; this is two streaming reads (~20 us).
+#include "plx_internal.h"
+
+namespace plx {
+
+constexpr int kDotBlocks = 1024;
+
+// threads = (row lane, column lane), column fastest; CW = power of two >= vd
+__global__ __launch_bounds__(kBlock) void coldot_partial_kernel(const float *__restrict__ a,
+                                                                const float *__restrict__ b, int64_t n, int vd,
+                                                                int logcw, float *__restrict__ partial)
+{
+    __shared__ float red[kBlock];
+    const int cw = 1 << logcw;
+    const int c = threadIdx.x & (cw - 1);
+    const int rl = threadIdx.x >> logcw;
+    const int rows_per_step = kBlock >> logcw;
+    const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, n);
+    float acc = 0.f;
+    if (c < vd)
+        for (int64_t r = r0 + rl; r < r1; r += rows_per_step) acc += a[r * vd + c] * b[r * vd + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    // fixed-order sum over the row lanes of each column
+    if (rl == 0 && c < vd) {
+        float s = 0.f;
+        for (int k = 0; k < rows_per_step; ++k) s += red[(k << logcw) + c];
+        partial[(size_t)blockIdx.x * vd + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void coldot_final_kernel(const float *__restrict__ partial, int nblocks, int vd,
+                                                              float *__restrict__ out)
+{
+    __shared__ float red[kBlock];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < nblocks; k += kBlock) acc += partial[(size_t)k * vd + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
+}
+
+}  // namespace plx
+
+using namespace plx;
+
+extern "C" int plx_coldot(const float *d_a, const float *d_b, int64_t n, int vd, float *d_out, float *d_work,
+                          void *stream)
+{
+    if (!d_a || !d_b || !d_out || !d_work) { set_error("plx_coldot: NULL argument"); return PLX_ERR_INVALID; }
+    if (n < 0 || vd < 1 || vd > kBlock) { set_error("plx_coldot: vd = %d outside 1..%d", vd, kBlock); return PLX_ERR_INVALID; }
+    int logcw = 0;
+    while ((1 << logcw) < vd) ++logcw;
+    hipStream_t s = (hipStream_t)stream;
+    coldot_partial_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_a, d_b, n, vd, logcw, d_work);
+    coldot_final_kernel<<<vd, kBlock, 0, s>>>(d_work, kDotBlocks, vd, d_out);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int64_t plx_coldot_work_floats(int vd) { return (int64_t)kDotBlocks * (vd > 0 ? vd : 1); }

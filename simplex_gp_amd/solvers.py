@@ -21,8 +21,32 @@ import torch.nn.functional as F
 from .lattice_kernel import LatticeAccelerated
 
 
+_dot_work = {}
+
+
 def _colsum(a, b, reduce=None):
-    s = (a * b).sum(0)
+    """Column-wise <a, b> of two [n, t] matrices (summed over ranks through `reduce`).
+    On the GPU this is libplx's plx_coldot (torch's (a*b).sum(0) is ~60x slower on
+    tall, narrow row-major matrices); elsewhere plain torch."""
+    if (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2
+            and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.shape[1] <= 256):
+        import ctypes
+        from . import _native as nv
+        n, t = a.shape
+        key = (a.device.index, t)
+        work = _dot_work.get(key)
+        if work is None:
+            work = _dot_work[key] = torch.empty(int(nv.lib().plx_coldot_work_floats(t)), dtype=torch.float32,
+                                                device=a.device)
+        out = torch.empty(t, dtype=torch.float32, device=a.device)
+        with torch.cuda.device(a.device):
+            rc = nv.lib().plx_coldot(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n, t,
+                                     ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(work.data_ptr()),
+                                     ctypes.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
+        nv.check(rc, "plx_coldot")
+        s = out
+    else:
+        s = (a * b).sum(0)
     return reduce(s) if reduce is not None else s
 
 
@@ -35,7 +59,7 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
     """
     X = torch.zeros_like(B)
-    R = B.clone()
+    R = B.clone().contiguous()
     P = R.clone()
     rs = _colsum(R, R, reduce)
     b_norm = rs.sqrt().clamp_min(1e-30)
@@ -43,17 +67,17 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     active = torch.ones_like(rs, dtype=torch.bool)
     it = 0
     for it in range(1, max_iter + 1):
-        AP = matmul(P)
+        AP = matmul(P).contiguous()
         pAp = _colsum(P, AP, reduce)
         alpha = torch.where(active, rs / pAp.clamp_min(1e-30), torch.zeros_like(rs))
-        X = X + P * alpha
-        R = R - AP * alpha
+        X.addcmul_(P, alpha)
+        R.addcmul_(AP, -alpha)
         rs_new = _colsum(R, R, reduce)
         beta = torch.where(active, rs_new / rs.clamp_min(1e-30), torch.zeros_like(rs))
         if want_tridiag:
             alphas.append(alpha)
             betas.append(beta)
-        P = R + P * beta
+        P.mul_(beta).add_(R)
         rs = rs_new
         active = active & (rs.sqrt() / b_norm > tol)
         if not bool(active.any()):
@@ -130,7 +154,7 @@ class LatticeGP(nn.Module):
             s, noise = self.outputscale, self.noise
             lat.set_lattice_row_order(True)
             try:
-                sol, info = batched_cg(lambda V: s * lat.apply(V.contiguous()) + noise * V,
+                sol, info = batched_cg(lambda V: lat.apply(V).mul_(s).addcmul_(V, noise),
                                        lat.to_lattice_order(rhs), **cg_args)
             finally:
                 lat.set_lattice_row_order(False)

@@ -214,3 +214,16 @@ def test_lattice_row_order_mode(plx):
         a, _ = model.khat_solve(x, rhs, max_iter=30, tol=1e-10)
         b, _ = solvers.batched_cg(model.khat_matmul(x), rhs, max_iter=30, tol=1e-10)
     assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
+
+
+def test_coldot_matches_torch(plx):
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(4)
+    for n, t in [(1, 1), (1000, 3), (100003, 11), (50000, 64), (20000, 200)]:
+        a = torch.randn(n, t, generator=g).cuda()
+        b = torch.randn(n, t, generator=g).cuda()
+        got = solvers._colsum(a, b)
+        want = (a.double() * b.double()).sum(0)
+        assert got.shape == (t,)
+        assert torch.allclose(got.double(), want, rtol=1e-4, atol=1e-3 * (n ** 0.5)), (n, t)
+        assert torch.equal(got, solvers._colsum(a, b))          # deterministic
