@@ -24,9 +24,10 @@ Also reported on the same JSON line (extra keys):
                    port (oracle/), timed on one full-size MVM on this host
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU): weak scaling,
-n = 1e6 points PER GPU.  Every rank builds the same lattice from all points,
-splats its own rows, one RCCL all-reduce of the vertex accumulators, replicated
-blur, slices its own rows.  value = (n_total / 1e6) * MVMs/s, i.e. 1e6-point
+n = 1e6 points PER GPU.  Build: every rank embeds / inserts its own rows, one
+all-gather of the per-rank vertex keys, merge into one numbering.  MVM: splat own
+rows, one RCCL all-reduce of the vertex accumulators, replicated blur, slice own
+rows.  value = (n_total / 1e6) * MVMs/s, i.e. 1e6-point
 row blocks of K.v produced per second by the whole job.
 """
 import argparse
@@ -194,7 +195,21 @@ def main():
     out = torch.empty_like(v)
 
     lat = plx.Lattice(dev)
-    lat.build(ref, RBF1, shard=(rank, world))
+
+    def build():
+        """One lattice build.  Multi-GPU: every rank embeds / inserts only its own rows, the per-rank
+        vertex keys are all-gathered (the one collective of a build) and merged into one numbering."""
+        if world == 1:
+            lat.build(ref, RBF1)
+        else:
+            keys = lat.build_local(ref_local, RBF1)
+            all_keys, counts = all_gather_rows(keys)
+            lat.build_merge(all_keys, counts, rank)
+
+    if world > 1:
+        from simplex_gp_amd.distributed import all_gather_rows
+        ref_local = ref[lo:hi].contiguous()
+    build()
     m = lat.m
     values = scratch = None
     if world > 1:
@@ -211,7 +226,7 @@ def main():
 
     def step(i):
         if i % args.rebuild_every == 0:
-            lat.build(ref, RBF1, shard=(rank, world))
+            build()
         mvm()
 
     if args.check:
@@ -244,8 +259,8 @@ def main():
                         f"lengthscale {args.ell}, x~N(0,I) seed 1234; one lattice build per "
                         f"{args.rebuild_every} MVMs (CG loop, BASELINE.json configs[2])",
             "n_total": n_total, "m_vertices": m, "rebuild_every": args.rebuild_every,
-            "parallelism": "single GPU" if world == 1 else f"points sharded x{world}, replicated lattice build, "
-                                                              "RCCL all-reduce of vertex values, replicated blur",
+            "parallelism": "single GPU" if world == 1 else f"points sharded x{world}; build: local + all-gather of vertex "
+                                                              "keys + merge; MVM: RCCL all-reduce of vertex values, replicated blur",
             "value_definition": "MVMs/s" if world == 1 else "(n_total/1e6) x MVMs/s of the n_total-point operator",
         },
     }

@@ -18,8 +18,8 @@
  *   - every data pointer is DEVICE memory (fp32, row-major, contiguous) on the
  *     lattice's device unless the name starts with h_ (host);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
- *     work is enqueued on it.  plx_build() synchronises that stream once (it
- *     must learn the vertex count m to size the lattice); plx_splat / plx_blur /
+ *     work is enqueued on it.  plx_build() synchronises that stream (once to learn
+ *     the vertex count m that sizes the lattice, once more for the neighbour count); plx_splat / plx_blur /
  *     plx_slice / plx_apply never synchronise and never allocate once their
  *     workspace has reached its high-water mark, so they are graph-capturable;
  *   - every function returns PLX_OK (0) or an error code; nothing calls exit()
@@ -101,6 +101,28 @@ void plx_destroy(plx_lattice *lat);
 int plx_build(plx_lattice *lat, const float *d_ref, int64_t n, int d,
               const float *h_taps, int ntaps,
               int shard_index, int n_shards, void *stream);
+
+/*
+ * Sharded build without replicated work (alternative to calling plx_build with the
+ * full d_ref on every rank): every rank passes ONLY ITS OWN rows.
+ *   1. plx_build_local     embeds / inserts / numbers the rank's own points;
+ *   2. the caller exchanges the per-rank vertex keys: m_r = plx_local_vertices(),
+ *      keys = [m_r][plx_key_words(d)] uint32 (plx_copy_local_keys), all-gathered in
+ *      rank order (RCCL all_gather through torch.distributed in this repo);
+ *   3. plx_build_merge     numbers the union (first occurrence in rank order, then
+ *      local order: the same ids plx_build's shard-major numbering produces),
+ *      relabels the local corners, builds the neighbour table over the union and the
+ *      splat CSR / slice tables over the rank's rows.
+ * Afterwards the lattice behaves like one built by plx_build for that shard:
+ * plx_num_points / plx_num_owned = n_local, plx_num_vertices = size of the union.
+ */
+int plx_build_local(plx_lattice *lat, const float *d_ref_local, int64_t n_local, int d,
+                    const float *h_taps, int ntaps, void *stream);
+int plx_key_words(int d);                               /* uint32 words per packed vertex key: ceil(d/2) */
+int64_t plx_local_vertices(const plx_lattice *lat);     /* m_r after plx_build_local                     */
+int plx_copy_local_keys(plx_lattice *lat, void *d_dst, void *stream);   /* d_dst: [m_r][key_words] uint32 */
+int plx_build_merge(plx_lattice *lat, const void *d_all_keys, const int64_t *h_counts, int n_ranks,
+                    int my_rank, void *stream);
 
 int64_t plx_num_points(const plx_lattice *lat);    /* n                              */
 int64_t plx_num_owned(const plx_lattice *lat);     /* rows of this shard             */

@@ -40,7 +40,7 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
     return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
             &L->sort_keys_in, &L->sort_keys_out, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_w, &L->row_ptr,
-            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids,
+            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
             &L->sortkey_in, &L->sortkey_out};
 }
 
@@ -129,12 +129,72 @@ int plx_build(plx_lattice *L, const float *d_ref, int64_t n, int d, const float 
     DeviceGuard g(L->device);
     if (!g.ok) { set_error("plx_build: cannot select device %d", L->device); return PLX_ERR_HIP; }
     L->built = false;
+    L->local_ready = false;
     L->n = n; L->d = d; L->ntaps = ntaps; L->order = ntaps / 2;
     L->shard_index = shard_index; L->n_shards = n_shards;
     shard_range(n, n_shards, shard_index, &L->own_begin, &L->own_end);
     memset(&L->taps, 0, sizeof(L->taps));
     for (int i = 0; i < ntaps; ++i) L->taps.c[i] = h_taps[i];
     int rc = build_impl(L, d_ref, (hipStream_t)stream);
+    if (rc == PLX_OK) L->built = true;
+    return rc;
+}
+
+// ---- sharded build: local stage, key exchange by the caller, merge stage ------------------------
+
+int plx_build_local(plx_lattice *L, const float *d_ref_local, int64_t n_local, int d, const float *h_taps, int ntaps,
+                    void *stream)
+{
+    if (!L || !d_ref_local || !h_taps) { set_error("plx_build_local: NULL argument"); return PLX_ERR_INVALID; }
+    if (n_local <= 0) { set_error("plx_build_local: n_local = %lld must be positive", (long long)n_local); return PLX_ERR_INVALID; }
+    if (d < 1 || d > PLX_MAX_DIM) { set_error("plx_build_local: d = %d outside 1..%d", d, PLX_MAX_DIM); return PLX_ERR_DIM; }
+    if (ntaps < 1 || (ntaps % 2) == 0) { set_error("plx_build_local: tap count %d must be odd", ntaps); return PLX_ERR_INVALID; }
+    if (ntaps / 2 > PLX_MAX_ORDER) { set_error("plx_build_local: order %d > %d", ntaps / 2, PLX_MAX_ORDER); return PLX_ERR_DIM; }
+    if (n_local * (int64_t)(d + 1) >= (1ll << 31) - 1024) {
+        set_error("plx_build_local: n*(d+1) = %lld does not fit the 31-bit entry index", (long long)(n_local * (d + 1)));
+        return PLX_ERR_TOO_LARGE;
+    }
+    DeviceGuard g(L->device);
+    if (!g.ok) { set_error("plx_build_local: cannot select device %d", L->device); return PLX_ERR_HIP; }
+    L->built = false;
+    L->local_ready = false;
+    L->n = n_local; L->d = d; L->ntaps = ntaps; L->order = ntaps / 2;
+    L->shard_index = 0; L->n_shards = 1;
+    L->own_begin = 0; L->own_end = n_local;
+    memset(&L->taps, 0, sizeof(L->taps));
+    for (int i = 0; i < ntaps; ++i) L->taps.c[i] = h_taps[i];
+    int rc = build_local_impl(L, d_ref_local, (hipStream_t)stream);
+    if (rc == PLX_OK) L->local_ready = true;
+    return rc;
+}
+
+int plx_key_words(int d) { return (d >= 1 && d <= PLX_MAX_DIM) ? (d + 1) / 2 : -1; }
+
+int64_t plx_local_vertices(const plx_lattice *L) { return (L && (L->local_ready || L->built)) ? L->m : -1; }
+
+int plx_copy_local_keys(plx_lattice *L, void *d_dst, void *stream)
+{
+    if (!L || !d_dst) { set_error("plx_copy_local_keys: NULL argument"); return PLX_ERR_INVALID; }
+    if (!L->local_ready) { set_error("plx_copy_local_keys: call plx_build_local first"); return PLX_ERR_STATE; }
+    DeviceGuard g(L->device);
+    PLX_HIP_TRY(hipMemcpyAsync(d_dst, L->vkeys.p, (size_t)L->m * plx_key_words(L->d) * 4, hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+    return PLX_OK;
+}
+
+int plx_build_merge(plx_lattice *L, const void *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
+                    void *stream)
+{
+    if (!L || !d_all_keys || !h_counts) { set_error("plx_build_merge: NULL argument"); return PLX_ERR_INVALID; }
+    if (!L->local_ready) { set_error("plx_build_merge: call plx_build_local first"); return PLX_ERR_STATE; }
+    if (n_ranks < 1 || my_rank < 0 || my_rank >= n_ranks) {
+        set_error("plx_build_merge: rank %d of %d", my_rank, n_ranks);
+        return PLX_ERR_INVALID;
+    }
+    DeviceGuard g(L->device);
+    if (!g.ok) { set_error("plx_build_merge: cannot select device %d", L->device); return PLX_ERR_HIP; }
+    int rc = build_merge_impl(L, (const uint32_t *)d_all_keys, h_counts, n_ranks, my_rank, (hipStream_t)stream);
+    L->local_ready = false;
     if (rc == PLX_OK) L->built = true;
     return rc;
 }

@@ -281,7 +281,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));
         return PLX_OK;
     }
-    const bool all_rows_touched = (L->n_shards == 1);
+    const bool all_rows_touched = (L->n_shards == 1 && !L->partial_cover);
     if (!all_rows_touched) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));
     PLX_TRY(ensure(L->head_partial, (size_t)L->nchunks * vdp * 4));
     PLX_TRY(ensure(L->tail_partial, (size_t)L->nchunks * vdp * 4));

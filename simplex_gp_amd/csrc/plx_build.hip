@@ -611,18 +611,18 @@ static float taps_variance(const float *c, int R)
     return mom2 / mom0 - mean * mean;
 }
 
+// ---- stage 1: everything that depends only on this lattice's own points --------------------
+// order, embed, hashed insert, first-touch numbering, per-corner vertex ids.  Leaves L->m (the
+// number of vertices THESE points touch), vkeys, evid, ew, perm and the key -> id table.
 template <int D>
-static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
+static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, int *evi)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
     const int n = (int)L->n;
-    const int n_own = (int)(L->own_end - L->own_begin);
     const int64_t E = (int64_t)n * D1;
     const int nblocks = ceil_div(n, kBlock);
-    const bool T = L->timing;
-    int evi = 0;
-    auto mark = [&]() { if (T) (void)hipEventRecord(L->ev[evi++], stream); };
+    auto mark = [&]() { if (L->timing) (void)hipEventRecord(L->ev[(*evi)++], stream); };
 
     // scale factors exactly as the reference computes them (h:372-390)
     ScaleArgs sf;
@@ -689,24 +689,14 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
                                                 L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
     scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
     PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned, L->counters.p, 8, hipMemcpyDeviceToHost, stream));
-    PLX_HIP_TRY(hipStreamSynchronize(stream));   // the one sync of a build: m sizes everything below
+    PLX_HIP_TRY(hipStreamSynchronize(stream));   // m sizes everything below
     if (L->h_pinned[1] != 0) {
         set_error("a lattice coordinate left the int16 key range (|x/lengthscale| too large, NaN or Inf)");
         return PLX_ERR_KEY_RANGE;
     }
     const int m = L->h_pinned[0];
     L->m = m;
-    L->mstride = ((int64_t)m + 63) & ~63ll;
-    L->nnz = (int64_t)n_own * D1;
-    L->nchunks = ceil_div(L->nnz, kSplatChunk);
-    const int order = L->order;
-
-    PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4));
-    PLX_TRY(ensure(L->nbr, (size_t)D1 * 2 * order * L->mstride * 4 + 4));
-    PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
-    PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
-    PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
-
+    PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));
     assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->blockcnt.as<int>(),
                                                      L->eslot.as<uint32_t>(), L->ekeys.as<uint32_t>(), n,
                                                      L->table.as<uint32_t>(), L->vkeys.as<uint32_t>());
@@ -714,6 +704,155 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
     ids_kernel<<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
                                                          L->evid.as<int>());
     mark();
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+// ---- stage 2 (sharded jobs only): merge the vertex sets of all ranks ---------------------------
+// all_keys = every rank's local vertex keys, concatenated in rank order, each block in that
+// rank's local id order.  First occurrence wins, ids in order of first occurrence: exactly the
+// first-touch numbering of the shard-major point order, the same on every rank.
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void merge_insert_kernel(const uint32_t *__restrict__ keys, int M,
+                                                              uint32_t *__restrict__ table, uint32_t mask,
+                                                              uint32_t *__restrict__ slot)
+{
+    constexpr int DW = (D + 1) / 2;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= M) return;
+    uint32_t k[DW];
+    load_key<DW>(keys, (size_t)idx, k);
+    uint32_t h = mix_hash(k, DW) & mask;
+    for (;;) {
+        uint32_t o = table[h];
+        if (o == kEmpty) {
+            o = atomicCAS(&table[h], kEmpty, (uint32_t)idx);
+            if (o == kEmpty) break;
+        }
+        if (o == (uint32_t)idx) break;
+        uint32_t ko[DW];
+        load_key<DW>(keys, (size_t)o, ko);
+        if (key_equal<DW>(k, ko)) {
+            if ((uint32_t)idx < o) atomicMin(&table[h], (uint32_t)idx);
+            break;
+        }
+        h = (h + 1) & mask;
+    }
+    slot[idx] = h;
+}
+
+__global__ __launch_bounds__(kBlock) void merge_flag_kernel(const uint32_t *__restrict__ slot,
+                                                            const uint32_t *__restrict__ table, int M,
+                                                            uint32_t *__restrict__ flags, int *__restrict__ blockcnt)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    int first = 0;
+    if (idx < M) {
+        first = table[slot[idx]] == (uint32_t)idx ? 1 : 0;
+        flags[idx] = (uint32_t)first;
+    }
+    int total;
+    block_exclusive_scan(first, &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void merge_assign_kernel(const uint32_t *__restrict__ flags,
+                                                              const int *__restrict__ blockoff,
+                                                              const uint32_t *__restrict__ slot,
+                                                              const uint32_t *__restrict__ keys, int M,
+                                                              uint32_t *__restrict__ table,
+                                                              uint32_t *__restrict__ gkeys)
+{
+    constexpr int DW = (D + 1) / 2;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const int first = (idx < M) ? (int)flags[idx] : 0;
+    int total;
+    const int gid = blockoff[blockIdx.x] + block_exclusive_scan(first, &total);
+    if (idx < M && first) {
+        table[slot[idx]] = (uint32_t)gid;
+        uint32_t k[DW];
+        load_key<DW>(keys, (size_t)idx, k);
+        store_key<DW>(gkeys, (size_t)gid, k);
+    }
+}
+
+// evid[i] = global id of local vertex evid[i]  (its key sits at all_keys[my_off + local id])
+__global__ __launch_bounds__(kBlock) void merge_remap_kernel(int *__restrict__ evid, int64_t E,
+                                                             const uint32_t *__restrict__ slot,
+                                                             const uint32_t *__restrict__ table, int my_off)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < E) evid[i] = (int)table[slot[my_off + evid[i]]];
+}
+
+template <int D>
+static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
+                       hipStream_t stream)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    int64_t M = 0, my_off = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        if (r == my_rank) my_off = M;
+        M += h_counts[r];
+    }
+    if (h_counts[my_rank] != L->m) {
+        set_error("plx_build_merge: rank %d announced %lld local vertices, the lattice has %lld", my_rank,
+                  (long long)h_counts[my_rank], (long long)L->m);
+        return PLX_ERR_STATE;
+    }
+    if (M >= (1ll << 31) - 1024) { set_error("plx_build_merge: %lld keys in total", (long long)M); return PLX_ERR_TOO_LARGE; }
+    uint64_t cap = 1024;
+    while (cap < 2ull * (uint64_t)M) cap <<= 1;
+    const int nblocks = ceil_div(M, kBlock);
+    PLX_TRY(ensure(L->table, (size_t)cap * 4));
+    PLX_TRY(ensure(L->merge_slot, (size_t)M * 4 + 16));
+    PLX_TRY(ensure(L->merge_flags, (size_t)M * 4 + 16));
+    PLX_TRY(ensure(L->blockcnt, (size_t)(nblocks + 1) * 4));
+    L->table_mask = (uint32_t)(cap - 1);
+    PLX_HIP_TRY(hipMemsetAsync(L->table.p, 0xFF, (size_t)cap * 4, stream));
+    merge_insert_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_all_keys, (int)M, L->table.as<uint32_t>(), L->table_mask,
+                                                           L->merge_slot.as<uint32_t>());
+    merge_flag_kernel<<<nblocks, kBlock, 0, stream>>>(L->merge_slot.as<uint32_t>(), L->table.as<uint32_t>(), (int)M,
+                                                      L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>());
+    scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
+    PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned, L->counters.p, 8, hipMemcpyDeviceToHost, stream));
+    PLX_HIP_TRY(hipStreamSynchronize(stream));
+    const int m = L->h_pinned[0];
+    PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));   // local keys are no longer needed: all_keys holds them
+    merge_assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>(),
+                                                           L->merge_slot.as<uint32_t>(), d_all_keys, (int)M,
+                                                           L->table.as<uint32_t>(), L->vkeys.as<uint32_t>());
+    const int64_t E = L->n * D1;
+    merge_remap_kernel<<<ceil_div(E, kBlock), kBlock, 0, stream>>>(L->evid.as<int>(), E, L->merge_slot.as<uint32_t>(),
+                                                                   L->table.as<uint32_t>(), (int)my_off);
+    L->m = m;
+    L->partial_cover = true;     // this rank's points do not touch every vertex: splat zero-fills first
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+// ---- stage 3: gather tables over the final vertex numbering -------------------------------------
+template <int D>
+static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
+{
+    constexpr int D1 = D + 1;
+    const int n = (int)L->n;
+    const int n_own = (int)(L->own_end - L->own_begin);
+    const int m = (int)L->m;
+    const int order = L->order;
+    auto mark = [&]() { if (L->timing) (void)hipEventRecord(L->ev[(*evi)++], stream); };
+    L->mstride = ((int64_t)m + 63) & ~63ll;
+    L->nnz = (int64_t)n_own * D1;
+    L->nchunks = ceil_div(L->nnz, kSplatChunk);
+
+    PLX_TRY(ensure(L->nbr, (size_t)D1 * 2 * order * L->mstride * 4 + 4));
+    PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
+    PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
+    PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
+
     if (order > 0)
         neighbor_kernel<D><<<dim3(ceil_div(m, kBlock), D1), kBlock, 0, stream>>>(
             L->vkeys.as<uint32_t>(), m, L->mstride, order, L->table.as<uint32_t>(), L->table_mask,
@@ -772,26 +911,79 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
     }
     mark();
     PLX_HIP_TRY(hipGetLastError());
-    if (T) {
+    return PLX_OK;
+}
+
+template <int D>
+static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
+{
+    int evi = 0;
+    L->partial_cover = false;
+    PLX_TRY(stage_local<D>(L, d_ref, stream, &evi));
+    PLX_TRY(stage_tables<D>(L, stream, &evi));
+    if (L->timing) {
         PLX_HIP_TRY(hipStreamSynchronize(stream));
         for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&L->build_ms[i], L->ev[i], L->ev[i + 1]);
     }
     return PLX_OK;
 }
 
+template <int D>
+static int local_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
+{
+    int evi = 0;
+    const bool t = L->timing;
+    L->timing = false;
+    L->partial_cover = false;
+    int rc = stage_local<D>(L, d_ref, stream, &evi);
+    L->timing = t;
+    return rc;
+}
+
+template <int D>
+static int merge_typed(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
+                       hipStream_t stream)
+{
+    int evi = 0;
+    const bool t = L->timing;
+    L->timing = false;
+    int rc = stage_merge<D>(L, d_all_keys, h_counts, n_ranks, my_rank, stream);
+    if (rc == PLX_OK) rc = stage_tables<D>(L, stream, &evi);
+    L->timing = t;
+    return rc;
+}
+
+#define PLX_DIM_SWITCH(CALL)                                                                                  \
+    switch (L->d) {                                                                                           \
+        PLX_CASE(1) PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8)       \
+        PLX_CASE(9) PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) \
+        PLX_CASE(17) PLX_CASE(18) PLX_CASE(19) PLX_CASE(20) PLX_CASE(21) PLX_CASE(22) PLX_CASE(23) PLX_CASE(24) \
+        PLX_CASE(25) PLX_CASE(26) PLX_CASE(27) PLX_CASE(28) PLX_CASE(29) PLX_CASE(30) PLX_CASE(31) PLX_CASE(32) \
+    default:                                                                                                  \
+        set_error("d = %d outside 1..%d", L->d, PLX_MAX_DIM);                                                 \
+        return PLX_ERR_DIM;                                                                                   \
+    }
+
 int build_impl(plx_lattice *L, const float *d_ref, hipStream_t stream)
 {
-    switch (L->d) {
 #define PLX_CASE(D) case D: return build_typed<D>(L, d_ref, stream);
-        PLX_CASE(1) PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8)
-        PLX_CASE(9) PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16)
-        PLX_CASE(17) PLX_CASE(18) PLX_CASE(19) PLX_CASE(20) PLX_CASE(21) PLX_CASE(22) PLX_CASE(23) PLX_CASE(24)
-        PLX_CASE(25) PLX_CASE(26) PLX_CASE(27) PLX_CASE(28) PLX_CASE(29) PLX_CASE(30) PLX_CASE(31) PLX_CASE(32)
+    PLX_DIM_SWITCH()
 #undef PLX_CASE
-    default:
-        set_error("d = %d outside 1..%d", L->d, PLX_MAX_DIM);
-        return PLX_ERR_DIM;
-    }
+}
+
+int build_local_impl(plx_lattice *L, const float *d_ref, hipStream_t stream)
+{
+#define PLX_CASE(D) case D: return local_typed<D>(L, d_ref, stream);
+    PLX_DIM_SWITCH()
+#undef PLX_CASE
+}
+
+int build_merge_impl(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
+                     hipStream_t stream)
+{
+#define PLX_CASE(D) case D: return merge_typed<D>(L, d_all_keys, h_counts, n_ranks, my_rank, stream);
+    PLX_DIM_SWITCH()
+#undef PLX_CASE
 }
 
 }  // namespace plx

@@ -47,6 +47,8 @@ struct plx_lattice {
     int device = 0;
     bool built = false;
     bool timing = false;
+    bool partial_cover = false;  // built by plx_build_merge: this rank's points do not touch every vertex
+    bool local_ready = false;    // plx_build_local done, waiting for plx_build_merge
     bool lattice_rows = false;   // d_src / d_out rows are in lattice order (plx_set_row_order)
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
 
@@ -74,6 +76,7 @@ struct plx_lattice {
     plx::DevBuf flagmask;   // uint32 [n]            bit r set: corner r is the first touch of its vertex
     plx::DevBuf blockcnt;   // int32  [nblocks+1]    per-workgroup first-touch counts, then offsets
     plx::DevBuf table;      // uint32 [capacity]     slot -> min entry index, later slot -> vertex id
+    plx::DevBuf merge_slot, merge_flags;   // uint32 [sum of all ranks' local vertex counts] (sharded build)
     plx::DevBuf counters;   // int32  [8]            {m, error flag, ...}
     plx::DevBuf sort_keys_in, sort_vals_in, sort_vals_out, sort_temp;
     plx::DevBuf sort_keys_out;   // int32 [nnz] sorted vertex id of every owned corner (kept: splat reads it at row ends)
@@ -115,6 +118,9 @@ void release(DevBuf &b);
 
 // plx_build.hip
 int build_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);
+int build_local_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);
+int build_merge_impl(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
+                     hipStream_t stream);
 // plx_sort.hip (rocPRIM radix sort of (vertex id, entry index) pairs)
 int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,

@@ -37,8 +37,31 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+def all_gather_rows(t_local, group=None):
+    """Concatenate every rank's rows (row counts may differ) -> (tensor, counts)."""
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([t_local.shape[0]], dtype=torch.int64, device=t_local.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    counts = [int(c.item()) for c in counts]
+    biggest = max(counts)
+    padded = torch.zeros((biggest,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
+    padded[: t_local.shape[0]] = t_local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:k] for p, k in zip(parts, counts)], 0), counts
+
+
 class ShardedLatticeMVM:
-    """K(ref_all) @ v with v and the result sharded by rows over the group."""
+    """K(ref_all) @ v with v and the result sharded by rows over the group.
+
+    Two ways to build it:
+      ShardedLatticeMVM(ref_all, coeffs)                 every rank holds all positions and builds the
+                                                         whole vertex set itself (no communication)
+      ShardedLatticeMVM.from_local_rows(ref_local, ...)  every rank holds only its rows; the per-rank vertex
+                                                         keys are all-gathered once and merged (no replicated
+                                                         O(N_total) work; same vertex numbering)
+    """
 
     def __init__(self, ref_all, coeffs, group=None, lattice=None):
         self.group = group
@@ -50,6 +73,33 @@ class ShardedLatticeMVM:
         self.lattice.build(ref_all, coeffs, shard=(self.rank, self.world))
         self._vd = None
         self._values = self._scratch = None
+
+    @classmethod
+    def from_local_rows(cls, ref_local, coeffs, group=None, lattice=None, n_total=None):
+        """Build from this rank's rows only (rank r must hold block r of shard_bounds(n_total, world, r))."""
+        self = cls.__new__(cls)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.lattice = lattice if lattice is not None else Lattice(ref_local.device)
+        self._vd = None
+        self._values = self._scratch = None
+        if self.world == 1:
+            self.n = ref_local.shape[0]
+            self.lo, self.hi = 0, self.n
+            self.lattice.build(ref_local, coeffs)
+            return self
+        keys = self.lattice.build_local(ref_local, coeffs)
+        all_keys, counts = all_gather_rows(keys, group)            # the one collective of the build
+        self.lattice.build_merge(all_keys, counts, self.rank)
+        rows = torch.tensor([ref_local.shape[0]], dtype=torch.int64, device=ref_local.device)
+        every = [torch.zeros_like(rows) for _ in range(self.world)]
+        dist.all_gather(every, rows, group=group)
+        every = [int(r.item()) for r in every]
+        self.n = sum(every) if n_total is None else n_total
+        self.lo = sum(every[: self.rank])
+        self.hi = self.lo + every[self.rank]
+        return self
 
     @property
     def m(self):
@@ -86,10 +136,4 @@ class ShardedLatticeMVM:
         """All ranks' row blocks concatenated (for tests / small outputs)."""
         if self.world == 1:
             return t_local
-        rows = [hi - lo for lo, hi in (shard_bounds(self.n, self.world, r) for r in range(self.world))]
-        biggest = max(rows)          # all_gather wants equal shapes: pad the short blocks
-        padded = torch.zeros((biggest,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
-        padded[: t_local.shape[0]] = t_local
-        parts = [torch.empty_like(padded) for _ in rows]
-        dist.all_gather(parts, padded, group=self.group)
-        return torch.cat([p[:k] for p, k in zip(parts, rows)], 0)
+        return all_gather_rows(t_local.contiguous(), self.group)[0]

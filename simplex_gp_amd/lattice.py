@@ -92,6 +92,39 @@ class Lattice:
         self._own_begin = index * base + min(index, extra)
         return self
 
+    # -- sharded build: local stage / key exchange / merge ---------------------
+    def build_local(self, ref_local, coeffs):
+        """Stage 1 of a sharded build: structure of this rank's own rows only.
+        Returns the rank's vertex keys as an int32 tensor [m_local, key_words]."""
+        _check_f32_cuda(ref_local, "ref_local")
+        ref_local = ref_local.contiguous()
+        taps = _taps_array(coeffs)
+        n, d = ref_local.shape
+        L = nv.lib()
+        with torch.cuda.device(self.device):
+            rc = L.plx_build_local(self._h, ctypes.c_void_p(ref_local.data_ptr()), n, d,
+                                   taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), taps.size,
+                                   _stream_ptr(self.device))
+        nv.check(rc, "plx_build_local")
+        self._ref, self.taps, self._perm_cache, self._own_begin = ref_local, taps, None, 0
+        keys = torch.empty((int(L.plx_local_vertices(self._h)), int(L.plx_key_words(d))), dtype=torch.int32,
+                           device=self.device)
+        with torch.cuda.device(self.device):
+            rc = L.plx_copy_local_keys(self._h, ctypes.c_void_p(keys.data_ptr()), _stream_ptr(self.device))
+        nv.check(rc, "plx_copy_local_keys")
+        return keys
+
+    def build_merge(self, all_keys, counts, rank):
+        """Stage 2: all ranks' keys concatenated in rank order ([sum(counts), key_words] int32)."""
+        all_keys = all_keys.contiguous()
+        assert all_keys.is_cuda and all_keys.dtype == torch.int32 and all_keys.shape[0] == sum(counts)
+        arr = (ctypes.c_int64 * len(counts))(*[int(c) for c in counts])
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_build_merge(self._h, ctypes.c_void_p(all_keys.data_ptr()), arr, len(counts), rank,
+                                          _stream_ptr(self.device))
+        nv.check(rc, "plx_build_merge")
+        return self
+
     @property
     def n(self):
         return int(nv.lib().plx_num_points(self._h))

@@ -78,3 +78,27 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
             sizes = [hi - lo for lo, hi in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _gather_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from simplex_gp_amd.distributed import all_gather_rows
+        rows = 3 + 2 * rank                                   # uneven blocks, like per-rank vertex key sets
+        t = torch.full((rows, 4), rank, dtype=torch.int32) + torch.arange(rows, dtype=torch.int32)[:, None] * 10
+        full, counts = all_gather_rows(t)
+        assert counts == [3 + 2 * r for r in range(world)]
+        want = torch.cat([torch.full((3 + 2 * r, 4), r, dtype=torch.int32)
+                          + torch.arange(3 + 2 * r, dtype=torch.int32)[:, None] * 10 for r in range(world)])
+        assert torch.equal(full, want)
+        if rank == 0:
+            np.save(os.path.join(outdir, "ok.npy"), np.array(1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_rows_uneven(tmp_path):
+    """The key exchange of the sharded lattice build: rank blocks of different length, rank order kept."""
+    mp.spawn(_gather_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    assert (tmp_path / "ok.npy").exists()

@@ -227,3 +227,47 @@ def test_coldot_matches_torch(plx):
         assert got.shape == (t,)
         assert torch.allclose(got.double(), want, rtol=1e-4, atol=1e-3 * (n ** 0.5)), (n, t)
         assert torch.equal(got, solvers._colsum(a, b))          # deterministic
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_sharded_build_equals_replicated_build(plx, shards):
+    """plx_build_local + key exchange + plx_build_merge (each rank sees only its rows) gives the SAME
+    vertex numbering and the same per-shard tables as plx_build(shard_index, n_shards) on all rows."""
+    from simplex_gp_amd import _native as nv
+    from simplex_gp_amd.distributed import shard_bounds
+    g = torch.Generator().manual_seed(21)
+    n, d, vd = 30011, 5, 3
+    x = torch.randn(n, d, generator=g).cuda()
+    v = torch.randn(n, vd, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    bounds = [shard_bounds(n, shards, r) for r in range(shards)]
+    locals_ = [plx.Lattice() for _ in range(shards)]
+    keys = [lat.build_local(x[lo:hi].contiguous(), taps) for lat, (lo, hi) in zip(locals_, bounds)]
+    counts = [k.shape[0] for k in keys]
+    all_keys = torch.cat(keys, 0)
+    total = None
+    for r, (lat, (lo, hi)) in enumerate(zip(locals_, bounds)):
+        lat.build_merge(all_keys, counts, r)
+        rep = plx.Lattice().build(x, taps, shard=(r, shards))
+        assert lat.m == rep.m and lat.n == hi - lo and lat.n_owned == hi - lo
+        assert np.array_equal(lat.export(nv.ARRAY_KEYS), rep.export(nv.ARRAY_KEYS))            # same numbering
+        assert np.array_equal(lat.export(nv.ARRAY_NEIGHBORS), rep.export(nv.ARRAY_NEIGHBORS))
+        assert np.array_equal(lat.export(nv.ARRAY_ENTRY_VERTEX), rep.export(nv.ARRAY_ENTRY_VERTEX)[:, lo:hi])
+        assert np.array_equal(lat.export(nv.ARRAY_ENTRY_WEIGHT), rep.export(nv.ARRAY_ENTRY_WEIGHT)[:, lo:hi])
+        part, part_rep = lat.splat(v[lo:hi]), rep.splat(v[lo:hi])
+        assert torch.equal(part, part_rep)
+        total = part.clone() if total is None else total + part
+        rep.close()
+    full = plx.Lattice().build(x, taps).apply(v)
+    got = torch.empty_like(full)
+    for lat, (lo, hi) in zip(locals_, bounds):
+        got[lo:hi] = lat.slice(lat.blur(total.clone(), vd=vd), vd=vd)
+    assert rel_l2(got.cpu().numpy(), full.cpu().numpy()) <= 1e-6
+    # protocol errors are reported, not UB
+    from simplex_gp_amd._native import PlxError
+    fresh = plx.Lattice()
+    with pytest.raises(PlxError):
+        fresh.build_merge(all_keys, counts, 0)            # merge without a local stage
+    fresh.build_local(x[:100].contiguous(), taps)
+    with pytest.raises(PlxError):
+        fresh.build_merge(all_keys, counts, 0)            # announced count does not match
