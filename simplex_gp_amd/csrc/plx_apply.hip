@@ -24,6 +24,8 @@
 namespace plx {
 
 static int g_blur_vpt = 4;     // vertices per thread in the vd = 1 blur (2 or 4)
+static int g_xcd_remap = 1;    // 1: workgroup b works on tile (b % 8) * ceil(nb/8) + b / 8, so that the 8 XCDs (which
+                               // receive workgroups round-robin) each own one contiguous slice of the lattice
 static int g_splat_ablate = 0; // diagnostics only: 1 no value gather, 2 no stores, 4 no row-id loads
 static int g_blur_ablate = 0;  // diagnostics only: 1 no neighbour gathers, 2 no neighbour-id loads either
 extern int g_sort_points;
@@ -32,10 +34,25 @@ extern int g_compact_nbr;
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"blur_vpt", &g_blur_vpt},
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap},
                           {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
+
+// Tile index for workgroup blockIdx.x.  With remap the launch has 8 * ceil(ntiles / 8) workgroups and
+// workgroup b takes tile (b % 8) * per + b / 8: workgroups are dealt to the 8 XCDs round-robin
+// (MI355X_MICROARCH.md, Workgroup dispatch), so every XCD sweeps one contiguous eighth of the tiles and its
+// gathers -- which follow the lattice order -- stay inside one eighth of the gathered array, i.e. inside
+// its own 4 MiB L2.  Placement only affects speed, never results.  Returns -1 for the padding workgroups.
+__device__ __forceinline__ int tile_index(int ntiles, int remap)
+{
+    const int b = blockIdx.x;
+    if (!remap) return b < ntiles ? b : -1;
+    const int per = (ntiles + 7) >> 3;
+    const int t = (b & 7) * per + (b >> 3);
+    return ((b >> 3) < per && t < ntiles) ? t : -1;
+}
+static inline int tile_grid(int ntiles, int remap) { return remap ? 8 * ((ntiles + 7) / 8) : ntiles; }
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -109,7 +126,8 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
                                                             const int *__restrict__ csr_vid,
                                                             const V *__restrict__ ssrc, int rowlen, int nnz,
                                                             V *__restrict__ values, V *__restrict__ head_partial,
-                                                            V *__restrict__ tail_partial, int ablate)
+                                                            V *__restrict__ tail_partial, int ablate, int nchunks,
+                                                            int remap)
 {
     using O = VecOps<V>;
     constexpr int EPT = kSplatChunk / kBlock;   // corners per thread
@@ -118,7 +136,8 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
     __shared__ V wave_sum[kBlock / 64][NCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = blockIdx.x;
+    const int c = tile_index(nchunks, remap);
+    if (c < 0) return;
     const int tile0 = blockIdx.y * NCH;
     const int k0 = c * kSplatChunk;
     const int kb = k0 + tid * EPT;
@@ -302,17 +321,17 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     float *hp = L->head_partial.as<float>(), *tp = L->tail_partial.as<float>();
     const int nnz = (int)L->nnz, nch_total = vdp / 4, nchunks = (int)L->nchunks;
     if (vd == 1) {
-        splat_scan_kernel<float, 1><<<nchunks, kBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, g_splat_ablate);
+        splat_scan_kernel<float, 1><<<tile_grid(nchunks, g_xcd_remap), kBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, g_splat_ablate, nchunks, g_xcd_remap);
     } else {
         const float4 *s4 = reinterpret_cast<const float4 *>(ss);
         float4 *v4 = reinterpret_cast<float4 *>(d_values), *h4 = reinterpret_cast<float4 *>(hp), *t4 = reinterpret_cast<float4 *>(tp);
         // up to 3 chunks (12 columns) per workgroup in registers; wider rows take more column tiles
         const int nch = nch_total <= 3 ? nch_total : (nch_total % 3 == 0 ? 3 : (nch_total % 2 == 0 ? 2 : 3));
-        dim3 grid((unsigned)nchunks, (unsigned)ceil_div(nch_total, nch));
+        dim3 grid((unsigned)tile_grid(nchunks, g_xcd_remap), (unsigned)ceil_div(nch_total, nch));
         switch (nch) {
-        case 1: splat_scan_kernel<float4, 1><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate); break;
-        case 2: splat_scan_kernel<float4, 2><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate); break;
-        default: splat_scan_kernel<float4, 3><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate); break;
+        case 1: splat_scan_kernel<float4, 1><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
+        case 2: splat_scan_kernel<float4, 2><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
+        default: splat_scan_kernel<float4, 3><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
         }
     }
     splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, nnz, vdp, hp, tp,
@@ -332,11 +351,14 @@ template <int ORDER, int VPT>
 __global__ __launch_bounds__(kBlock) void blur_axis_v1_kernel(const float *__restrict__ old,
                                                               float *__restrict__ out,
                                                               const int *__restrict__ nbr, int m,
-                                                              int64_t mstride, TapArgs taps, int ablate)
+                                                              int64_t mstride, TapArgs taps, int ablate, int ntiles,
+                                                              int remap)
 {
     using ivec = typename std::conditional<VPT == 4, int4, int2>::type;
     using fvec = typename std::conditional<VPT == 4, float4, float2>::type;
-    const int i0 = (blockIdx.x * kBlock + threadIdx.x) * VPT;
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int i0 = (tile * kBlock + threadIdx.x) * VPT;
     if (i0 >= m) return;
     if (i0 + VPT <= m) {
         int nb[2 * ORDER][VPT];
@@ -489,10 +511,11 @@ template <int ORDER>
 static void launch_blur_v1(const float *cur, float *nxt, const int *nb, int m, int64_t mstride, const TapArgs &taps,
                            hipStream_t stream)
 {
+    const int nt4 = ceil_div(ceil_div(m, 4), kBlock), nt2 = ceil_div(ceil_div(m, 2), kBlock);
     if (g_blur_vpt == 4)
-        blur_axis_v1_kernel<ORDER, 4><<<ceil_div(ceil_div(m, 4), kBlock), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate);
+        blur_axis_v1_kernel<ORDER, 4><<<tile_grid(nt4, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate, nt4, g_xcd_remap);
     else
-        blur_axis_v1_kernel<ORDER, 2><<<ceil_div(ceil_div(m, 2), kBlock), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate);
+        blur_axis_v1_kernel<ORDER, 2><<<tile_grid(nt2, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate, nt2, g_xcd_remap);
 }
 
 template <class V>
@@ -557,9 +580,11 @@ __global__ __launch_bounds__(kBlock) void slice_v1_kernel(const int *__restrict_
                                                           const float *__restrict__ ew,
                                                           const uint32_t *__restrict__ perm, int n, int own_begin,
                                                           int n_own, const float *__restrict__ values, float denom,
-                                                          float *__restrict__ out)
+                                                          float *__restrict__ out, int ntiles, int remap)
 {
-    const int pl = blockIdx.x * kBlock + threadIdx.x;
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int pl = tile * kBlock + threadIdx.x;
     if (pl >= n_own) return;
     const int p = own_begin + pl;
     int v[D1];
@@ -618,10 +643,11 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
     const int n = (int)L->n, ob = (int)L->own_begin;
     if (vd == 1) {
-        const int grid = ceil_div(n_own, kBlock);
+        const int nt = ceil_div(n_own, kBlock);
+        const int grid = tile_grid(nt, g_xcd_remap);
         switch (L->d + 1) {
 #define PLX_CASE(D1) \
-    case D1: slice_v1_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, d_values, L->slice_denom, d_out); break;
+    case D1: slice_v1_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, d_values, L->slice_denom, d_out, nt, g_xcd_remap); break;
             PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9)
             PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17)
             PLX_CASE(18) PLX_CASE(19) PLX_CASE(20) PLX_CASE(21) PLX_CASE(22) PLX_CASE(23) PLX_CASE(24) PLX_CASE(25)
