@@ -31,10 +31,11 @@ static int g_blur_ablate = 0;  // diagnostics only: 1 no neighbour gathers, 2 no
 extern int g_sort_points;
 extern int g_csr_point_major;
 extern int g_compact_nbr;
+extern int g_insert_dedupe;
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap},
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap},
                           {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
