@@ -32,10 +32,11 @@ extern int g_sort_points;
 extern int g_csr_point_major;
 extern int g_compact_nbr;
 extern int g_insert_dedupe;
+extern int g_nbr_symmetric;
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap},
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap},
                           {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }

@@ -39,6 +39,8 @@
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
+int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only and mirrors the hits
+                              // (fine regime 7.2 -> 4.9 ms; an occupancy bitmap on top did not pay)
 int g_insert_dedupe = 1;      // wave-level skip of repeated keys in the hashed insert (0.38 -> 0.32 ms at m = 4e5)
 int g_compact_nbr = 1;        // 0 never, 1 when under half of the neighbour slots exist, 2 always (A/B)
 int g_csr_point_major = 0;   // corners of one vertex row ordered by corner index then point (0, coalesced key
@@ -450,7 +452,9 @@ __global__ __launch_bounds__(kBlock) void ids_kernel(const uint32_t *__restrict_
 // neighbours: h:539-545 evaluated once per lattice instead of once per MVM.
 // nbr[(axis*2r + s)*mstride + i]; s enumerates nid = -r..-1, 1..r.
 
-template <int D>
+// SYMMETRIC = true: only the positive taps are looked up; a hit j = nbr(i, +t) also fills
+// nbr(j, -t) = i (the relation is symmetric), the planes having been preset to -1.
+template <int D, bool SYMMETRIC>
 __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__restrict__ vkeys, int m,
                                                           int64_t mstride, int order,
                                                           const uint32_t *__restrict__ table,
@@ -467,7 +471,8 @@ __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__rest
 #pragma unroll
     for (int c = 0; c < D; ++c) key[c] = (int)(int16_t)((kw[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu);
 
-    for (int s = 0; s < 2 * order; ++s) {
+    int *plane = nbr + (size_t)axis * 2 * order * mstride;
+    for (int s = SYMMETRIC ? order : 0; s < 2 * order; ++s) {
         const int nid = (s < order) ? (s - order) : (s - order + 1);
         uint32_t nk[DW];
 #pragma unroll
@@ -492,7 +497,8 @@ __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__rest
                 h = (h + 1) & mask;
             }
         }
-        nbr[((size_t)axis * 2 * order + s) * mstride + i] = found;
+        plane[(size_t)s * mstride + i] = found;
+        if (SYMMETRIC && found >= 0) plane[(size_t)(order - nid) * mstride + found] = i;   // slot of tap -nid
     }
 }
 
@@ -879,10 +885,19 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
     PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
 
-    if (order > 0)
-        neighbor_kernel<D><<<dim3(ceil_div(m, kBlock), D1), kBlock, 0, stream>>>(
-            L->vkeys.as<uint32_t>(), m, L->mstride, order, L->table.as<uint32_t>(), L->table_mask,
-            L->nbr.as<int>());
+    if (order > 0) {
+        dim3 ngrid(ceil_div(m, kBlock), D1);
+        if (g_nbr_symmetric) {
+            PLX_HIP_TRY(hipMemsetAsync(L->nbr.p, 0xFF, (size_t)D1 * 2 * order * L->mstride * 4, stream));
+            neighbor_kernel<D, true><<<ngrid, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, L->mstride, order,
+                                                                    L->table.as<uint32_t>(), L->table_mask,
+                                                                    L->nbr.as<int>());
+        } else {
+            neighbor_kernel<D, false><<<ngrid, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, L->mstride, order,
+                                                                     L->table.as<uint32_t>(), L->table_mask,
+                                                                     L->nbr.as<int>());
+        }
+    }
     // compacted copy for sparse lattices (used by the vd = 1 blur when under half the neighbours exist)
     L->use_compact = false;
     if (order >= 1 && order <= 3 && g_compact_nbr != 0) {
