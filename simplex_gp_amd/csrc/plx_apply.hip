@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
 {
     using O = VecOps<V>;
     constexpr int EPT = kSplatChunk / kBlock;   // corners per thread
-    static_assert(EPT == 4, "vector loads below assume 4 corners per thread");
+    static_assert(EPT % 4 == 0, "vector loads below take 4 corners at a time");
     __shared__ int wave_cnt[kBlock / 64];
     __shared__ V wave_sum[kBlock / 64][NCH];
 
@@ -148,10 +148,13 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
     int pt[EPT + 1];
     float w[EPT];
     if (kb + EPT <= nnz) {
-        const int4 a = *reinterpret_cast<const int4 *>(csr_pt + kb);
-        const float4 b = *reinterpret_cast<const float4 *>(csr_w + kb);
-        pt[0] = a.x; pt[1] = a.y; pt[2] = a.z; pt[3] = a.w;
-        w[0] = b.x; w[1] = b.y; w[2] = b.z; w[3] = b.w;
+#pragma unroll
+        for (int q4 = 0; q4 < EPT / 4; ++q4) {
+            const int4 a = *reinterpret_cast<const int4 *>(csr_pt + kb + 4 * q4);
+            const float4 b = *reinterpret_cast<const float4 *>(csr_w + kb + 4 * q4);
+            pt[4 * q4] = a.x; pt[4 * q4 + 1] = a.y; pt[4 * q4 + 2] = a.z; pt[4 * q4 + 3] = a.w;
+            w[4 * q4] = b.x; w[4 * q4 + 1] = b.y; w[4 * q4 + 2] = b.z; w[4 * q4 + 3] = b.w;
+        }
         pt[EPT] = (kb + EPT < nnz) ? csr_pt[kb + EPT] : -1;
     } else {
 #pragma unroll
