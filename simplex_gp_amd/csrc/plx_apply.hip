@@ -26,6 +26,9 @@ namespace plx {
 static int g_blur_vpt = 4;     // vertices per thread in the vd = 1 blur (2 or 4)
 static int g_xcd_remap = 1;    // 1: workgroup b works on tile (b % 8) * ceil(nb/8) + b / 8, so that the 8 XCDs (which
                                // receive workgroups round-robin) each own one contiguous slice of the lattice
+static int g_splat_direct = 1;  // vd = 1: gather from d_src through caller-row indices instead of a sorted copy:
+                                // 0 never, 1 for launch-bound sizes (<= 2e6 corners: saves a launch; at 9e6 corners
+                                // the sorted copy wins, 58 vs 60 us), 2 always
 static int g_splat_ablate = 0; // diagnostics only: 1 no value gather, 2 no stores, 4 no row-id loads
 static int g_blur_ablate = 0;  // diagnostics only: 1 no neighbour gathers, 2 no neighbour-id loads either
 extern int g_sort_points;
@@ -37,7 +40,7 @@ extern int g_nbr_symmetric;
 Tunable *tunables()
 {
     static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap},
-                          {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
+                          {"splat_direct", &g_splat_direct}, {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
 
@@ -312,15 +315,20 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     PLX_TRY(ensure(L->ssrc, (size_t)n_own * vdp * 4));
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
     const float *ss = L->ssrc.as<float>();
-    if (L->lattice_rows && vd == 1)
-        ss = d_src;                       // already in lattice order and unpadded: read it in place
-    else if (vd == 1)
+    const int *pt = L->csr_pt.as<int>();
+    const bool direct = g_splat_direct == 2 || (g_splat_direct == 1 && L->nnz <= 2000000);
+    if (vd == 1 && (L->lattice_rows || direct)) {
+        // single column: no padding needed, so gather straight from the caller's buffer -- through the
+        // lattice-order indices when the rows are in lattice order, else through the caller-row indices
+        ss = d_src;
+        if (!L->lattice_rows) pt = L->csr_row.as<int>();
+    } else if (vd == 1) {
         gather_in_v1_kernel<<<ceil_div(n_own, kBlock), kBlock, 0, stream>>>(d_src, perm, (int)L->own_begin, n_own,
                                                                             L->ssrc.as<float>());
-    else
+    } else {
         gather_in_kernel<<<ceil_div((int64_t)n_own * vdp, kBlock), kBlock, 0, stream>>>(
             d_src, perm, (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());
-    const int *pt = L->csr_pt.as<int>();
+    }
     const float *w = L->csr_w.as<float>();
     const int *vid = L->sort_keys_out.as<int>();   // sorted vertex id of every corner
     float *hp = L->head_partial.as<float>(), *tp = L->tail_partial.as<float>();

@@ -607,7 +607,9 @@ __global__ __launch_bounds__(kBlock) void csr_finalize_kernel(const uint32_t *__
                                                               const uint32_t *__restrict__ svals,
                                                               const float *__restrict__ ew, int n,
                                                               int own_begin, int nnz, int m,
+                                                              const uint32_t *__restrict__ perm,
                                                               int *__restrict__ csr_pt,
+                                                              int *__restrict__ csr_row,
                                                               float *__restrict__ csr_w,
                                                               int *__restrict__ row_ptr)
 {
@@ -620,7 +622,9 @@ __global__ __launch_bounds__(kBlock) void csr_finalize_kernel(const uint32_t *__
     const int prev = (k == 0) ? -1 : (int)skeys[k - 1];
     // sign bit of csr_pt marks the first entry of a vertex row (segment head)
     const uint32_t head = (prev != (int)v) ? 0x80000000u : 0u;
-    csr_pt[k] = (int)(((idx - r * (uint32_t)n) - (uint32_t)own_begin) | head);
+    const uint32_t p = idx - r * (uint32_t)n;                  // point, lattice order
+    csr_pt[k] = (int)((p - (uint32_t)own_begin) | head);
+    csr_row[k] = (int)((perm[p] - (uint32_t)own_begin) | head);   // the same point as the caller numbers its rows
     csr_w[k] = ew[idx];
     for (int u = prev + 1; u <= (int)v; ++u) row_ptr[u] = k;
     if (k == nnz - 1)
@@ -884,6 +888,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
     PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
     PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
+    PLX_TRY(ensure(L->csr_row, (size_t)L->nnz * 4 + 64));
 
     if (order > 0) {
         dim3 ngrid(ceil_div(m, kBlock), D1);
@@ -945,8 +950,8 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
                            L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, stream));
         csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
             L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
-            (int)L->own_begin, (int)L->nnz, m, L->csr_pt.as<int>(), L->csr_w.as<float>(),
-            L->row_ptr.as<int>());
+            (int)L->own_begin, (int)L->nnz, m, L->perm.as<uint32_t>(), L->csr_pt.as<int>(), L->csr_row.as<int>(),
+            L->csr_w.as<float>(), L->row_ptr.as<int>());
     } else {
         PLX_HIP_TRY(hipMemsetAsync(L->row_ptr.p, 0, (size_t)(m + 1) * 4, stream));
     }

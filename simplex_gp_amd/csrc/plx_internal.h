@@ -96,6 +96,8 @@ struct plx_lattice {
     plx::DevBuf cbase;      // uint32 [d+1][nqwaves + 1]
     plx::DevBuf cids;       // int32  [total existing neighbours]
     plx::DevBuf csr_pt;     // int32  [nnz]          local (owned) point index, sorted by vertex
+    plx::DevBuf csr_row;    // int32  [nnz]          the same points numbered as the caller's rows (vd = 1 splat
+                            //                       gathers straight from d_src, no sorted copy)
     plx::DevBuf csr_w;      // float  [nnz]
     plx::DevBuf row_ptr;    // int32  [m+1]
 
