@@ -294,3 +294,77 @@ def test_orders_and_dims(plx):
         taps = np.array(taps, np.float32)
         out = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), taps).cpu().numpy()
         assert rel_l2(out, oracle.filter(src, ref, taps)) <= TOL_ORACLE, len(taps)
+
+
+def test_one_shot_plx_filter_through_raw_abi(plx):
+    """plx_filter(scratch=NULL, ...) = the reference's filter(): builds, applies, leaves nothing behind."""
+    import ctypes
+    from simplex_gp_amd import _native as nv
+    rng = np.random.default_rng(3)
+    n, d, vd = 4000, 3, 2
+    ref = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda()
+    src = torch.from_numpy(rng.standard_normal((n, vd)).astype(np.float32)).cuda()
+    out = torch.empty_like(src)
+    taps = np.array([0.5, 1.0, 0.5], np.float32)
+    rc = nv.lib().plx_filter(None, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(ref.data_ptr()), n, d, vd,
+                             taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 3, ctypes.c_void_p(out.data_ptr()),
+                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, nv.lib().plx_last_error()
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().numpy(), oracle.filter(src.cpu().numpy(), ref.cpu().numpy(), taps)) <= TOL_ORACLE
+    # bad arguments come back as codes with a message, never as a crash
+    assert nv.lib().plx_filter(None, None, ctypes.c_void_p(ref.data_ptr()), n, d, vd,
+                               taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 3, ctypes.c_void_p(out.data_ptr()), None) != 0
+    assert nv.lib().plx_filter(None, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(ref.data_ptr()), n, 99, vd,
+                               taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 3, ctypes.c_void_p(out.data_ptr()), None) == 4
+
+
+def test_wide_right_hand_sides(plx):
+    """vd = 2L(1+d) columns as in the backward pass (py:113-119): column tiles and padding."""
+    rng = np.random.default_rng(5)
+    n, d = 3000, 4
+    ref = rng.standard_normal((n, d)).astype(np.float32)
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    lat = plx.Lattice().build(torch.from_numpy(ref).cuda(), taps)
+    for vd in (2, 5, 12, 13, 30, 110):
+        src = rng.standard_normal((n, vd)).astype(np.float32)
+        out = lat.apply(torch.from_numpy(src).cuda()).cpu().numpy()
+        assert out.shape == (n, vd)
+        oracle.set_exact_mode(False)
+        want = oracle.filter(src, ref, taps)
+        oracle.set_exact_mode(True)
+        assert rel_l2(out, want) <= TOL_ORACLE, vd
+
+
+def test_random_small_shapes(plx):
+    """Randomised shapes, scales, orders and degenerate clouds against the oracle."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(n=st.integers(1, 400), d=st.integers(1, 7), vd=st.integers(1, 6), order=st.integers(0, 3),
+           scale=st.sampled_from([0.05, 0.5, 1.0, 3.0, 20.0]), kind=st.sampled_from(["normal", "grid", "dup", "line"]),
+           seed=st.integers(0, 10**6))
+    def run(n, d, vd, order, scale, kind, seed):
+        rng = np.random.default_rng(seed)
+        if kind == "normal":
+            ref = rng.standard_normal((n, d))
+        elif kind == "grid":                       # many exact ties in the rounding / ranking
+            ref = rng.integers(-3, 4, (n, d)).astype(np.float64) * 0.5
+        elif kind == "dup":                        # few distinct points, many duplicates
+            ref = rng.standard_normal((max(1, n // 20), d))[rng.integers(0, max(1, n // 20), n)]
+        else:                                      # points on a line
+            ref = np.outer(rng.standard_normal(n), rng.standard_normal(d))
+        ref = (ref * scale).astype(np.float32)
+        src = rng.standard_normal((n, vd)).astype(np.float32)
+        taps = np.array([0.1, 0.3, 0.6, 1.0, 0.6, 0.3, 0.1][3 - order: 4 + order], np.float32)
+        out = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), taps).cpu().numpy()
+        oracle.set_exact_mode(False)
+        want, m = oracle.filter(src, ref, taps, return_m=True)
+        oracle.set_exact_mode(True)
+        err = np.linalg.norm(out - want) / max(np.linalg.norm(want), 1e-20)
+        # hundreds of points collapsing into one or two vertices with random signs: the oracle adds them one
+        # by one in fp32, the scan adds them as a tree, and cancellation amplifies the difference to ~1e-5;
+        # 5e-5 keeps a 2x margin to the 1e-4 north-star bound
+        assert err <= 5e-5, (n, d, vd, order, scale, kind, seed, err)
+
+    run()
