@@ -1,0 +1,140 @@
+"""Prediction, evaluation and the training loop around the lattice operator
+(SURVEY 8f-3): what experiments/train_simplexgp.py does with GPyTorch, written
+against simplex_gp_amd.solvers so that it runs where GPyTorch is absent.
+
+    predict     mean through the rectangular operator K(x*, X) (py:142-160) and a
+                Lanczos (LOVE-style) variance cache, as `fast_pred_var` does
+                (train_simplexgp.py:63-72)
+    evaluate    RMSE / MAE / NLL exactly as train_simplexgp.py:74-84 defines them
+    EarlyStopper  same contract as experiments/utils.py:170-199
+    fit         Adam on the CG/SLQ marginal likelihood with validation-RMSE early
+                stopping and a best-state checkpoint (train_simplexgp.py:117-165)
+"""
+import math
+
+import torch
+
+from .solvers import LatticeGP, marginal_log_likelihood
+
+
+def lanczos(matmul, v0, steps):
+    """`steps` Lanczos iterations with full re-orthogonalisation.
+    Returns Q [n, t] (orthonormal) and the tridiagonal T [t, t] with Q^T A Q = T."""
+    q = v0 / v0.norm()
+    Q, alphas, betas = [q], [], []
+    beta, q_prev = None, None
+    for i in range(steps):
+        w = matmul(Q[-1].unsqueeze(-1)).squeeze(-1)
+        if q_prev is not None:
+            w = w - beta * q_prev
+        alpha = torch.dot(w, Q[-1])
+        w = w - alpha * Q[-1]
+        Qm = torch.stack(Q, 1)
+        w = w - Qm @ (Qm.t() @ w)                 # full re-orthogonalisation
+        alphas.append(alpha)
+        beta = w.norm()
+        if i + 1 == steps or float(beta) < 1e-6 * float(alphas[0].abs()):
+            break
+        betas.append(beta)
+        q_prev = Q[-1]
+        Q.append(w / beta)
+    t = len(alphas)
+    T = torch.zeros(t, t, dtype=v0.dtype, device=v0.device)
+    for i in range(t):
+        T[i, i] = alphas[i]
+        if i + 1 < t:
+            T[i, i + 1] = T[i + 1, i] = betas[i]
+    return torch.stack(Q[:t], 1), T
+
+
+@torch.no_grad()
+def predict(model, x, y, x_star, max_cg_iter=1000, cg_tol=1e-2, lanc_iter=100, variance=True):
+    """Posterior mean and variance of the latent function at x_star.
+
+    mean = mu + s K(x*, X) (s K + sigma^2 I)^-1 (y - mu)          one CG solve + one rectangular MVM
+    var  = s k(x*, x*) - || L^-1 Q^T (s K(X, x*)) ||^2            K^-1 ~ Q T^-1 Q^T from `lanc_iter`
+           Lanczos steps started at y - mu, T = L L^T; one rectangular MVM with lanc_iter columns
+    """
+    assert isinstance(model, LatticeGP)
+    r = (y - model.mean).reshape(-1, 1)
+    alpha, _ = model.khat_solve(x, r, max_iter=max_cg_iter, tol=cg_tol)
+    K_star = model.kernel(x_star, x)                      # RectangularLazyLattice, [n*, n]
+    s = model.outputscale
+    mean = model.mean + s * K_star.matmul(alpha).squeeze(-1)
+    if not variance:
+        return mean, None
+    Q, T = lanczos(model.khat_matmul(x), r.squeeze(-1), min(lanc_iter, x.shape[0]))
+    jitter = 1e-6 * T.diagonal().abs().max()
+    Lc = torch.linalg.cholesky(T + jitter * torch.eye(T.shape[0], dtype=T.dtype, device=T.device))
+    KQ = s * K_star.matmul(Q.contiguous())                # [n*, t]
+    proj = torch.linalg.solve_triangular(Lc, KQ.t(), upper=False)
+    prior = s * model.kernel(x_star, x_star, diag=True)
+    var = (prior - (proj ** 2).sum(0)).clamp_min(1e-8)
+    return mean, var
+
+
+@torch.no_grad()
+def evaluate(model, x, y, x_star, y_star, label="test", **predict_args):
+    """RMSE, MAE and mean negative log predictive density (train_simplexgp.py:74-84)."""
+    mean, var = predict(model, x, y, x_star, **predict_args)
+    rmse = (mean - y_star).pow(2).mean(0).sqrt()
+    mae = (mean - y_star).abs().mean(0)
+    nll = -torch.distributions.Normal(mean, (var + model.noise).sqrt()).log_prob(y_star).mean()
+    return {f"{label}/rmse": rmse.item(), f"{label}/mae": mae.item(), f"{label}/nll": nll.item()}
+
+
+class EarlyStopper:
+    """Keeps the best (score, info); done after `patience` non-improving calls
+    (improvement = more than `delta` above the best score)."""
+
+    def __init__(self, patience=10, delta=1e-4):
+        self.patience, self.delta = patience, delta
+        self._misses = 0
+        self._best_score = None
+        self._best_info = None
+
+    def is_done(self):
+        return self.patience >= 0 and self._misses >= self.patience
+
+    def info(self):
+        return self._best_info
+
+    def __call__(self, score, info):
+        assert not self.is_done()
+        if self._best_score is None or score >= self._best_score + self.delta:
+            self._best_score, self._best_info, self._misses = score, info, 0
+        else:
+            self._misses += 1
+
+
+def fit(model, train, val=None, test=None, epochs=100, lr=0.1, patience=200, log_every=1, num_probes=10,
+        cg_iter=1000, cg_tol=1.0, cg_eval_tol=1e-2, lanc_iter=100, checkpoint=None, log=None):
+    """Adam on -MLL; every `log_every` epochs evaluate on val/test, keep the state
+    with the best validation RMSE, stop after `patience` evaluations without
+    improvement; optionally torch.save the best state_dict to `checkpoint`."""
+    x, y = train
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    stopper = EarlyStopper(patience=patience)
+    history = []
+    for epoch in range(epochs):
+        opt.zero_grad()
+        mll = marginal_log_likelihood(model, x, y, num_probes=num_probes, max_cg_iter=cg_iter, cg_tol=cg_tol, seed=epoch)
+        (-mll).backward()
+        opt.step()
+        row = {"epoch": epoch + 1, "train/mll": float(mll.detach())}
+        if val is not None and epoch % log_every == 0:
+            row.update(evaluate(model, x, y, val[0], val[1], label="val", max_cg_iter=cg_iter, cg_tol=cg_eval_tol,
+                                lanc_iter=lanc_iter))
+            if test is not None:
+                row.update(evaluate(model, x, y, test[0], test[1], label="test", max_cg_iter=cg_iter,
+                                    cg_tol=cg_eval_tol, lanc_iter=lanc_iter))
+            stopper(-row["val/rmse"], {"state_dict": {k: v.detach().clone() for k, v in model.state_dict().items()},
+                                       "summary": dict(row)})
+            if checkpoint is not None:
+                torch.save(stopper.info()["state_dict"], checkpoint)
+        history.append(row)
+        if log is not None:
+            log(row)
+        if val is not None and stopper.is_done():
+            break
+    return history, (stopper.info() if val is not None else None)

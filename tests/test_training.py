@@ -1,0 +1,88 @@
+"""Prediction / evaluation / training loop (simplex_gp_amd.training) on CPU via the oracle hook."""
+import numpy as np
+import pytest
+import torch
+
+import simplex_gp_amd as plx
+from simplex_gp_amd import solvers, training
+from oracle import oracle
+
+
+def oracle_filter(src, ref, coeffs):
+    return torch.from_numpy(oracle.filter(src.detach().numpy(), ref.detach().numpy(), coeffs.detach().numpy()))
+
+
+@pytest.fixture
+def cpu_method():
+    plx.LatticeFilterGeneral.method = staticmethod(oracle_filter)
+    yield
+    plx.LatticeFilterGeneral.method = None
+
+
+def test_lanczos_reproduces_the_operator():
+    g = torch.Generator().manual_seed(0)
+    n = 40
+    B = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = B @ B.T / n + torch.eye(n, dtype=torch.float64)
+    Q, T = training.lanczos(lambda V: A @ V, torch.randn(n, generator=g, dtype=torch.float64), n)
+    assert torch.allclose(Q.T @ Q, torch.eye(Q.shape[1], dtype=torch.float64), atol=1e-8)
+    assert torch.allclose(Q.T @ A @ Q, T, atol=1e-8)
+
+
+def test_predict_matches_dense_formulas(cpu_method):
+    """Mean and (full-rank Lanczos) variance against the dense expressions built from the same lattice operators."""
+    torch.manual_seed(0)
+    n, ns = 60, 25
+    x = torch.randn(n, 2)
+    y = torch.sin(2 * x[:, 0]) + 0.1 * torch.randn(n)
+    xs = torch.randn(ns, 2)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1), min_noise=1e-2)
+    mean, var = training.predict(model, x, y, xs, cg_tol=1e-8, lanc_iter=n)
+    with torch.no_grad():
+        s, noise = model.outputscale, model.noise
+        K = model.kernel(x, x).evaluate()
+        Ks = model.kernel(xs, x).evaluate()              # [ns, n]
+        Khat = s * K + noise * torch.eye(n)
+        r = (y - model.mean).reshape(-1, 1)
+        # the lattice operator is only approximately symmetric; CG / Lanczos see its action, so compare loosely
+        mean_dense = model.mean + (s * Ks @ torch.linalg.solve(Khat, r)).squeeze(-1)
+        var_dense = s - ((s * Ks) * torch.linalg.solve(Khat, (s * Ks).T).T).sum(1)
+    assert mean.shape == (ns,) and var.shape == (ns,)
+    assert torch.allclose(mean, mean_dense, atol=5e-2, rtol=5e-2)
+    assert (var > 0).all() and torch.allclose(var, var_dense.clamp_min(1e-8), atol=0.1)
+
+
+def test_early_stopper_contract():
+    st = training.EarlyStopper(patience=2, delta=0.1)
+    st(1.0, "a")
+    assert st.info() == "a" and not st.is_done()
+    st(1.05, "b")                       # not more than delta better: a miss
+    assert st.info() == "a"
+    st(1.2, "c")                        # improvement resets the counter
+    assert st.info() == "c" and not st.is_done()
+    st(1.0, "d")
+    st(1.1, "e")
+    assert st.is_done() and st.info() == "c"
+    with pytest.raises(AssertionError):
+        st(5.0, "f")
+    assert not training.EarlyStopper(patience=-1)._misses and not training.EarlyStopper(patience=-1).is_done()
+
+
+def test_fit_improves_validation_rmse(cpu_method, tmp_path):
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(400, 2, generator=g) * 4 - 2
+    f = torch.sin(2 * x[:, 0]) * torch.cos(x[:, 1])
+    y = f + 0.1 * torch.randn(400, generator=g)
+    tr, va, te = slice(0, 250), slice(250, 325), slice(325, 400)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=2), min_noise=1e-3)
+    before = training.evaluate(model, x[tr], y[tr], x[va], y[va], label="val")
+    ckpt = tmp_path / "model.pt"
+    history, best = training.fit(model, (x[tr], y[tr]), val=(x[va], y[va]), test=(x[te], y[te]), epochs=25, lr=0.1,
+                                 patience=50, cg_tol=1e-2, checkpoint=str(ckpt))
+    assert len(history) == 25 and best is not None and ckpt.exists()
+    assert best["summary"]["val/rmse"] <= before["val/rmse"] + 1e-6
+    assert best["summary"]["val/rmse"] < 0.6 * float(y[va].std())        # far better than predicting the mean
+    assert np.isfinite(best["summary"]["test/nll"]) and best["summary"]["test/rmse"] < 0.5
+    assert history[-1]["train/mll"] > history[0]["train/mll"]
+    state = torch.load(str(ckpt))
+    assert set(state) == set(model.state_dict())
