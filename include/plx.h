@@ -190,6 +190,9 @@ int64_t plx_coldot_work_floats(int vd);
 /* Copy one structure array to host memory (parity tests, debugging).
  * h_dst must hold `bytes` bytes, which must equal the array's size. */
 int plx_export(plx_lattice *lat, int which, void *h_dst, int64_t bytes, void *stream);
+/* PLX_ARRAY_POINT_PERM device to device (uint32 [n]): lets a caller permute its vectors into lattice row
+ * order on the GPU without a host round trip. */
+int plx_copy_point_perm(plx_lattice *lat, void *d_dst, void *stream);
 /* size in bytes of an exportable array, or -1 */
 int64_t plx_export_bytes(const plx_lattice *lat, int which);
 

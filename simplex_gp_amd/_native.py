@@ -55,6 +55,7 @@ _SIGNATURES = {
     "plx_coldot_work_floats": (_i64, [_i32]),
     "plx_export": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "plx_export_bytes": (_i64, [_vp, _i32]),
+    "plx_copy_point_perm": (_i32, [_vp, _vp, _vp]),
     "plx_tune": (_i32, [ctypes.c_char_p, _i32]),
     "plx_set_timing": (_i32, [_vp, _i32]),
     "plx_build_times": (_i32, [_vp, _f32p]),

@@ -367,6 +367,15 @@ int plx_tune(const char *key, int value)
     return PLX_ERR_INVALID;
 }
 
+int plx_copy_point_perm(plx_lattice *L, void *d_dst, void *stream)
+{
+    if (!L || !d_dst) { set_error("plx_copy_point_perm: NULL argument"); return PLX_ERR_INVALID; }
+    if (!L->built) { set_error("plx_copy_point_perm: lattice not built"); return PLX_ERR_STATE; }
+    DeviceGuard g(L->device);
+    PLX_HIP_TRY(hipMemcpyAsync(d_dst, L->perm.p, (size_t)L->n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PLX_OK;
+}
+
 int plx_set_timing(plx_lattice *L, int on)
 {
     if (!L) return PLX_ERR_INVALID;

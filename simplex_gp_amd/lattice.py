@@ -151,13 +151,14 @@ class Lattice:
 
     # -- row order ----------------------------------------------------------
     def shard_perm(self):
-        """int64 tensor: caller row (within this shard) of the i-th row in lattice order."""
+        """int64 device tensor: caller row (within this shard) of the i-th row in lattice order."""
         if self._perm_cache is None:
-            perm = torch.from_numpy(self.export(nv.ARRAY_POINT_PERM).astype(np.int64))
-            n_own = self.n_owned
-            # rows of this shard occupy the same index range in both orders
-            begin = self._own_begin
-            self._perm_cache = (perm[begin:begin + n_own] - begin).to(self.device)
+            raw = torch.empty(self.n, dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = nv.lib().plx_copy_point_perm(self._h, ctypes.c_void_p(raw.data_ptr()), _stream_ptr(self.device))
+            nv.check(rc, "plx_copy_point_perm")
+            begin = self._own_begin        # rows of this shard occupy the same index range in both orders
+            self._perm_cache = raw[begin:begin + self.n_owned].to(torch.int64) - begin
         return self._perm_cache
 
     def set_lattice_row_order(self, on=True):

@@ -132,15 +132,15 @@ class LatticeGP(nn.Module):
     def noise(self):
         return F.softplus(self.raw_noise) + self.min_noise
 
-    def khat_matmul(self, x):
-        """V -> (s K(x,x) + sigma^2 I) V as a differentiable closure."""
-        K = self.kernel(x, x)
+    def khat_matmul(self, x, K=None):
+        """V -> (s K(x,x) + sigma^2 I) V as a differentiable closure (K: an already built kernel(x, x))."""
+        K = self.kernel(x, x) if K is None else K
 
         def mm(V):
             return self.outputscale * K.matmul(V) + self.noise * V
         return mm
 
-    def khat_solve(self, x, rhs, **cg_args):
+    def khat_solve(self, x, rhs, K=None, **cg_args):
         """(s K + sigma^2 I)^-1 rhs by batched CG, no gradients.  On the HIP path the
         iteration runs in lattice row order: the right-hand side is permuted once, every
         MVM skips its two row permutations, the solution is permuted back once (dot
@@ -148,8 +148,11 @@ class LatticeGP(nn.Module):
         from . import lattice_kernel as lk
         with torch.no_grad():
             if lk.LatticeFilterGeneral.method is not None or not x.is_cuda:
-                return batched_cg(self.khat_matmul(x), rhs, **cg_args)
-            ref = x.div(self.kernel.lengthscale).contiguous()
+                return batched_cg(self.khat_matmul(x, K), rhs, **cg_args)
+            # the positions of an existing operator share storage with its tensor: same lattice-cache key, so the
+            # differentiable MVM that follows a solve reuses the lattice built here
+            ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
+            ref = ref if ref.is_contiguous() else ref.contiguous()
             lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
             s, noise = self.outputscale, self.noise
             lat.set_lattice_row_order(True)
@@ -176,12 +179,13 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     n_local = y.shape[0]
     n = n_local if n_total is None else n_total
     r = (y - model.mean).reshape(-1, 1)
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    Z = (torch.randint(0, 2, (n_local, num_probes), generator=g).float() * 2 - 1).to(y.device)
-    mm = model.khat_matmul(x)
+    g = torch.Generator(device=y.device).manual_seed(seed)      # on the device: 1e7 CPU draws cost ~0.1 s per step
+    Z = torch.randint(0, 2, (n_local, num_probes), generator=g, device=y.device).float() * 2 - 1
+    K = model.kernel(x, x)
+    mm = model.khat_matmul(x, K)
     with torch.no_grad():
         rhs = torch.cat([r.detach(), Z], 1)
-        sol, info = model.khat_solve(x, rhs, max_iter=max_cg_iter, tol=cg_tol, reduce=reduce, want_tridiag=True)
+        sol, info = model.khat_solve(x, rhs, K=K, max_iter=max_cg_iter, tol=cg_tol, reduce=reduce, want_tridiag=True)
         u, W = sol[:, :1], sol[:, 1:]
         quad = _colsum(r.detach(), u, reduce).sum()
         logdet = slq_logdet(info["tridiag"][1:], n)
