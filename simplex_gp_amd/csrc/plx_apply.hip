@@ -498,11 +498,13 @@ __global__ __launch_bounds__(kBlock) void blur_axis_compact_kernel(const float *
 template <class V, int ORDER>   // ORDER 0 = runtime order
 __global__ __launch_bounds__(kBlock) void blur_axis_kernel(const V *__restrict__ old, V *__restrict__ out,
                                                            const int *__restrict__ nbr, int m, int64_t mstride,
-                                                           int rowlen, int order_rt, TapArgs taps)
+                                                           int rowlen, int order_rt, TapArgs taps, int ntiles, int remap)
 {
     using O = VecOps<V>;
     const int order = ORDER > 0 ? ORDER : order_rt;
-    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int64_t item = (int64_t)tile * kBlock + threadIdx.x;
     if (item >= (int64_t)m * rowlen) return;
     const int i = (int)(item / rowlen), ch = (int)(item - (int64_t)i * rowlen);
     V acc = O::zero();
@@ -535,12 +537,13 @@ template <class V>
 static void launch_blur_general(const V *cur, V *nxt, const int *nb, int m, int64_t mstride, int rowlen, int order,
                                 const TapArgs &taps, hipStream_t stream)
 {
-    const int grid = ceil_div((int64_t)m * rowlen, kBlock);
+    const int nt = ceil_div((int64_t)m * rowlen, kBlock);
+    const int grid = tile_grid(nt, g_xcd_remap);
     switch (order) {
-    case 1: blur_axis_kernel<V, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps); break;
-    case 2: blur_axis_kernel<V, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps); break;
-    case 3: blur_axis_kernel<V, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps); break;
-    default: blur_axis_kernel<V, 0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps); break;
+    case 1: blur_axis_kernel<V, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap); break;
+    case 2: blur_axis_kernel<V, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap); break;
+    case 3: blur_axis_kernel<V, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap); break;
+    default: blur_axis_kernel<V, 0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap); break;
     }
 }
 
@@ -621,9 +624,12 @@ __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict
                                                            const float *__restrict__ ew,
                                                            const uint32_t *__restrict__ perm, int n, int own_begin,
                                                            int n_own, int d1, const float4 *__restrict__ values,
-                                                           int nch, int vd, float denom, float *__restrict__ out)
+                                                           int nch, int vd, float denom, float *__restrict__ out,
+                                                           int ntiles, int remap)
 {
-    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int64_t item = (int64_t)tile * kBlock + threadIdx.x;
     if (item >= (int64_t)n_own * nch) return;
     const int pl = (int)(item / nch), ch = (int)(item - (int64_t)pl * nch);
     const int p = own_begin + pl;
@@ -669,9 +675,10 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
         }
     } else {
         const int nch = values_stride(vd) / 4;
-        slice_vec_kernel<<<ceil_div((int64_t)n_own * nch, kBlock), kBlock, 0, stream>>>(
+        const int nt = ceil_div((int64_t)n_own * nch, kBlock);
+        slice_vec_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
             evid, ew, perm, n, ob, n_own, L->d + 1, reinterpret_cast<const float4 *>(d_values), nch, vd,
-            L->slice_denom, d_out);
+            L->slice_denom, d_out, nt, g_xcd_remap);
     }
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());
