@@ -29,6 +29,7 @@ static int g_xcd_remap = 1;    // 1: workgroup b works on tile (b % 8) * ceil(nb
 static int g_splat_direct = 1;  // vd = 1: gather from d_src through caller-row indices instead of a sorted copy:
                                 // 0 never, 1 for launch-bound sizes (<= 2e6 corners: saves a launch; at 9e6 corners
                                 // the sorted copy wins, 58 vs 60 us), 2 always
+static int g_splat_wide = 1;    // row-parallel splat for rows of 32..128 chunks (vd 125..512)
 static int g_splat_ablate = 0; // diagnostics only: 1 no value gather, 2 no stores, 4 no row-id loads
 static int g_blur_ablate = 0;  // diagnostics only: 1 no neighbour gathers, 2 no neighbour-id loads either
 extern int g_sort_points;
@@ -40,7 +41,7 @@ extern int g_nbr_symmetric;
 Tunable *tunables()
 {
     static Tunable t[] = {{"sort_points", &g_sort_points}, {"csr_point_major", &g_csr_point_major}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap},
-                          {"splat_direct", &g_splat_direct}, {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
+                          {"splat_direct", &g_splat_direct}, {"splat_wide", &g_splat_wide}, {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
 
@@ -270,6 +271,89 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
     }
 }
 
+// ----------------------------------------------------------------------------
+// splat for WIDE rows (nch >= 32 chunks, i.e. vd >= 125: the backward pass, py:113-119).  The scan kernel tiles the
+// columns, so with 50 chunks it would touch every gathered source row 17-25 times, 32-48 bytes at a time.  Here a
+// wave owns a vertex row and its lanes own the 16-byte chunks of the value row: every gathered source row is read
+// once, contiguously.  Work is still cut into the same kSplatChunk corner ranges, so rows that cross a range edge
+// leave head / tail partial sums for the same splat_fixup_kernel, and the order of additions is fixed.
+//   short rows (<= 64 corners inside the range): one wave per row;
+//   long rows: the four waves take every fourth corner, partial sums are added in wave order through LDS.
+
+template <int MAXCH>   // chunks a lane group can hold: nch <= 64 * MAXCH
+__global__ __launch_bounds__(kBlock) void splat_wide_kernel(const int *__restrict__ csr_pt,
+                                                            const float *__restrict__ csr_w,
+                                                            const int *__restrict__ csr_vid,
+                                                            const int *__restrict__ row_ptr,
+                                                            const float4 *__restrict__ ssrc, int nch, int nnz,
+                                                            float4 *__restrict__ values,
+                                                            float4 *__restrict__ head_partial,
+                                                            float4 *__restrict__ tail_partial, int nchunks, int remap)
+{
+    __shared__ float4 part[kBlock / 64][64 * MAXCH];
+    const int c = tile_index(nchunks, remap);
+    if (c < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = c * kSplatChunk, k1 = min(k0 + kSplatChunk, nnz);
+    const int v_first = csr_vid[k0], v_last = csr_vid[k1 - 1];
+
+    auto emit = [&](int v, int ra, int rb, const float4 (&acc)[MAXCH]) {
+        const bool started_before = ra < k0, ends_after = rb > k1;
+        float4 *dst = (!started_before && !ends_after) ? values + (size_t)v * nch
+                      : (started_before ? head_partial : tail_partial) + (size_t)c * nch;
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q)
+            if (lane + 64 * q < nch) dst[lane + 64 * q] = acc[q];
+    };
+
+    // phase 1: short rows, one wave each
+    for (int v = v_first + wave; v <= v_last; v += kBlock / 64) {
+        const int ra = row_ptr[v], rb = row_ptr[v + 1];
+        const int a = max(ra, k0), b = min(rb, k1);
+        if (b <= a || b - a > 64) continue;
+        float4 acc[MAXCH];
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) acc[q] = f4_zero();
+        for (int k = a; k < b; ++k) {
+            const int pt = csr_pt[k] & 0x7FFFFFFF;
+            const float w = csr_w[k];
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q)
+                if (lane + 64 * q < nch) acc[q] = f4_add(acc[q], f4_scale(w, ssrc[(size_t)pt * nch + lane + 64 * q]));
+        }
+        emit(v, ra, rb, acc);
+    }
+    // phase 2: long rows, all four waves on one row at a time (at most kSplatChunk / 65 of them per range)
+    for (int v = v_first; v <= v_last; ++v) {
+        const int ra = row_ptr[v], rb = row_ptr[v + 1];
+        const int a = max(ra, k0), b = min(rb, k1);
+        if (b - a <= 64) continue;
+        float4 acc[MAXCH];
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) acc[q] = f4_zero();
+        for (int k = a + wave; k < b; k += kBlock / 64) {
+            const int pt = csr_pt[k] & 0x7FFFFFFF;
+            const float w = csr_w[k];
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q)
+                if (lane + 64 * q < nch) acc[q] = f4_add(acc[q], f4_scale(w, ssrc[(size_t)pt * nch + lane + 64 * q]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) part[wave][lane + 64 * q] = acc[q];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q) {
+                float4 t = part[0][lane + 64 * q];
+                for (int wv = 1; wv < kBlock / 64; ++wv) t = f4_add(t, part[wv][lane + 64 * q]);
+                acc[q] = t;
+            }
+            emit(v, ra, rb, acc);
+        }
+    }
+}
+
 __device__ __forceinline__ bool chunk_has_head(const int *__restrict__ csr_pt, const int *__restrict__ csr_vid,
                                                int k0, int k1)
 {
@@ -338,6 +422,19 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     } else {
         const float4 *s4 = reinterpret_cast<const float4 *>(ss);
         float4 *v4 = reinterpret_cast<float4 *>(d_values), *h4 = reinterpret_cast<float4 *>(hp), *t4 = reinterpret_cast<float4 *>(tp);
+        if (nch_total >= 32 && nch_total <= 128 && g_splat_wide) {   // measured: 16 chunks 8 % slower, 50 chunks 1.8x faster
+            const int grid = tile_grid(nchunks, g_xcd_remap);
+            const int *rp = L->row_ptr.as<int>();
+            if (nch_total <= 64)
+                splat_wide_kernel<1><<<grid, kBlock, 0, stream>>>(pt, w, vid, rp, s4, nch_total, nnz, v4, h4, t4, nchunks, g_xcd_remap);
+            else
+                splat_wide_kernel<2><<<grid, kBlock, 0, stream>>>(pt, w, vid, rp, s4, nch_total, nnz, v4, h4, t4, nchunks, g_xcd_remap);
+            splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, nnz, vdp,
+                                                                                                 hp, tp, d_values);
+            tmark(L, stream);
+            PLX_HIP_TRY(hipGetLastError());
+            return PLX_OK;
+        }
         // up to 3 chunks (12 columns) per workgroup in registers; wider rows take more column tiles
         const int nch = nch_total <= 3 ? nch_total : (nch_total % 3 == 0 ? 3 : (nch_total % 2 == 0 ? 2 : 3));
         dim3 grid((unsigned)tile_grid(nchunks, g_xcd_remap), (unsigned)ceil_div(nch_total, nch));

@@ -326,7 +326,7 @@ def test_wide_right_hand_sides(plx):
     ref = rng.standard_normal((n, d)).astype(np.float32)
     taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
     lat = plx.Lattice().build(torch.from_numpy(ref).cuda(), taps)
-    for vd in (2, 5, 12, 13, 30, 110):
+    for vd in (2, 5, 12, 13, 30, 110, 128, 198, 300):      # >= 125 columns take the row-parallel splat
         src = rng.standard_normal((n, vd)).astype(np.float32)
         out = lat.apply(torch.from_numpy(src).cuda()).cpu().numpy()
         assert out.shape == (n, vd)
