@@ -43,8 +43,6 @@ int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only
                               // (fine regime 7.2 -> 4.9 ms; an occupancy bitmap on top did not pay)
 int g_insert_dedupe = 1;      // wave-level skip of repeated keys in the hashed insert (0.38 -> 0.32 ms at m = 4e5)
 int g_compact_nbr = 1;        // 0 never, 1 when under half of the neighbour slots exist, 2 always (A/B)
-int g_csr_point_major = 0;   // corners of one vertex row ordered by corner index then point (0, coalesced key
-                             // writes) or by point (1; measured: no gain in splat, 5x slower key kernel)
 
 // ----------------------------------------------------------------------------
 // small device helpers
@@ -592,13 +590,13 @@ __global__ __launch_bounds__(kBlock) void compact_fill_kernel(const int *__restr
 
 __global__ __launch_bounds__(kBlock) void csr_keys_kernel(const int *__restrict__ evid, int n, int own_begin,
                                                           int n_own, uint32_t *__restrict__ keys,
-                                                          uint32_t *__restrict__ vals, int g_csr_point_major)
+                                                          uint32_t *__restrict__ vals)
 {
     const int pl = blockIdx.x * kBlock + threadIdx.x;
     if (pl >= n_own) return;
     const int r = blockIdx.y;
     const size_t src = (size_t)r * n + own_begin + pl;
-    const size_t dst = g_csr_point_major ? ((size_t)pl * gridDim.y + r) : ((size_t)r * n_own + pl);
+    const size_t dst = (size_t)r * n_own + pl;   // corner-major: coalesced; inside a vertex row the stable sort keeps (r, p) order
     keys[dst] = (uint32_t)evid[src];
     vals[dst] = (uint32_t)src;
 }
@@ -944,7 +942,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
         csr_keys_kernel<<<dim3(ceil_div(n_own, kBlock), D1), kBlock, 0, stream>>>(
             L->evid.as<int>(), n, (int)L->own_begin, n_own, L->sort_keys_in.as<uint32_t>(),
-            L->sort_vals_in.as<uint32_t>(), g_csr_point_major);
+            L->sort_vals_in.as<uint32_t>());
         PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(),
                            L->sort_keys_out.as<uint32_t>(), L->sort_vals_in.as<uint32_t>(),
                            L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, stream));
