@@ -28,6 +28,8 @@ _VARIANTS = {
     "cpu_lattice_ref": ["-O3"],
     "cpu_lattice_ref_dbg": ["-O2", "-DDEBUG"],
 }
+# our own stage-dump driver (oracle/ref_stage_driver.cpp) compiled against the reference header in place
+_DRIVER = ("ref_stages", os.path.join(HERE, "ref_stage_driver.cpp"), ["-O2", "-I" + os.path.dirname(SRC)])
 
 
 def available(name="cpu_lattice_ref"):
@@ -48,7 +50,13 @@ def build(verbose=False):
             load(name=name, sources=[SRC], extra_cflags=flags,
                  build_directory=bdir, verbose=verbose)
             os.replace(os.path.join(bdir, name + ".so"), os.path.join(OUT, name + ".so"))
-    return [n for n in _VARIANTS if available(n)]
+        name, src, flags = _DRIVER
+        if not available(name):
+            bdir = os.path.join(OUT, "build_" + name)
+            os.makedirs(bdir, exist_ok=True)
+            load(name=name, sources=[src], extra_cflags=flags, build_directory=bdir, verbose=verbose)
+            os.replace(os.path.join(bdir, name + ".so"), os.path.join(OUT, name + ".so"))
+    return [n for n in list(_VARIANTS) + [_DRIVER[0]] if available(n)]
 
 
 def load(name="cpu_lattice_ref"):

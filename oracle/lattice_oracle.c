@@ -14,7 +14,8 @@
  * by the reference's own CPU extension (built from /root/reference by
  * oracle/build_ref.py into oracle/_ref/, script tests/golden/make_golden.py);
  * tests/test_oracle_golden.py checks this file against every one of them
- * (bit-for-bit on outputs, identical vertex count m).
+ * (bit-for-bit on outputs, identical vertex count m, and stage by stage -- keys,
+ * greedy / rank, values after splat and after blur -- on the stage dumps).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: the reference's JIT
  * build emits no FMA on baseline x86-64, so contraction must stay off for the

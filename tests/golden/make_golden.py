@@ -9,6 +9,9 @@ oracle/build_ref.py).  The outputs are data: inputs + expected outputs.
                      for the BASELINE.json shapes (inputs are re-generated from
                      the seed at test time; head of the inputs stored to prove
                      the re-generation matches)
+  stages_small.npz   what the reference holds BETWEEN the stages of filter() on 9 of the small cases:
+                     vertex keys, values after splat and after blur, per-point greedy / rank
+                     (dumped through oracle/ref_stage_driver.cpp, which includes the reference header in place)
   host_side.npz      bilateral_kernel.py: tap vectors (get_coeffs, py:14-28,
                      py:162-181) and LatticeFilterGeneral forward / backward
                      (py:76-124) on small inputs
@@ -145,6 +148,25 @@ def main():
             flat[f"{name}/{k}"] = a
     np.savez_compressed(os.path.join(HERE, "filter_small.npz"), **flat)
     print("filter_small.npz:", len(cases), "cases")
+
+    # ------------------------------------------------------------ per-stage dumps
+    # oracle/ref_stage_driver.cpp drives the reference header's public members (splat, blur, slice,
+    # hashTable, greedy, rank) and records what lies between the stages of filter()
+    stg = build_ref.load("ref_stages")
+    stages = {}
+    for name in ["lattice_test_recipe", "cuda_test_recipe", "cloud_n256_d4_o2_ell0.25", "cloud_n256_d8_o1_ell1.0",
+                 "cloud_n2000_d3_vd11_o3_ell1.0", "matern_o3_d18", "grid_ties_d2", "origin_ties",
+                 "cloud_grow_quirk_n2000_d8"]:
+        c = cases[name]
+        keys, v_splat, v_blur, out, greedy, rank = stg.stages(torch.from_numpy(c["src"]), torch.from_numpy(c["ref"]),
+                                                              torch.from_numpy(c["taps"]))
+        assert np.array_equal(out.numpy(), c["out"]), name          # the driver replays filter() exactly
+        assert keys.shape[0] == int(c["m"]), name
+        stages.update({f"{name}/keys": keys.numpy(), f"{name}/values_after_splat": v_splat.numpy(),
+                       f"{name}/values_after_blur": v_blur.numpy(), f"{name}/greedy": greedy.numpy(),
+                       f"{name}/rank": rank.numpy()})
+    np.savez_compressed(os.path.join(HERE, "stages_small.npz"), **stages)
+    print("stages_small.npz:", len(stages) // 5, "cases")
 
     # ------------------------------------------------------------ large cases
     large = {}

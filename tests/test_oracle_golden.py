@@ -41,6 +41,27 @@ def test_staged_equals_fused(golden_dir):
         lat.close()
 
 
+def test_stage_by_stage_bit_exact(golden_dir):
+    """Keys (first-touch order), per-point greedy / rank, values after splat and after blur as the
+    reference's own lattice object holds them (tests/golden/stages_small.npz)."""
+    z, _ = _cases(os.path.join(golden_dir, "filter_small.npz"))
+    st = np.load(os.path.join(golden_dir, "stages_small.npz"))
+    names = sorted({k.split("/")[0] for k in st.files})
+    assert len(names) >= 9
+    oracle.set_exact_mode(True)
+    for name in names:
+        lat = oracle.Lattice(z[f"{name}/ref"], z[f"{name}/taps"])
+        assert np.array_equal(lat.keys, st[f"{name}/keys"]), name
+        assert np.array_equal(lat.greedy, st[f"{name}/greedy"]), name
+        assert np.array_equal(lat.rank, st[f"{name}/rank"]), name
+        v0 = lat.splat(z[f"{name}/src"])
+        assert np.array_equal(v0, st[f"{name}/values_after_splat"]), name
+        v1 = lat.blur(v0)
+        assert np.array_equal(v1, st[f"{name}/values_after_blur"]), name
+        assert np.array_equal(lat.slice(v1), z[f"{name}/out"]), name
+        lat.close()
+
+
 def test_grow_quirk_is_pinned(golden_dir):
     """The reference probes from a stale bucket on the lookup that grows the
     table (h:105 vs h:61-63).  Exact mode reproduces it; the duplicate-free
