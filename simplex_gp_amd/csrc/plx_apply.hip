@@ -24,6 +24,7 @@
 namespace plx {
 
 static int g_blur_vpt = 4;     // vertices per thread in the vd = 1 blur (2 or 4)
+static int g_blur_small = 1;   // all blur passes in one workgroup when m <= 16384 (vd = 1)
 static int g_xcd_remap = 1;    // 1: workgroup b works on tile (b % 8) * ceil(nb/8) + b / 8, so that the 8 XCDs (which
                                // receive workgroups round-robin) each own one contiguous slice of the lattice
 static int g_splat_direct = 1;  // vd = 1: gather from d_src through caller-row indices instead of a sorted copy:
@@ -39,7 +40,7 @@ extern int g_nbr_symmetric;
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap},
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap}, {"blur_small", &g_blur_small},
                           {"splat_direct", &g_splat_direct}, {"splat_wide", &g_splat_wide}, {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
@@ -588,6 +589,43 @@ __global__ __launch_bounds__(kBlock) void blur_axis_compact_kernel(const float *
     }
 }
 
+// vd == 1 on a lattice so small that both ping-pong copies of the vertex values fit in LDS (m <= kSmallM): every
+// pass is launch-bound there (a few us of host + device launch cost for < 1 us of work), so ONE workgroup runs all
+// d+1 passes with a barrier between them.  Same tap order as the per-axis kernels: bit-identical results.
+constexpr int kSmallM = 16384;
+
+template <int ORDER>
+__global__ __launch_bounds__(1024) void blur_small_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                          const int *__restrict__ nbr, int m, int64_t mstride,
+                                                          int d1, TapArgs taps)
+{
+    __shared__ float buf[2][kSmallM];
+    for (int i = threadIdx.x; i < m; i += 1024) buf[0][i] = in[i];
+    __syncthreads();
+    int cur = 0;
+    for (int axis = 0; axis < d1; ++axis) {
+        const int *nb = nbr + (size_t)axis * 2 * ORDER * mstride;
+        for (int i = threadIdx.x; i < m; i += 1024) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < ORDER; ++s) {
+                const int j = nb[s * mstride + i];
+                acc += taps.c[s] * (j >= 0 ? buf[cur][j] : 0.f);
+            }
+            acc += taps.c[ORDER] * buf[cur][i];
+#pragma unroll
+            for (int s = 0; s < ORDER; ++s) {
+                const int j = nb[(ORDER + s) * mstride + i];
+                acc += taps.c[ORDER + 1 + s] * (j >= 0 ? buf[cur][j] : 0.f);
+            }
+            buf[cur ^ 1][i] = acc;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int i = threadIdx.x; i < m; i += 1024) out[i] = buf[cur][i];
+}
+
 // general: one thread per (vertex, value element).  V = float handles any order at
 // vd = 1; V = float4 handles vd > 1 with rowlen = vdp/4 chunks per vertex (lanes of
 // one vertex read the same neighbour id and adjacent 16-byte chunks).
@@ -649,6 +687,20 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
     const int m = (int)L->m, d1 = L->d + 1, order = L->order;
     const int vdp = values_stride(vd);
     const bool v1 = (vd == 1 && order >= 1 && order <= 3 && (g_blur_vpt == 2 || g_blur_vpt == 4));
+    if (v1 && m <= kSmallM && g_blur_small) {
+        // result goes where the per-axis path would leave it, so callers see no difference
+        float *dst = (d1 & 1) ? d_scratch : d_values;
+        const int *nb = L->nbr.as<int>();
+        switch (order) {
+        case 1: blur_small_kernel<1><<<1, 1024, 0, stream>>>(d_values, dst, nb, m, L->mstride, d1, L->taps); break;
+        case 2: blur_small_kernel<2><<<1, 1024, 0, stream>>>(d_values, dst, nb, m, L->mstride, d1, L->taps); break;
+        default: blur_small_kernel<3><<<1, 1024, 0, stream>>>(d_values, dst, nb, m, L->mstride, d1, L->taps); break;
+        }
+        tmark(L, stream);
+        *result_in_scratch = (d1 & 1) ? 1 : 0;
+        PLX_HIP_TRY(hipGetLastError());
+        return PLX_OK;
+    }
     float *cur = d_values, *nxt = d_scratch;
     for (int axis = 0; axis < d1; ++axis) {
         const int *nb = L->nbr.as<int>() + (size_t)axis * 2 * order * L->mstride;
