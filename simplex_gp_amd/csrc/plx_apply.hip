@@ -632,7 +632,8 @@ __global__ __launch_bounds__(1024) void blur_small_kernel(const float *__restric
 template <class V, int ORDER>   // ORDER 0 = runtime order
 __global__ __launch_bounds__(kBlock) void blur_axis_kernel(const V *__restrict__ old, V *__restrict__ out,
                                                            const int *__restrict__ nbr, int m, int64_t mstride,
-                                                           int rowlen, int order_rt, TapArgs taps, int ntiles, int remap)
+                                                           int rowlen, int order_rt, TapArgs taps, int ntiles, int remap,
+                                                           int ablate)
 {
     using O = VecOps<V>;
     const int order = ORDER > 0 ? ORDER : order_rt;
@@ -645,13 +646,13 @@ __global__ __launch_bounds__(kBlock) void blur_axis_kernel(const V *__restrict__
 #pragma unroll
     for (int s = 0; s < order; ++s) {
         const int nb = nbr[s * mstride + i];
-        if (nb >= 0) acc = O::add(acc, O::scale(taps.c[s], old[(size_t)nb * rowlen + ch]));
+        if (nb >= 0) acc = O::add(acc, O::scale(taps.c[s], old[(ablate & 1) ? (size_t)item : (size_t)nb * rowlen + ch]));
     }
     acc = O::add(acc, O::scale(taps.c[order], old[item]));
 #pragma unroll
     for (int s = 0; s < order; ++s) {
         const int nb = nbr[(order + s) * mstride + i];
-        if (nb >= 0) acc = O::add(acc, O::scale(taps.c[order + 1 + s], old[(size_t)nb * rowlen + ch]));
+        if (nb >= 0) acc = O::add(acc, O::scale(taps.c[order + 1 + s], old[(ablate & 1) ? (size_t)item : (size_t)nb * rowlen + ch]));
     }
     out[item] = acc;
 }
@@ -674,10 +675,10 @@ static void launch_blur_general(const V *cur, V *nxt, const int *nb, int m, int6
     const int nt = ceil_div((int64_t)m * rowlen, kBlock);
     const int grid = tile_grid(nt, g_xcd_remap);
     switch (order) {
-    case 1: blur_axis_kernel<V, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap); break;
-    case 2: blur_axis_kernel<V, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap); break;
-    case 3: blur_axis_kernel<V, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap); break;
-    default: blur_axis_kernel<V, 0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap); break;
+    case 1: blur_axis_kernel<V, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
+    case 2: blur_axis_kernel<V, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
+    case 3: blur_axis_kernel<V, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
+    default: blur_axis_kernel<V, 0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
     }
 }
 

@@ -289,3 +289,31 @@ def test_fit_and_predict_on_gpu(plx, tmp_path):
     assert np.isfinite(best["summary"]["test/nll"])
     mean, var = training.predict(model, x[tr], y[tr], x[te])
     assert mean.shape == (n - 16000,) and (var > 0).all()
+
+
+def test_side_stream_and_buffer_reuse_soak(plx):
+    """Work is enqueued on torch's CURRENT stream (not the legacy default one), and one lattice object survives
+    a long sequence of rebuilds with growing / shrinking shapes, dimensions, orders and column counts."""
+    rng = np.random.default_rng(11)
+    lat = plx.Lattice()
+    side = torch.cuda.Stream()
+    shapes = [(5000, 3, 1, 1), (200, 7, 4, 2), (60000, 2, 1, 1), (1, 5, 3, 0), (3000, 12, 2, 3), (40000, 4, 11, 1),
+              (17, 1, 1, 1), (20000, 6, 1, 2), (999, 9, 5, 1), (50000, 3, 1, 1)]
+    for n, d, vd, order in shapes:
+        ref = (rng.standard_normal((n, d)) * rng.choice([0.3, 1.0, 3.0])).astype(np.float32)
+        src = rng.standard_normal((n, vd)).astype(np.float32)
+        taps = np.array([0.1, 0.3, 0.6, 1.0, 0.6, 0.3, 0.1][3 - order: 4 + order], np.float32)
+        ref_t, src_t = torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            lat.build(ref_t, taps)
+            out = lat.apply(src_t)
+            out2 = lat.apply(src_t)          # second MVM on the same lattice
+        side.synchronize()
+        oracle.set_exact_mode(False)
+        want, m = oracle.filter(src, ref, taps, return_m=True)
+        oracle.set_exact_mode(True)
+        assert lat.m == m, (n, d, vd, order)
+        assert rel_l2(out.cpu().numpy(), want) <= 5e-5, (n, d, vd, order)
+        assert torch.equal(out, out2)
+    lat.close()
