@@ -127,7 +127,7 @@ template <> struct VecOps<float4> {
 // rowlen = V-elements per value row (1 for float, nch for float4); tile0 = first
 // chunk of this workgroup's column tile (blockIdx.y * NCH)
 template <class V, int NCH>
-__global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restrict__ csr_pt,
+__global__ __launch_bounds__(kSplatBlock) void splat_scan_kernel(const int *__restrict__ csr_pt,
                                                             const float *__restrict__ csr_w,
                                                             const int *__restrict__ csr_vid,
                                                             const V *__restrict__ ssrc, int rowlen, int nnz,
@@ -136,10 +136,10 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
                                                             int remap)
 {
     using O = VecOps<V>;
-    constexpr int EPT = kSplatChunk / kBlock;   // corners per thread
+    constexpr int EPT = kSplatChunk / kSplatBlock;   // corners per thread
     static_assert(EPT % 4 == 0, "vector loads below take 4 corners at a time");
-    __shared__ int wave_cnt[kBlock / 64];
-    __shared__ V wave_sum[kBlock / 64][NCH];
+    __shared__ int wave_cnt[kSplatBlock / 64];
+    __shared__ V wave_sum[kSplatBlock / 64][NCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = tile_index(nchunks, remap);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void splat_scan_kernel(const int *__restric
         if (head[j]) ++hc;
 #pragma unroll
         for (int cc = 0; cc < NCH; ++cc) run[cc] = O::sel(head[j], p[j][cc], O::add(run[cc], p[j][cc]));
-        const bool chunk_ends = (j == EPT - 1 && tid == kBlock - 1);
+        const bool chunk_ends = (j == EPT - 1 && tid == kSplatBlock - 1);
         if (ablate & 2) continue;
         if (row_ends[j] || chunk_ends) {
             V *dst;
@@ -418,7 +418,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     float *hp = L->head_partial.as<float>(), *tp = L->tail_partial.as<float>();
     const int nnz = (int)L->nnz, nch_total = vdp / 4, nchunks = (int)L->nchunks;
     if (vd == 1) {
-        splat_scan_kernel<float, 1><<<tile_grid(nchunks, g_xcd_remap), kBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, g_splat_ablate, nchunks, g_xcd_remap);
+        splat_scan_kernel<float, 1><<<tile_grid(nchunks, g_xcd_remap), kSplatBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, g_splat_ablate, nchunks, g_xcd_remap);
     } else {
         const float4 *s4 = reinterpret_cast<const float4 *>(ss);
         float4 *v4 = reinterpret_cast<float4 *>(d_values), *h4 = reinterpret_cast<float4 *>(hp), *t4 = reinterpret_cast<float4 *>(tp);
@@ -439,9 +439,9 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         const int nch = nch_total <= 3 ? nch_total : (nch_total % 3 == 0 ? 3 : (nch_total % 2 == 0 ? 2 : 3));
         dim3 grid((unsigned)tile_grid(nchunks, g_xcd_remap), (unsigned)ceil_div(nch_total, nch));
         switch (nch) {
-        case 1: splat_scan_kernel<float4, 1><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
-        case 2: splat_scan_kernel<float4, 2><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
-        default: splat_scan_kernel<float4, 3><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
+        case 1: splat_scan_kernel<float4, 1><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
+        case 2: splat_scan_kernel<float4, 2><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
+        default: splat_scan_kernel<float4, 3><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
         }
     }
     splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, nnz, vdp, hp, tp,

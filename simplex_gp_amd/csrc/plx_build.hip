@@ -902,8 +902,11 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         }
     }
     // compacted copy for sparse lattices (used by the vd = 1 blur when under half the neighbours exist)
+    // Neighbourhoods are only sparse when most corners created a vertex of their own (measured: m/E = 0.19 ->
+    // 57 % of the slots exist, 0.8 -> ~30 %, 0.99 -> 12 %), so the count + host sync is skipped for denser lattices.
     L->use_compact = false;
-    if (order >= 1 && order <= 3 && g_compact_nbr != 0) {
+    const bool maybe_sparse = g_compact_nbr == 2 || (double)m >= 0.4 * (double)L->n * D1;
+    if (order >= 1 && order <= 3 && g_compact_nbr != 0 && maybe_sparse) {
         const int taps2 = 2 * order;
         L->nquads = ((int64_t)m + 3) / 4;
         L->nqwaves = (L->nquads + 63) / 64;

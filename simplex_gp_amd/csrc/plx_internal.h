@@ -11,7 +11,8 @@ namespace plx {
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;   // empty hash slot
 constexpr int kBlock = 256;                // threads per workgroup for every kernel here
-constexpr int kSplatChunk = 1024;          // CSR corners per splat workgroup (4 per thread; 8 measured slower)
+constexpr int kSplatBlock = 256;           // threads per splat-scan workgroup (one wave per chunk measured 15 % slower)
+constexpr int kSplatChunk = 4 * kSplatBlock; // CSR corners per splat workgroup (4 per thread; 8 measured slower)
 
 void set_error(const char *fmt, ...);
 
