@@ -113,6 +113,8 @@ def roofline_for(kt, n, d, m, vd, r, ell=1.0):
         "traffic": pmc["bytes"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,
         "bytes_per_launch": int(ab[dom]), "launch_us": round(launch_ms * 1e3, 2),
         "launches_per_mvm": (d + 1) if dom == "blur_axis" else 1,
+        "note": ("cache-resident lattice: bound by the L2 request rate of 4-byte gathers, not HBM (DESIGN.md 4); "
+                 "the HBM-bound regime is reported under 'fine'") if m * (d + 1) * 8 * r < 128e6 else "",
     }, {
         k: {"us_per_mvm": round(per_mvm_ms[k] * 1e3, 2), "alg_MB_per_mvm": round(ab[k] * ((d + 1) if k == "blur_axis" else 1) / 1e6, 2),
             "GBps": round(ab[k] * ((d + 1) if k == "blur_axis" else 1) / (per_mvm_ms[k] * 1e-3) / 1e9, 1)}
