@@ -216,7 +216,8 @@ def main():
     n_total = n_local * world
     x, v_all = synth(n_total, d, vd)
     lo, hi = rank * n_local, (rank + 1) * n_local
-    ref = (x / args.ell).contiguous().to(dev)
+    # a rank keeps only its own rows on the device (the sharded build never needs the others)
+    ref = (x[lo:hi] / args.ell).contiguous().to(dev) if world > 1 else (x / args.ell).contiguous().to(dev)
     v = v_all[lo:hi].contiguous().to(dev)
     out = torch.empty_like(v)
 
@@ -234,7 +235,7 @@ def main():
 
     if world > 1:
         from simplex_gp_amd.distributed import all_gather_rows
-        ref_local = ref[lo:hi].contiguous()
+        ref_local = ref
     build()
     m = lat.m
     values = scratch = None
