@@ -186,6 +186,12 @@ int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref,
  */
 int plx_coldot(const float *d_a, const float *d_b, int64_t n, int vd, float *d_out, float *d_work, void *stream);
 int64_t plx_coldot_work_floats(int vd);
+/* The two vector updates of a batched CG iteration, one pass each (row-major [n][vd], per-column scalars on the
+ * device):  plx_cg_update: X += P*alpha, R -= AP*alpha, d_rs_new[c] = sum_r R[r][c]^2 (d_work as for plx_coldot);
+ *           plx_cg_direction: P = R + P*beta. */
+int plx_cg_update(float *d_x, float *d_r, const float *d_p, const float *d_ap, const float *d_alpha,
+                  int64_t n, int vd, float *d_rs_new, float *d_work, void *stream);
+int plx_cg_direction(float *d_p, const float *d_r, const float *d_beta, int64_t n, int vd, void *stream);
 
 /* Copy one structure array to host memory (parity tests, debugging).
  * h_dst must hold `bytes` bytes, which must equal the array's size. */

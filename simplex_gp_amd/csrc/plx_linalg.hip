@@ -50,9 +50,78 @@ __global__ __launch_bounds__(kBlock) void coldot_final_kernel(const float *__res
     if (threadIdx.x == 0) out[c] = red[0];
 }
 
+// CG vector updates fused into one pass each (the torch formulation is 2 addcmul_ + a column dot = three
+// passes over [n][vd] plus a mul_/add_ pair for the direction).
+//   update:    X += P * alpha;  R -= AP * alpha;  partial[c] += R[.][c]^2      (alpha per column)
+//   direction: P  = R + P * beta                                                 (beta per column)
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(float *__restrict__ X, float *__restrict__ R,
+                                                           const float *__restrict__ P, const float *__restrict__ AP,
+                                                           const float *__restrict__ alpha, int64_t n, int vd,
+                                                           int logcw, float *__restrict__ partial)
+{
+    __shared__ float red[kBlock];
+    const int cw = 1 << logcw;
+    const int c = threadIdx.x & (cw - 1);
+    const int rl = threadIdx.x >> logcw;
+    const int rows_per_step = kBlock >> logcw;
+    const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, n);
+    float acc = 0.f;
+    if (c < vd) {
+        const float a = alpha[c];
+        for (int64_t r = r0 + rl; r < r1; r += rows_per_step) {
+            const int64_t i = r * vd + c;
+            X[i] += P[i] * a;
+            const float res = R[i] - AP[i] * a;
+            R[i] = res;
+            acc += res * res;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c < vd) {
+        float s = 0.f;
+        for (int k = 0; k < rows_per_step; ++k) s += red[(k << logcw) + c];
+        partial[(size_t)blockIdx.x * vd + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cg_direction_kernel(float *__restrict__ P, const float *__restrict__ R,
+                                                              const float *__restrict__ beta, int64_t total, int vd)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < total) P[i] = R[i] + P[i] * beta[i % vd];
+}
+
 }  // namespace plx
 
 using namespace plx;
+
+extern "C" int plx_cg_update(float *d_x, float *d_r, const float *d_p, const float *d_ap, const float *d_alpha,
+                             int64_t n, int vd, float *d_rs_new, float *d_work, void *stream)
+{
+    if (!d_x || !d_r || !d_p || !d_ap || !d_alpha || !d_rs_new || !d_work) { set_error("plx_cg_update: NULL argument"); return PLX_ERR_INVALID; }
+    if (n < 0 || vd < 1 || vd > kBlock) { set_error("plx_cg_update: vd = %d outside 1..%d", vd, kBlock); return PLX_ERR_INVALID; }
+    int logcw = 0;
+    while ((1 << logcw) < vd) ++logcw;
+    hipStream_t s = (hipStream_t)stream;
+    cg_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_alpha, n, vd, logcw, d_work);
+    coldot_final_kernel<<<vd, kBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_cg_direction(float *d_p, const float *d_r, const float *d_beta, int64_t n, int vd, void *stream)
+{
+    if (!d_p || !d_r || !d_beta) { set_error("plx_cg_direction: NULL argument"); return PLX_ERR_INVALID; }
+    if (n < 0 || vd < 1) { set_error("plx_cg_direction: bad shape"); return PLX_ERR_INVALID; }
+    const int64_t total = n * vd;
+    if (total > 0)
+        cg_direction_kernel<<<ceil_div(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(d_p, d_r, d_beta, total, vd);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
 
 extern "C" int plx_coldot(const float *d_a, const float *d_b, int64_t n, int vd, float *d_out, float *d_work,
                           void *stream)

@@ -50,10 +50,59 @@ def _colsum(a, b, reduce=None):
     return reduce(s) if reduce is not None else s
 
 
-def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False):
+def _native_ok(*ts):
+    t0 = ts[0]
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous() and t.shape == t0.shape
+               for t in ts) and t0.shape[1] <= 256
+
+
+def _cg_update(X, R, P, AP, alpha, reduce=None):
+    """X += P*alpha; R -= AP*alpha; returns the new column-wise |R|^2 (one fused pass on the GPU)."""
+    if _native_ok(X, R, P, AP):
+        import ctypes
+        from . import _native as nv
+        n, t = X.shape
+        key = (X.device.index, t)
+        work = _dot_work.get(key)
+        if work is None:
+            work = _dot_work[key] = torch.empty(int(nv.lib().plx_coldot_work_floats(t)), dtype=torch.float32,
+                                                device=X.device)
+        out = torch.empty(t, dtype=torch.float32, device=X.device)
+        alpha = alpha.to(torch.float32).contiguous()
+        p = lambda a: ctypes.c_void_p(a.data_ptr())          # noqa: E731
+        with torch.cuda.device(X.device):
+            rc = nv.lib().plx_cg_update(p(X), p(R), p(P), p(AP), p(alpha), n, t, p(out), p(work),
+                                        ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream))
+        nv.check(rc, "plx_cg_update")
+        return reduce(out) if reduce is not None else out
+    X.addcmul_(P, alpha)
+    R.addcmul_(AP, -alpha)
+    return _colsum(R, R, reduce)
+
+
+def _cg_direction(P, R, beta):
+    """P = R + P*beta in one pass."""
+    if _native_ok(P, R):
+        import ctypes
+        from . import _native as nv
+        beta = beta.to(torch.float32).contiguous()
+        with torch.cuda.device(P.device):
+            rc = nv.lib().plx_cg_direction(ctypes.c_void_p(P.data_ptr()), ctypes.c_void_p(R.data_ptr()),
+                                           ctypes.c_void_p(beta.data_ptr()), P.shape[0], P.shape[1],
+                                           ctypes.c_void_p(torch.cuda.current_stream(P.device).cuda_stream))
+        nv.check(rc, "plx_cg_direction")
+        return
+    P.mul_(beta).add_(R)
+
+
+def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False, check_every=4):
     """Solve A X = B for all columns of B at once (A symmetric positive definite,
     known through `matmul`).  Stops when every column's residual norm is below
-    `tol` x its right-hand-side norm, or after max_iter iterations.
+    `tol` x its right-hand-side norm, or after max_iter iterations.  The stopping
+    test reads a device flag, i.e. synchronises with the GPU; it runs every
+    `check_every` iterations so that the launch queue stays full (converged
+    columns are frozen on the device in every iteration, so the extra iterations
+    do not change them).
 
     Returns (X, info); with want_tridiag, info["tridiag"] holds the per-column
     Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
@@ -70,17 +119,15 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
         AP = matmul(P).contiguous()
         pAp = _colsum(P, AP, reduce)
         alpha = torch.where(active, rs / pAp.clamp_min(1e-30), torch.zeros_like(rs))
-        X.addcmul_(P, alpha)
-        R.addcmul_(AP, -alpha)
-        rs_new = _colsum(R, R, reduce)
+        rs_new = _cg_update(X, R, P, AP, alpha, reduce)
         beta = torch.where(active, rs_new / rs.clamp_min(1e-30), torch.zeros_like(rs))
         if want_tridiag:
             alphas.append(alpha)
             betas.append(beta)
-        P.mul_(beta).add_(R)
+        _cg_direction(P, R, beta)
         rs = rs_new
         active = active & (rs.sqrt() / b_norm > tol)
-        if not bool(active.any()):
+        if tol > 0 and (it % check_every == 0 or it == max_iter) and not bool(active.any()):
             break
     info = {"iterations": it, "residual": (rs.sqrt() / b_norm)}
     if want_tridiag:

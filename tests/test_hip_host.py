@@ -317,3 +317,19 @@ def test_side_stream_and_buffer_reuse_soak(plx):
         assert rel_l2(out.cpu().numpy(), want) <= 5e-5, (n, d, vd, order)
         assert torch.equal(out, out2)
     lat.close()
+
+
+def test_fused_cg_updates_match_torch(plx):
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(6)
+    for n, t in [(1000, 1), (100003, 11), (5000, 40)]:
+        X, R, P, AP = (torch.randn(n, t, generator=g).cuda() for _ in range(4))
+        alpha = torch.randn(t, generator=g).cuda()
+        beta = torch.randn(t, generator=g).cuda()
+        Xw, Rw = X + P * alpha, R - AP * alpha
+        rs = solvers._cg_update(X, R, P, AP, alpha)
+        assert torch.allclose(X, Xw, atol=1e-6) and torch.allclose(R, Rw, atol=1e-6)
+        assert torch.allclose(rs.double(), (Rw.double() ** 2).sum(0), rtol=1e-4)
+        Pw = R + P * beta
+        solvers._cg_direction(P, R, beta)
+        assert torch.allclose(P, Pw, atol=1e-6)
