@@ -186,6 +186,13 @@ int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref,
  */
 int plx_coldot(const float *d_a, const float *d_b, int64_t n, int vd, float *d_out, float *d_work, void *stream);
 int64_t plx_coldot_work_floats(int vd);
+/* The two elementwise ends of the position gradient (bilateral_kernel.py:113-122), one pass each, row-major fp32:
+ *   plx_backward_stack:    d_out[n][2L(1+d)] = [ g | g (x) x | src | src (x) x ]   (the matrix the filter is applied to)
+ *   plx_backward_contract: d_grad_x[n][d] = -2 sum_l ( src x wg - src wgx + g x ws - g wsx ) from the filtered stack */
+int plx_backward_stack(const float *d_g, const float *d_src, const float *d_x, int64_t n, int L, int d,
+                       float *d_out, void *stream);
+int plx_backward_contract(const float *d_g, const float *d_src, const float *d_x, const float *d_filtered,
+                          int64_t n, int L, int d, float *d_grad_x, void *stream);
 /* The two vector updates of a batched CG iteration, one pass each (row-major [n][vd], per-column scalars on the
  * device):  plx_cg_update: X += P*alpha, R -= AP*alpha, d_rs_new[c] = sum_r R[r][c]^2 (d_work as for plx_coldot);
  *           plx_cg_direction: P = R + P*beta. */

@@ -94,9 +94,77 @@ __global__ __launch_bounds__(kBlock) void cg_direction_kernel(float *__restrict_
     if (i < total) P[i] = R[i] + P[i] * beta[i % vd];
 }
 
+// Backward pass of the lattice filter with respect to the positions (bilateral_kernel.py:113-122), the two
+// elementwise ends of it in one pass each:
+//   stack:    out[p] = [ g (L) | g (x) x (L*d) | src (L) | src (x) x (L*d) ],  (a (x) x)[l*d + k] = a[p][l] * x[p][k]
+//   contract: grad_x[p][k] = -2 sum_l ( src_l x_k wg_l - src_l wgx_{l,k} + g_l x_k ws_l - g_l wsx_{l,k} )
+//             with [wg | wgx | ws | wsx] = the filtered stack
+__global__ __launch_bounds__(kBlock) void backward_stack_kernel(const float *__restrict__ g, const float *__restrict__ src,
+                                                                const float *__restrict__ x, int64_t n, int L, int d,
+                                                                float *__restrict__ out)
+{
+    const int W = 2 * L * (1 + d);
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= n * W) return;
+    const int64_t p = item / W;
+    int c = (int)(item - p * W);
+    const float *a = g;
+    if (c >= L * (1 + d)) { a = src; c -= L * (1 + d); }
+    float v;
+    if (c < L) v = a[p * L + c];
+    else { const int q = c - L, l = q / d, k = q - l * d; v = a[p * L + l] * x[p * d + k]; }
+    out[item] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void backward_contract_kernel(const float *__restrict__ g,
+                                                                   const float *__restrict__ src,
+                                                                   const float *__restrict__ x,
+                                                                   const float *__restrict__ f, int64_t n, int L, int d,
+                                                                   float *__restrict__ grad_x)
+{
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= n * d) return;
+    const int64_t p = item / d;
+    const int k = (int)(item - p * d);
+    const int W = 2 * L * (1 + d);
+    const float *fp = f + p * W;
+    const float *wg = fp, *wgx = fp + L, *ws = fp + L + L * d, *wsx = fp + 2 * L + L * d;
+    const float xk = x[item];
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float s = src[p * L + l], gg = g[p * L + l];
+        acc += s * xk * wg[l] - s * wgx[l * d + k] + gg * xk * ws[l] - gg * wsx[l * d + k];
+    }
+    grad_x[item] = -2.0f * acc;
+}
+
 }  // namespace plx
 
 using namespace plx;
+
+extern "C" int plx_backward_stack(const float *d_g, const float *d_src, const float *d_x, int64_t n, int L, int d,
+                                  float *d_out, void *stream)
+{
+    if (!d_g || !d_src || !d_x || !d_out) { set_error("plx_backward_stack: NULL argument"); return PLX_ERR_INVALID; }
+    if (n < 0 || L < 1 || d < 1) { set_error("plx_backward_stack: bad shape"); return PLX_ERR_INVALID; }
+    const int64_t total = n * 2 * L * (1 + d);
+    if (total > 0)
+        backward_stack_kernel<<<ceil_div(total, kBlock), kBlock, 0, (hipStream_t)stream>>>(d_g, d_src, d_x, n, L, d, d_out);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_backward_contract(const float *d_g, const float *d_src, const float *d_x, const float *d_filtered,
+                                     int64_t n, int L, int d, float *d_grad_x, void *stream)
+{
+    if (!d_g || !d_src || !d_x || !d_filtered || !d_grad_x) { set_error("plx_backward_contract: NULL argument"); return PLX_ERR_INVALID; }
+    if (n < 0 || L < 1 || d < 1) { set_error("plx_backward_contract: bad shape"); return PLX_ERR_INVALID; }
+    if (n * d > 0)
+        backward_contract_kernel<<<ceil_div(n * d, kBlock), kBlock, 0, (hipStream_t)stream>>>(d_g, d_src, d_x, d_filtered, n,
+                                                                                            L, d, d_grad_x);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
 
 extern "C" int plx_cg_update(float *d_x, float *d_r, const float *d_p, const float *d_ap, const float *d_alpha,
                              int64_t n, int vd, float *d_rs_new, float *d_work, void *stream)

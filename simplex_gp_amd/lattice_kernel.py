@@ -122,7 +122,27 @@ class LatticeFilterGeneral(Function):
             if ctx.needs_input_grad[0] and not ctx.needs_input_grad[1]:
                 # K is treated as symmetric (py:110-111)
                 grad_source = filt(g.contiguous(), ref.contiguous(), ctx.coeffs)
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and LatticeFilterGeneral.method is None and g.is_cuda and g.dim() == 2:
+                # same computation, the stack and the contraction each as one native pass (plx_backward_*)
+                import ctypes
+                from . import _native as nv
+                n = src.shape[0]
+                gc, sc, rc_ = g.contiguous(), src.contiguous(), ref.contiguous()
+                stacked = torch.empty((n, 2 * L * (1 + d)), dtype=torch.float32, device=g.device)
+                ptr = lambda t: ctypes.c_void_p(t.data_ptr())        # noqa: E731
+                stream = ctypes.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
+                with torch.cuda.device(g.device):
+                    nv.check(nv.lib().plx_backward_stack(ptr(gc), ptr(sc), ptr(rc_), n, L, d, ptr(stacked), stream),
+                             "plx_backward_stack")
+                filtered = filt(stacked, rc_, ctx.deriv_coeffs)
+                del stacked
+                grad_reference = torch.empty_like(rc_)
+                with torch.cuda.device(g.device):
+                    nv.check(nv.lib().plx_backward_contract(ptr(gc), ptr(sc), ptr(rc_), ptr(filtered), n, L, d,
+                                                            ptr(grad_reference), stream), "plx_backward_contract")
+                if ctx.needs_input_grad[0]:
+                    grad_source = filtered[:, :L].contiguous()   # filtered with the derivative taps (py:123)
+            elif ctx.needs_input_grad[1]:
                 # one filter with the derivative taps over [g, g (x) x, src, src (x) x]   (py:113-119)
                 gx = (g[..., None] * ref[..., None, :])          # n x L x d
                 sx = (src[..., None] * ref[..., None, :])
