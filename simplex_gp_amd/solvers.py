@@ -95,7 +95,75 @@ def _cg_direction(P, R, beta):
     P.mul_(beta).add_(R)
 
 
-def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False, check_every=4):
+class PivotedCholeskyPreconditioner:
+    """P = L L^T + sigma^2 I with L [n, k] the rank-k pivoted Cholesky factor of s K: the
+    preconditioner GPyTorch builds for (s K + sigma^2 I) when max_preconditioner_size > 0
+    (experiments/train_simplexgp.py:34-41 runs with pre_size = 100, configs/simplexgp.yml).
+
+    The factor needs the diagonal of K (ones: py:139-140) and k rows of it; a row is one
+    MVM with a one-hot right-hand side (the operator is known through matmul only).  The
+    pivot index stays on the device (scatter with an index tensor), so the k steps queue
+    without host synchronisation.
+
+    solve(R)  = P^-1 R by Woodbury, (R - L C^-1 L^T R) / sigma^2 with C = sigma^2 I_k + L^T L
+    logdet()  = logdet C + (n - k) log sigma^2
+    sample(t) = t columns drawn from N(0, P):  L g1 + sigma g2
+    """
+
+    def __init__(self, kmatmul, n, outputscale, noise, rank, device, dtype=torch.float32, rel_tol=1e-6):
+        s, noise = float(outputscale), float(noise)
+        rank = int(min(rank, n))
+        Lt = torch.zeros(rank, n, dtype=dtype, device=device)           # L^T: every pivot's column is one contiguous row
+        diag = torch.full((n,), s, dtype=dtype, device=device)          # s * diag(K), diag(K) = 1
+        onehot = torch.zeros(n, 1, dtype=dtype, device=device)
+        for m in range(rank):
+            piv = torch.argmax(diag).reshape(1)
+            dmax = diag[piv]
+            onehot.zero_().index_fill_(0, piv, 1.0)
+            row = s * kmatmul(onehot).reshape(-1)
+            if m > 0:
+                row = row - Lt[:m].t() @ Lt[:m].index_select(1, piv).reshape(-1)
+            # a pivot whose residual diagonal has fallen to rounding level contributes nothing (column of zeros)
+            ok = dmax > rel_tol * s
+            col = torch.where(ok, row / dmax.clamp_min(1e-30).sqrt(), torch.zeros_like(row))
+            Lt[m] = col
+            diag = (diag - col * col).clamp_min(0).index_fill(0, piv, 0.0)
+        self.Lt, self.noise, self.n, self.rank = Lt, noise, n, rank
+        C = self._gram(Lt.t()).double() + noise * torch.eye(rank, dtype=torch.float64, device=device)
+        self._chol = torch.linalg.cholesky(C)
+
+    @property
+    def L(self):
+        return self.Lt.t()
+
+    def _gram(self, R, splits=256):
+        """L^T R, [k, t]: the reduction runs over the n rows, so it is cut into `splits` independent
+        partial products (one batched GEMM) instead of one GEMM with a single long inner loop."""
+        n, k = self.n, self.rank
+        if n < 64 * splits:
+            return self.Lt @ R
+        chunk = n // splits
+        main = chunk * splits
+        A = self.Lt[:, :main].reshape(k, splits, chunk).permute(1, 0, 2)         # [splits, k, chunk], a view
+        out = torch.bmm(A, R[:main].reshape(splits, chunk, R.shape[1])).sum(0)
+        if main < n:
+            out = out + self.Lt[:, main:] @ R[main:]
+        return out
+
+    def solve(self, R):
+        t = torch.cholesky_solve(self._gram(R).double(), self._chol).to(R.dtype)
+        return (R - self.Lt.t() @ t) / self.noise
+
+    def logdet(self):
+        return 2.0 * self._chol.diagonal().log().sum() + (self.n - self.rank) * math.log(self.noise)
+
+    def sample(self, t, generator=None):
+        g1 = torch.randn(self.rank, t, generator=generator, device=self.Lt.device, dtype=self.Lt.dtype)
+        g2 = torch.randn(self.n, t, generator=generator, device=self.Lt.device, dtype=self.Lt.dtype)
+        return self.Lt.t() @ g1 + math.sqrt(self.noise) * g2
+
+
+def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False, check_every=4, precond=None):
     """Solve A X = B for all columns of B at once (A symmetric positive definite,
     known through `matmul`).  Stops when every column's residual norm is below
     `tol` x its right-hand-side norm, or after max_iter iterations.  The stopping
@@ -104,9 +172,15 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     columns are frozen on the device in every iteration, so the extra iterations
     do not change them).
 
+    `precond` (an object with solve(R) = P^-1 R) switches to preconditioned CG; the
+    tridiagonals are then those of P^-1/2 A P^-1/2 started at P^-1/2 B, and
+    info["rz0"] holds B^T P^-1 B per column (the quadrature weight).
+
     Returns (X, info); with want_tridiag, info["tridiag"] holds the per-column
     Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
     """
+    if precond is not None:
+        return _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every)
     X = torch.zeros_like(B)
     R = B.clone().contiguous()
     P = R.clone()
@@ -131,31 +205,72 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
             break
     info = {"iterations": it, "residual": (rs.sqrt() / b_norm)}
     if want_tridiag:
-        k = len(alphas)
-        a = torch.stack(alphas, 0).double()           # [k, t]
-        b = torch.stack(betas, 0).double()
-        # a column that converged early has alpha = 0 afterwards: freeze its tridiagonal there
-        valid = a > 0
-        inv_a = torch.where(valid, 1.0 / a.clamp_min(1e-300), torch.zeros_like(a))
-        t = B.shape[1]
-        T = torch.zeros(t, k, k, dtype=torch.float64, device=B.device)
-        for i in range(k):
-            diag = inv_a[i] + (b[i - 1] * inv_a[i - 1] if i > 0 else 0.0)
-            T[:, i, i] = torch.where(valid[i], diag, torch.ones_like(diag))
-            if i + 1 < k:
-                off = torch.where(valid[i + 1], b[i].clamp_min(0).sqrt() * inv_a[i], torch.zeros_like(diag))
-                T[:, i, i + 1] = off
-                T[:, i + 1, i] = off
-        info["tridiag"] = T
+        info["tridiag"] = _tridiag_from_cg(alphas, betas, B)
     return X, info
 
 
-def slq_logdet(tridiag, n):
-    """Stochastic Lanczos quadrature: logdet(A) ~ n * mean_i e1^T log(T_i) e1 for
-    probes with ||z||^2 = n."""
+def _tridiag_from_cg(alphas, betas, B):
+    k = len(alphas)
+    a = torch.stack(alphas, 0).double()           # [k, t]
+    b = torch.stack(betas, 0).double()
+    # a column that converged early has alpha = 0 afterwards: freeze its tridiagonal there
+    valid = a > 0
+    inv_a = torch.where(valid, 1.0 / a.clamp_min(1e-300), torch.zeros_like(a))
+    t = B.shape[1]
+    T = torch.zeros(t, k, k, dtype=torch.float64, device=B.device)
+    for i in range(k):
+        diag = inv_a[i] + (b[i - 1] * inv_a[i - 1] if i > 0 else 0.0)
+        T[:, i, i] = torch.where(valid[i], diag, torch.ones_like(diag))
+        if i + 1 < k:
+            off = torch.where(valid[i + 1], b[i].clamp_min(0).sqrt() * inv_a[i], torch.zeros_like(diag))
+            T[:, i, i + 1] = off
+            T[:, i + 1, i] = off
+    return T
+
+
+def _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every):
+    X = torch.zeros_like(B)
+    R = B.clone().contiguous()
+    Z = precond.solve(R).contiguous()
+    P = Z.clone()
+    rz = _colsum(R, Z, reduce)
+    rz0 = rz.clone()
+    b_norm = _colsum(R, R, reduce).sqrt().clamp_min(1e-30)
+    alphas, betas = [], []
+    active = torch.ones_like(rz, dtype=torch.bool)
+    it = 0
+    rr = b_norm ** 2
+    for it in range(1, max_iter + 1):
+        AP = matmul(P).contiguous()
+        pAp = _colsum(P, AP, reduce)
+        alpha = torch.where(active, rz / pAp.clamp_min(1e-30), torch.zeros_like(rz))
+        rr = _cg_update(X, R, P, AP, alpha, reduce)
+        Z = precond.solve(R).contiguous()
+        rz_new = _colsum(R, Z, reduce)
+        beta = torch.where(active, rz_new / rz.clamp_min(1e-30), torch.zeros_like(rz))
+        if want_tridiag:
+            alphas.append(alpha)
+            betas.append(beta)
+        _cg_direction(P, Z, beta)
+        rz = rz_new
+        active = active & (rr.sqrt() / b_norm > tol)
+        if tol > 0 and (it % check_every == 0 or it == max_iter) and not bool(active.any()):
+            break
+    info = {"iterations": it, "residual": (rr.sqrt() / b_norm), "rz0": rz0}
+    if want_tridiag:
+        info["tridiag"] = _tridiag_from_cg(alphas, betas, B)
+    return X, info
+
+
+def slq_logdet(tridiag, n, weights=None):
+    """Stochastic Lanczos quadrature: logdet(A) ~ mean_i |z_i|^2 e1^T log(T_i) e1; Rademacher
+    probes have |z|^2 = n, preconditioned probes pass their own weights (b^T P^-1 b)."""
     evals, evecs = torch.linalg.eigh(tridiag)
     w = evecs[:, 0, :] ** 2
-    return float(n) * (w * evals.clamp_min(1e-30).log()).sum(-1).mean()
+    quad = (w * evals.clamp_min(1e-30).log()).sum(-1)
+    if weights is None:
+        return float(n) * quad.mean()
+    return (weights.double() * quad).mean()
 
 
 class LatticeGP(nn.Module):
@@ -204,15 +319,26 @@ class LatticeGP(nn.Module):
             s, noise = self.outputscale, self.noise
             lat.set_lattice_row_order(True)
             try:
+                if cg_args.get("precond") is not None:
+                    # the factor's rows are in the caller's order: keep that order for the whole solve
+                    lat.set_lattice_row_order(False)
+                    return batched_cg(lambda V: lat.apply(V).mul_(s).addcmul_(V, noise), rhs, **cg_args)
                 sol, info = batched_cg(lambda V: lat.apply(V).mul_(s).addcmul_(V, noise),
                                        lat.to_lattice_order(rhs), **cg_args)
             finally:
                 lat.set_lattice_row_order(False)
             return lat.from_lattice_order(sol), info
 
+    def preconditioner(self, x, rank, K=None):
+        """Rank-`rank` pivoted-Cholesky preconditioner of (s K + sigma^2 I) (no gradients)."""
+        with torch.no_grad():
+            K = self.kernel(x, x) if K is None else K
+            return PivotedCholeskyPreconditioner(K.matmul, x.shape[0], self.outputscale, self.noise, rank,
+                                                 device=x.device, dtype=x.dtype)
+
 
 def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, reduce=None,
-                            n_total=None):
+                            n_total=None, pre_size=0):
     """Per-datapoint log marginal likelihood (the quantity GPyTorch's
     ExactMarginalLogLikelihood returns) of a LatticeGP, differentiable with
     respect to every hyper-parameter.
@@ -222,20 +348,38 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
         S = -u^T r + 1/2 u^T K u - 1/(2t) sum_i w_i^T K z_i,   u = K^-1 r, w_i = K^-1 z_i (detached)
     whose gradient equals that of the MLL; it costs one more MVM (vd = 1 + t)
     and its backward (one wide filter, py:113-122).
+
+    pre_size > 0 (GPyTorch's max_preconditioner_size; the reference trains with 100)
+    preconditions the solve with P = pivoted-Cholesky(s K, pre_size) + sigma^2 I:
+    probes are drawn from N(0, P), logdet = logdet P + SLQ of P^-1/2 (sK + sigma^2 I) P^-1/2,
+    and the log-det gradient pairs w_i with P^-1 z_i  (E[P^-1 z z^T] = I).
     """
     n_local = y.shape[0]
     n = n_local if n_total is None else n_total
     r = (y - model.mean).reshape(-1, 1)
     g = torch.Generator(device=y.device).manual_seed(seed)      # on the device: 1e7 CPU draws cost ~0.1 s per step
-    Z = torch.randint(0, 2, (n_local, num_probes), generator=g, device=y.device).float() * 2 - 1
     K = model.kernel(x, x)
     mm = model.khat_matmul(x, K)
+    precond = None
+    if pre_size > 0:
+        if reduce is not None:
+            raise NotImplementedError("the pivoted-Cholesky preconditioner is single-process (rows of K are not sharded)")
+        precond = model.preconditioner(x, pre_size, K=K)
     with torch.no_grad():
+        if precond is None:
+            Z = torch.randint(0, 2, (n_local, num_probes), generator=g, device=y.device).to(r.dtype) * 2 - 1
+        else:
+            Z = precond.sample(num_probes, generator=g)
         rhs = torch.cat([r.detach(), Z], 1)
-        sol, info = model.khat_solve(x, rhs, K=K, max_iter=max_cg_iter, tol=cg_tol, reduce=reduce, want_tridiag=True)
+        sol, info = model.khat_solve(x, rhs, K=K, max_iter=max_cg_iter, tol=cg_tol, reduce=reduce, want_tridiag=True,
+                                     precond=precond)
         u, W = sol[:, :1], sol[:, 1:]
         quad = _colsum(r.detach(), u, reduce).sum()
-        logdet = slq_logdet(info["tridiag"][1:], n)
+        if precond is None:
+            logdet = slq_logdet(info["tridiag"][1:], n)
+        else:
+            logdet = precond.logdet() + slq_logdet(info["tridiag"][1:], n, weights=info["rz0"][1:])
+            Z = precond.solve(Z)
         value = -0.5 * quad - 0.5 * logdet - 0.5 * n * math.log(2 * math.pi)
     KV = mm(torch.cat([u, Z], 1))                                # differentiable MVM
     s_quad = -(u * r).sum() + 0.5 * (u * KV[:, :1]).sum()

@@ -48,7 +48,7 @@ def lanczos(matmul, v0, steps):
 
 
 @torch.no_grad()
-def predict(model, x, y, x_star, max_cg_iter=1000, cg_tol=1e-2, lanc_iter=100, variance=True):
+def predict(model, x, y, x_star, max_cg_iter=1000, cg_tol=1e-2, lanc_iter=100, variance=True, pre_size=0):
     """Posterior mean and variance of the latent function at x_star.
 
     mean = mu + s K(x*, X) (s K + sigma^2 I)^-1 (y - mu)          one CG solve + one rectangular MVM
@@ -57,7 +57,8 @@ def predict(model, x, y, x_star, max_cg_iter=1000, cg_tol=1e-2, lanc_iter=100, v
     """
     assert isinstance(model, LatticeGP)
     r = (y - model.mean).reshape(-1, 1)
-    alpha, _ = model.khat_solve(x, r, max_iter=max_cg_iter, tol=cg_tol)
+    precond = model.preconditioner(x, pre_size) if pre_size > 0 else None
+    alpha, _ = model.khat_solve(x, r, max_iter=max_cg_iter, tol=cg_tol, precond=precond)
     K_star = model.kernel(x_star, x)                      # RectangularLazyLattice, [n*, n]
     s = model.outputscale
     mean = model.mean + s * K_star.matmul(alpha).squeeze(-1)
@@ -108,26 +109,29 @@ class EarlyStopper:
 
 
 def fit(model, train, val=None, test=None, epochs=100, lr=0.1, patience=200, log_every=1, num_probes=10,
-        cg_iter=1000, cg_tol=1.0, cg_eval_tol=1e-2, lanc_iter=100, checkpoint=None, log=None):
+        cg_iter=1000, cg_tol=1.0, cg_eval_tol=1e-2, lanc_iter=100, pre_size=0, checkpoint=None, log=None):
     """Adam on -MLL; every `log_every` epochs evaluate on val/test, keep the state
     with the best validation RMSE, stop after `patience` evaluations without
-    improvement; optionally torch.save the best state_dict to `checkpoint`."""
+    improvement; optionally torch.save the best state_dict to `checkpoint`.
+    `pre_size` is the rank of the pivoted-Cholesky preconditioner (train_simplexgp.py:36, the
+    reference's configs use 100; it costs pre_size extra single-column MVMs per solve)."""
     x, y = train
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     stopper = EarlyStopper(patience=patience)
     history = []
     for epoch in range(epochs):
         opt.zero_grad()
-        mll = marginal_log_likelihood(model, x, y, num_probes=num_probes, max_cg_iter=cg_iter, cg_tol=cg_tol, seed=epoch)
+        mll = marginal_log_likelihood(model, x, y, num_probes=num_probes, max_cg_iter=cg_iter, cg_tol=cg_tol, seed=epoch,
+                                      pre_size=pre_size)
         (-mll).backward()
         opt.step()
         row = {"epoch": epoch + 1, "train/mll": float(mll.detach())}
         if val is not None and epoch % log_every == 0:
             row.update(evaluate(model, x, y, val[0], val[1], label="val", max_cg_iter=cg_iter, cg_tol=cg_eval_tol,
-                                lanc_iter=lanc_iter))
+                                lanc_iter=lanc_iter, pre_size=pre_size))
             if test is not None:
                 row.update(evaluate(model, x, y, test[0], test[1], label="test", max_cg_iter=cg_iter,
-                                    cg_tol=cg_eval_tol, lanc_iter=lanc_iter))
+                                    cg_tol=cg_eval_tol, lanc_iter=lanc_iter, pre_size=pre_size))
             stopper(-row["val/rmse"], {"state_dict": {k: v.detach().clone() for k, v in model.state_dict().items()},
                                        "summary": dict(row)})
             if checkpoint is not None:

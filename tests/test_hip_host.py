@@ -333,3 +333,31 @@ def test_fused_cg_updates_match_torch(plx):
         Pw = R + P * beta
         solvers._cg_direction(P, R, beta)
         assert torch.allclose(P, Pw, atol=1e-6)
+
+
+def test_preconditioned_solve_on_gpu(plx):
+    """Pivoted-Cholesky preconditioner on the HIP path (rows of K through one-hot MVMs): same solution as plain CG
+    in fewer iterations at small noise, and the preconditioned MLL agrees with the unpreconditioned one."""
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(5)
+    n, d = 30000, 2
+    x = torch.randn(n, d, generator=g).cuda()
+    y = (torch.sin(2 * x[:, 0]) + 0.05 * torch.randn(n, generator=g).cuda())
+    model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).cuda()
+    with torch.no_grad():
+        model.raw_noise.fill_(-5.0)
+        rhs = y[:, None].contiguous()
+        sol0, info0 = model.khat_solve(x, rhs, max_iter=2000, tol=1e-4, check_every=1)
+        pre = model.preconditioner(x, 50)
+        sol1, info1 = model.khat_solve(x, rhs, max_iter=2000, tol=1e-4, check_every=1, precond=pre)
+        mm = model.khat_matmul(x)
+        r0 = float((mm(sol0) - rhs).norm() / rhs.norm())
+        r1 = float((mm(sol1) - rhs).norm() / rhs.norm())
+    print("cg iterations", info0["iterations"], "pcg", info1["iterations"], "residuals", r0, r1)
+    assert r0 < 5e-4 and r1 < 5e-4
+    assert info1["iterations"] < info0["iterations"]
+    a = solvers.marginal_log_likelihood(model, x, y, num_probes=20, cg_tol=1e-3, seed=0)
+    b = solvers.marginal_log_likelihood(model, x, y, num_probes=20, cg_tol=1e-3, seed=0, pre_size=50)
+    b.backward()
+    assert abs(float(a.detach()) - float(b.detach())) < 0.02 * (1 + abs(float(a.detach())))
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())

@@ -41,6 +41,82 @@ def test_batched_cg_and_slq_on_dense_spd():
     assert abs(est - exact) < 0.05 * abs(exact) + 1.0
 
 
+def _dense_spd(n, noise, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 1, generator=g, dtype=torch.float64) * 4
+    K = torch.exp(-0.5 * torch.cdist(x / 0.5, x / 0.5).pow(2))
+    return K, K + noise * torch.eye(n, dtype=torch.float64), g
+
+
+def test_pivoted_cholesky_factor_and_woodbury():
+    n, noise = 150, 1e-2
+    K, A, g = _dense_spd(n, noise)
+    pre = solvers.PivotedCholeskyPreconditioner(lambda V: K @ V, n, 1.0, noise, rank=25, device="cpu", dtype=torch.float64)
+    # a smooth kernel matrix is numerically low rank: 25 pivots leave a small residual, and it shrinks with the rank
+    err25 = float((K - pre.L @ pre.L.T).diagonal().sum())
+    pre10 = solvers.PivotedCholeskyPreconditioner(lambda V: K @ V, n, 1.0, noise, rank=10, device="cpu", dtype=torch.float64)
+    err10 = float((K - pre10.L @ pre10.L.T).diagonal().sum())
+    assert 0 <= err25 < err10 < float(K.diagonal().sum()) and err25 < 1e-3 * n
+    # full rank reproduces the matrix
+    full = solvers.PivotedCholeskyPreconditioner(lambda V: K @ V, n, 1.0, noise, rank=n, device="cpu", dtype=torch.float64)
+    assert float((K - full.L @ full.L.T).abs().max()) < 1e-6
+    # Woodbury solve and the determinant lemma against the dense P
+    Pd = pre.L @ pre.L.T + noise * torch.eye(n, dtype=torch.float64)
+    R = torch.randn(n, 3, generator=g, dtype=torch.float64)
+    assert torch.allclose(pre.solve(R), torch.linalg.solve(Pd, R), atol=1e-8, rtol=1e-6)
+    assert abs(float(pre.logdet()) - float(torch.logdet(Pd))) < 1e-6 * n
+    # samples have covariance P
+    S = pre.sample(20000, generator=g)
+    emp = S @ S.T / S.shape[1]
+    assert float((emp - Pd).abs().max()) < 0.05
+
+
+def test_preconditioned_cg_converges_faster_and_slq_matches_logdet():
+    n, noise = 150, 1e-2
+    K, A, g = _dense_spd(n, noise)
+    B = torch.randn(n, 4, generator=g, dtype=torch.float64)
+    exact = torch.linalg.solve(A, B)
+    X0, info0 = solvers.batched_cg(lambda V: A @ V, B, max_iter=2000, tol=1e-8, check_every=1)
+    pre = solvers.PivotedCholeskyPreconditioner(lambda V: K @ V, n, 1.0, noise, rank=25, device="cpu", dtype=torch.float64)
+    X1, info1 = solvers.batched_cg(lambda V: A @ V, B, max_iter=2000, tol=1e-8, check_every=1, precond=pre)
+    assert torch.allclose(X0, exact, atol=1e-5) and torch.allclose(X1, exact, atol=1e-5)
+    assert info1["iterations"] * 3 < info0["iterations"], (info1["iterations"], info0["iterations"])
+    # logdet A = logdet P + tr log(P^-1/2 A P^-1/2): the second term is small and its SLQ estimate has little
+    # variance, so a few probes from N(0, P) beat many Rademacher probes without the preconditioner
+    Z = pre.sample(16, generator=g)
+    _, info = solvers.batched_cg(lambda V: A @ V, Z, max_iter=2000, tol=1e-10, want_tridiag=True, precond=pre)
+    est = float(pre.logdet() + solvers.slq_logdet(info["tridiag"], n, weights=info["rz0"]))
+    assert abs(est - float(torch.logdet(A))) < 0.5, (est, float(torch.logdet(A)))
+
+
+def test_mll_with_preconditioner_matches_dense(cpu_method):
+    torch.manual_seed(0)
+    n = 60
+    x = torch.randn(n, 2)
+    y = torch.sin(x[:, 0]) + 0.1 * torch.randn(n)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1))
+    with torch.no_grad():
+        model.raw_noise.fill_(-3.0)               # small noise: the regime where the preconditioner matters
+    mll = solvers.marginal_log_likelihood(model, x, y, num_probes=n, cg_tol=1e-7, seed=1, pre_size=15)
+    mll.backward()
+    got = {k: p.grad.clone() for k, p in model.named_parameters()}
+    with torch.no_grad():
+        Kd = model.kernel(x, x).evaluate()
+        Kd = 0.5 * (Kd + Kd.T)
+    s = model.raw_outputscale.detach().clone().requires_grad_(True)
+    nz = model.raw_noise.detach().clone().requires_grad_(True)
+    mu = model.mean.detach().clone().requires_grad_(True)
+    Khat = torch.nn.functional.softplus(s) * Kd + (torch.nn.functional.softplus(nz) + model.min_noise) * torch.eye(n)
+    r = (y - mu).reshape(-1, 1)
+    dense = (-0.5 * (r * torch.linalg.solve(Khat, r)).sum() - 0.5 * torch.logdet(Khat) - 0.5 * n * np.log(2 * np.pi)) / n
+    dense.backward()
+    assert abs(float(mll) - float(dense)) < 0.05
+    assert abs(float(got["mean"]) - float(mu.grad)) < 2e-2 * (1 + abs(float(mu.grad)))
+    assert abs(float(got["raw_noise"]) - float(nz.grad)) < 5e-2 * (1 + abs(float(nz.grad)))
+    assert abs(float(got["raw_outputscale"]) - float(s.grad)) < 5e-2 * (1 + abs(float(s.grad)))
+    assert torch.isfinite(got["kernel.raw_lengthscale"]).all()
+
+
 def test_mll_gradient_matches_dense_autograd(cpu_method):
     """Surrogate gradient of the CG/SLQ MLL vs autograd through a dense evaluation of the same operator."""
     torch.manual_seed(0)
