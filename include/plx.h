@@ -186,6 +186,14 @@ int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref,
  */
 int plx_coldot(const float *d_a, const float *d_b, int64_t n, int vd, float *d_out, float *d_work, void *stream);
 int64_t plx_coldot_work_floats(int vd);
+/* Position gradient of one filter call, fused (replaces LatticeFilterGeneral.backward with a reference gradient,
+ * bilateral_kernel.py:113-123): `lat` is built on d_ref [n][d] with the DERIVATIVE taps; d_g (the incoming gradient)
+ * and d_src (the forward right-hand side) are [n][nrhs].  Writes d_grad_ref [n][d] and, unless NULL,
+ * d_grad_src [n][nrhs].  The 2*nrhs*(1+d)-column stacked matrix and its filtered image are never stored: the splat
+ * forms the stack from packed per-point records, slice and contraction are one kernel.  Column range 125..512
+ * and 2*nrhs + d <= 62 (PLX_ERR_INVALID otherwise: use the three-call form below), single-shard lattices only. */
+int plx_apply_backward(plx_lattice *lat, const float *d_g, const float *d_src, const float *d_ref, int nrhs,
+                       float *d_grad_ref, float *d_grad_src, void *stream);
 /* The two elementwise ends of the position gradient (bilateral_kernel.py:113-122), one pass each, row-major fp32:
  *   plx_backward_stack:    d_out[n][2L(1+d)] = [ g | g (x) x | src | src (x) x ]   (the matrix the filter is applied to)
  *   plx_backward_contract: d_grad_x[n][d] = -2 sum_l ( src x wg - src wgx + g x ws - g wsx ) from the filtered stack */

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "plx_filter": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _f32p, _i32, _vp, _vp]),
     "plx_coldot": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "plx_coldot_work_floats": (_i64, [_i32]),
+    "plx_apply_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "plx_backward_stack": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "plx_backward_contract": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "plx_cg_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),

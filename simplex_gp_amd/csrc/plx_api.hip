@@ -40,7 +40,7 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
     return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
             &L->sort_keys_in, &L->sort_keys_out, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->row_ptr,
-            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
+            &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
             &L->sortkey_in, &L->sortkey_out};
 }
 
@@ -273,6 +273,27 @@ int plx_apply(plx_lattice *L, const float *d_src, int vd, float *d_out, void *st
     int in_b = 0;
     PLX_TRY(blur_impl(L, L->val_a.as<float>(), L->val_b.as<float>(), vd, &in_b, s));
     return slice_impl(L, in_b ? L->val_b.as<float>() : L->val_a.as<float>(), vd, d_out, s);
+}
+
+int plx_apply_backward(plx_lattice *L, const float *d_g, const float *d_src, const float *d_ref, int nrhs,
+                       float *d_grad_ref, float *d_grad_src, void *stream)
+{
+    if (!L) { set_error("plx_apply_backward: NULL lattice"); return PLX_ERR_INVALID; }
+    if (!L->built) { set_error("plx_apply_backward: lattice not built"); return PLX_ERR_STATE; }
+    if (L->n_shards != 1 || L->partial_cover) {
+        set_error("plx_apply_backward: single-shard lattices only (a sharded caller needs the vertex all-reduce between splat and blur)");
+        return PLX_ERR_STATE;
+    }
+    if (!d_g || !d_src || !d_ref || !d_grad_ref) { set_error("plx_apply_backward: NULL argument"); return PLX_ERR_INVALID; }
+    const int nch = values_stride(2 * nrhs * (1 + L->d)) / 4;
+    if (nrhs < 1 || nch < 32 || nch > 128 || 2 * nrhs + L->d + 2 > 64) {
+        set_error("plx_apply_backward: nrhs = %d, d = %d (%d columns) is outside the fused kernels' range (125..512 "
+                  "columns, 2*nrhs + d <= 62); use plx_backward_stack + plx_apply + plx_backward_contract", nrhs, L->d,
+                  2 * nrhs * (1 + L->d));
+        return PLX_ERR_INVALID;
+    }
+    DeviceGuard g(L->device);
+    return backward_impl(L, d_g, d_src, d_ref, nrhs, d_grad_ref, d_grad_src, (hipStream_t)stream);
 }
 
 int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref, int64_t n, int d, int vd,

@@ -273,85 +273,182 @@ __global__ __launch_bounds__(kSplatBlock) void splat_scan_kernel(const int *__re
 
 // ----------------------------------------------------------------------------
 // splat for WIDE rows (nch >= 32 chunks, i.e. vd >= 125: the backward pass, py:113-119).  The scan kernel tiles the
-// columns, so with 50 chunks it would touch every gathered source row 17-25 times, 32-48 bytes at a time.  Here a
-// wave owns a vertex row and its lanes own the 16-byte chunks of the value row: every gathered source row is read
-// once, contiguously.  Work is still cut into the same kSplatChunk corner ranges, so rows that cross a range edge
-// leave head / tail partial sums for the same splat_fixup_kernel, and the order of additions is fixed.
-//   short rows (<= 64 corners inside the range): one wave per row;
-//   long rows: the four waves take every fourth corner, partial sums are added in wave order through LDS.
+// columns, so with 50 chunks it would touch every gathered source row 17-25 times, 32-48 bytes at a time.  Here the
+// lanes of a wave own the 16-byte chunks of the value row and the wave walks a range of corners: every gathered
+// source row is read once, contiguously (splat_wide_kernel below).
 
-template <int MAXCH>   // chunks a lane group can hold: nch <= 64 * MAXCH
+// Where the splatted rows come from.  RowSource: a row-major [n_own][nch] float4 matrix in lattice
+// order.  StackSource: the backward pass' stacked matrix [ g | g (x) x | s | s (x) x ] (py:113-118),
+// never stored -- every 16-byte chunk is formed from the point's packed record
+// rec[p] = [ g (L) | s (L) | x (d) | 0 | 1 | pad ]; a lane keeps, for each of its columns, the record
+// slots of its two factors (the 0 and 1 slots serve the padding and the un-multiplied columns).
+// stage() prepares a batch of up to 64 corners (lane e holds corner e's point), fetch() only issues
+// the loads of corner j (so that several corners are in flight together), value() turns what was
+// fetched into the 16-byte chunk.  Lanes beyond the row (chunk >= nch) fetch valid memory (the last
+// chunk / the 0 and 1 slots) and are never stored.
+struct RowSource {
+    const float4 *ssrc;
+    int nch;
+    struct Lane { uint32_t off; };
+    using Raw = float4;
+    __device__ __forceinline__ void init(Lane &ln, int chunk) const { ln.off = 16u * (uint32_t)min(chunk, nch - 1); }
+    __device__ __forceinline__ int lds_floats_per_corner() const { return 0; }
+    __device__ __forceinline__ void stage(float *, int, int, int) const {}
+    __device__ __forceinline__ Raw fetch(const Lane &ln, const float *, int, int pt) const
+    {
+        // wave-uniform row base (scalar registers) + 32-bit lane offset
+        const char *row = reinterpret_cast<const char *>(ssrc + (size_t)pt * nch);
+        return *reinterpret_cast<const float4 *>(row + ln.off);
+    }
+    static __device__ __forceinline__ float4 value(const Raw &r) { return r; }
+};
+
+// Eight 4-byte loads per corner with lane-dependent addresses cost the texture addresser 16 cycles
+// each (measured: 2.0 ms per splat at N = 1e6, d = 8, L = 11, the address unit saturated), so the
+// batch's records go through LDS first: coalesced 16-byte loads in, then eight conflict-free
+// ds_read_b32 per corner (a record spans distinct banks).
+struct StackSource {
+    const float *rec;
+    int recw, L, d;
+    struct Lane { uint32_t a[4], x[4]; };       // float offsets of the two factors of each column
+    struct Raw { float a[4], x[4]; };
+    __device__ __forceinline__ void init(Lane &ln, int chunk) const
+    {
+        const int half = L * (1 + d), zero = 2 * L + d, one = zero + 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * chunk + j;
+            int a, x;
+            if (c >= 2 * half) { a = zero; x = one; }
+            else {
+                const int base = c < half ? 0 : L, cc = c < half ? c : c - half;
+                if (cc < L) { a = base + cc; x = one; }
+                else { const int q = cc - L, l = q / d; a = base + l; x = 2 * L + (q - l * d); }
+            }
+            ln.a[j] = (uint32_t)a;
+            ln.x[j] = (uint32_t)x;
+        }
+    }
+    __device__ __forceinline__ int lds_floats_per_corner() const { return recw; }
+    __device__ __forceinline__ void stage(float *wl, int my_pt, int len, int lane) const
+    {
+        const int recw4 = recw / 4;
+        const float4 *rec4 = reinterpret_cast<const float4 *>(rec);
+        float4 *wl4 = reinterpret_cast<float4 *>(wl);
+        for (int t = lane; t < 64 * recw4; t += 64) {          // same trip count in every lane (shuffles inside)
+            const int e = t / recw4, c4 = t - e * recw4;
+            const int pt = __shfl(my_pt, e);
+            if (e < len) wl4[t] = rec4[(size_t)pt * recw4 + c4];
+        }
+    }
+    __device__ __forceinline__ Raw fetch(const Lane &ln, const float *wl, int j, int) const
+    {
+        const float *r = wl + j * recw;
+        Raw o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o.a[k] = r[ln.a[k]]; o.x[k] = r[ln.x[k]]; }
+        return o;
+    }
+    static __device__ __forceinline__ float4 value(const Raw &r)
+    {
+        return make_float4(r.a[0] * r.x[0], r.a[1] * r.x[1], r.a[2] * r.x[2], r.a[3] * r.x[3]);
+    }
+};
+
+constexpr int kWideChunk = 256;   // corners per wave of splat_wide_kernel
+
+// One wave per kWideChunk consecutive corners, lanes over the 16-byte chunks of a row.  The corners
+// are walked in CSR order: acc += w * row(point); a corner that closes its vertex row stores acc
+// and clears it.  The chain corner -> point -> source row would cost two dependent memory
+// latencies per corner (and a third per vertex row for its bounds), so (a) the lanes fetch 64
+// corners' (point, weight, vertex, closes-row) in four coalesced loads, one batch ahead, and
+// (b) the source rows of U corners are requested together before the first is used -- across
+// vertex-row boundaries, which only matter to the accumulation.  A row that enters the range
+// from the left leaves its sum in head_partial, one that leaves it to the right in
+// tail_partial, for splat_fixup_kernel; the order of additions is fixed.
+template <int MAXCH, class S>   // chunks a lane group can hold: nch <= 64 * MAXCH
 __global__ __launch_bounds__(kBlock) void splat_wide_kernel(const int *__restrict__ csr_pt,
                                                             const float *__restrict__ csr_w,
                                                             const int *__restrict__ csr_vid,
-                                                            const int *__restrict__ row_ptr,
-                                                            const float4 *__restrict__ ssrc, int nch, int nnz,
+                                                            const S src, int nch, int nnz,
                                                             float4 *__restrict__ values,
                                                             float4 *__restrict__ head_partial,
-                                                            float4 *__restrict__ tail_partial, int nchunks, int remap)
+                                                            float4 *__restrict__ tail_partial, int ntiles, int remap)
 {
-    __shared__ float4 part[kBlock / 64][64 * MAXCH];
-    const int c = tile_index(nchunks, remap);
-    if (c < 0) return;
+    constexpr int U = (MAXCH == 1 ? 8 : 4) / (sizeof(typename S::Raw) > 16 ? 2 : 1);   // corners in flight
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = c * kSplatChunk, k1 = min(k0 + kSplatChunk, nnz);
-    const int v_first = csr_vid[k0], v_last = csr_vid[k1 - 1];
-
-    auto emit = [&](int v, int ra, int rb, const float4 (&acc)[MAXCH]) {
-        const bool started_before = ra < k0, ends_after = rb > k1;
-        float4 *dst = (!started_before && !ends_after) ? values + (size_t)v * nch
-                      : (started_before ? head_partial : tail_partial) + (size_t)c * nch;
+    const int c = tile * (kBlock / 64) + wave;
+    const int k0 = c * kWideChunk, k1 = min(k0 + kWideChunk, nnz);
+    if (k0 >= nnz) return;
+    typename S::Lane ln[MAXCH];
 #pragma unroll
-        for (int q = 0; q < MAXCH; ++q)
+    for (int q = 0; q < MAXCH; ++q) src.init(ln[q], lane + 64 * q);
+    extern __shared__ float wide_lds[];                          // StackSource: [waves][64][recw] staged records
+    float *wl = wide_lds + (size_t)wave * 64 * src.lds_floats_per_corner();
+
+    float4 acc[MAXCH];
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) acc[q] = f4_zero();
+    bool from_left = csr_pt[k0] >= 0;      // the first corner continues a row that began before k0
+    bool open = false;                     // acc holds corners of a row that has not closed yet
+
+    auto store = [&](float4 *dst) {
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
             if (lane + 64 * q < nch) dst[lane + 64 * q] = acc[q];
+            acc[q] = f4_zero();
+        }
+    };
+    auto fetch = [&](int base, int &pt, float &w, int &vid, int &closes) {
+        const int e = base + lane;
+        pt = 0; w = 0.f; vid = 0; closes = 0;
+        if (e < k1) {
+            pt = csr_pt[e] & 0x7FFFFFFF;
+            w = csr_w[e];
+            vid = csr_vid[e];
+            closes = (e + 1 >= nnz) || (csr_pt[e + 1] < 0);
+        }
     };
 
-    // phase 1: short rows, one wave each
-    for (int v = v_first + wave; v <= v_last; v += kBlock / 64) {
-        const int ra = row_ptr[v], rb = row_ptr[v + 1];
-        const int a = max(ra, k0), b = min(rb, k1);
-        if (b <= a || b - a > 64) continue;
-        float4 acc[MAXCH];
+    int n_pt, n_vid, n_closes;
+    float n_w;
+    fetch(k0, n_pt, n_w, n_vid, n_closes);
+    for (int base = k0; base < k1; base += 64) {
+        const int my_pt = n_pt, my_vid = n_vid, my_closes = n_closes;
+        const float my_w = n_w;
+        if (base + 64 < k1) fetch(base + 64, n_pt, n_w, n_vid, n_closes);
+        const int len = min(64, k1 - base);
+        src.stage(wl, my_pt, len, lane);
+        for (int j = 0; j < len; j += U) {
+            typename S::Raw r[U][MAXCH];
 #pragma unroll
-        for (int q = 0; q < MAXCH; ++q) acc[q] = f4_zero();
-        for (int k = a; k < b; ++k) {
-            const int pt = csr_pt[k] & 0x7FFFFFFF;
-            const float w = csr_w[k];
+            for (int u = 0; u < U; ++u) {
+                // wave-uniform point index in a scalar register: the row address is scalar base + lane offset
+                const int jj = min(j + u, len - 1);                                      // past the end: a harmless re-read
+                const int pt = __builtin_amdgcn_readlane(my_pt, jj);
 #pragma unroll
-            for (int q = 0; q < MAXCH; ++q)
-                if (lane + 64 * q < nch) acc[q] = f4_add(acc[q], f4_scale(w, ssrc[(size_t)pt * nch + lane + 64 * q]));
-        }
-        emit(v, ra, rb, acc);
-    }
-    // phase 2: long rows, all four waves on one row at a time (at most kSplatChunk / 65 of them per range)
-    for (int v = v_first; v <= v_last; ++v) {
-        const int ra = row_ptr[v], rb = row_ptr[v + 1];
-        const int a = max(ra, k0), b = min(rb, k1);
-        if (b - a <= 64) continue;
-        float4 acc[MAXCH];
-#pragma unroll
-        for (int q = 0; q < MAXCH; ++q) acc[q] = f4_zero();
-        for (int k = a + wave; k < b; k += kBlock / 64) {
-            const int pt = csr_pt[k] & 0x7FFFFFFF;
-            const float w = csr_w[k];
-#pragma unroll
-            for (int q = 0; q < MAXCH; ++q)
-                if (lane + 64 * q < nch) acc[q] = f4_add(acc[q], f4_scale(w, ssrc[(size_t)pt * nch + lane + 64 * q]));
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < MAXCH; ++q) part[wave][lane + 64 * q] = acc[q];
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int q = 0; q < MAXCH; ++q) {
-                float4 t = part[0][lane + 64 * q];
-                for (int wv = 1; wv < kBlock / 64; ++wv) t = f4_add(t, part[wv][lane + 64 * q]);
-                acc[q] = t;
+                for (int q = 0; q < MAXCH; ++q) r[u][q] = src.fetch(ln[q], wl, jj, pt);
             }
-            emit(v, ra, rb, acc);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j + u < len) {
+                    const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j + u));
+#pragma unroll
+                    for (int q = 0; q < MAXCH; ++q) acc[q] = f4_add(acc[q], f4_scale(w, S::value(r[u][q])));
+                    open = true;
+                    if (__builtin_amdgcn_readlane(my_closes, j + u)) {
+                        store(from_left ? head_partial + (size_t)c * nch
+                                        : values + (size_t)__builtin_amdgcn_readlane(my_vid, j + u) * nch);
+                        from_left = false;
+                        open = false;
+                    }
+                }
+            }
         }
     }
+    if (open) store((from_left ? head_partial : tail_partial) + (size_t)c * nch);
 }
 
 __device__ __forceinline__ bool chunk_has_head(const int *__restrict__ csr_pt, const int *__restrict__ csr_vid,
@@ -364,7 +461,7 @@ __device__ __forceinline__ bool chunk_has_head(const int *__restrict__ csr_pt, c
 // partials of the chunks it covers, in chunk order.  One thread per (chunk, float).
 __global__ __launch_bounds__(kBlock) void splat_fixup_kernel(const int *__restrict__ csr_pt,
                                                              const int *__restrict__ csr_vid, int nchunks,
-                                                             int nnz, int vdp,
+                                                             int chunk, int nnz, int vdp,
                                                              const float *__restrict__ head_partial,
                                                              const float *__restrict__ tail_partial,
                                                              float *__restrict__ values)
@@ -372,12 +469,12 @@ __global__ __launch_bounds__(kBlock) void splat_fixup_kernel(const int *__restri
     const int it = blockIdx.x * kBlock + threadIdx.x;
     if (it >= nchunks * vdp) return;
     const int c = it / vdp, col = it - c * vdp;
-    const int k0 = c * kSplatChunk, k1 = min(k0 + kSplatChunk, nnz);
+    const int k0 = c * chunk, k1 = min(k0 + chunk, nnz);
     if (k1 >= nnz || csr_pt[k1] < 0 || !chunk_has_head(csr_pt, csr_vid, k0, k1)) return;
     float total = tail_partial[(size_t)c * vdp + col];
     for (int c2 = c + 1; c2 < nchunks; ++c2) {
         total += head_partial[(size_t)c2 * vdp + col];
-        const int a = c2 * kSplatChunk, b = min(a + kSplatChunk, nnz);
+        const int a = c2 * chunk, b = min(a + chunk, nnz);
         if (b >= nnz || csr_pt[b] < 0 || chunk_has_head(csr_pt, csr_vid, a, b)) break;
     }
     values[(size_t)csr_vid[k1 - 1] * vdp + col] = total;
@@ -423,14 +520,19 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         const float4 *s4 = reinterpret_cast<const float4 *>(ss);
         float4 *v4 = reinterpret_cast<float4 *>(d_values), *h4 = reinterpret_cast<float4 *>(hp), *t4 = reinterpret_cast<float4 *>(tp);
         if (nch_total >= 32 && nch_total <= 128 && g_splat_wide) {   // measured: 16 chunks 8 % slower, 50 chunks 1.8x faster
-            const int grid = tile_grid(nchunks, g_xcd_remap);
-            const int *rp = L->row_ptr.as<int>();
+            const int nwide = ceil_div(nnz, kWideChunk), nt = ceil_div(nwide, kBlock / 64);
+            PLX_TRY(ensure(L->head_partial, (size_t)nwide * vdp * 4));
+            PLX_TRY(ensure(L->tail_partial, (size_t)nwide * vdp * 4));
+            h4 = reinterpret_cast<float4 *>(L->head_partial.as<float>());
+            t4 = reinterpret_cast<float4 *>(L->tail_partial.as<float>());
+            const int grid = tile_grid(nt, g_xcd_remap);
+            const RowSource rows{s4, nch_total};
             if (nch_total <= 64)
-                splat_wide_kernel<1><<<grid, kBlock, 0, stream>>>(pt, w, vid, rp, s4, nch_total, nnz, v4, h4, t4, nchunks, g_xcd_remap);
+                splat_wide_kernel<1, RowSource><<<grid, kBlock, 0, stream>>>(pt, w, vid, rows, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap);
             else
-                splat_wide_kernel<2><<<grid, kBlock, 0, stream>>>(pt, w, vid, rp, s4, nch_total, nnz, v4, h4, t4, nchunks, g_xcd_remap);
-            splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, nnz, vdp,
-                                                                                                 hp, tp, d_values);
+                splat_wide_kernel<2, RowSource><<<grid, kBlock, 0, stream>>>(pt, w, vid, rows, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap);
+            splat_fixup_kernel<<<ceil_div((int64_t)nwide * vdp, kBlock), kBlock, 0, stream>>>(
+                pt, vid, nwide, kWideChunk, nnz, vdp, L->head_partial.as<float>(), L->tail_partial.as<float>(), d_values);
             tmark(L, stream);
             PLX_HIP_TRY(hipGetLastError());
             return PLX_OK;
@@ -444,8 +546,8 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         default: splat_scan_kernel<float4, 3><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
         }
     }
-    splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, nnz, vdp, hp, tp,
-                                                                                         d_values);
+    splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, kSplatChunk, nnz, vdp,
+                                                                                         hp, tp, d_values);
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -830,6 +932,160 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
             L->slice_denom, d_out, nt, g_xcd_remap);
     }
     tmark(L, stream);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// fused position gradient (py:113-123): splat of the stacked matrix straight from
+// the packed records, the usual blur, then slice and contraction in one kernel --
+// neither the stacked matrix nor its filtered image ever reach memory.
+
+// rec[i] = [ g | s | x | 0 | 1 | pad ] of the i-th point in lattice order
+__global__ __launch_bounds__(kBlock) void backward_pack_kernel(const float *__restrict__ g, const float *__restrict__ s,
+                                                               const float *__restrict__ x,
+                                                               const uint32_t *__restrict__ perm, int own_begin,
+                                                               int n_own, int L, int d, int recw, float *__restrict__ rec)
+{
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= (int64_t)n_own * recw) return;
+    const int i = (int)(item / recw), c = (int)(item - (int64_t)i * recw);
+    const size_t row = perm ? (size_t)((int)perm[own_begin + i] - own_begin) : (size_t)i;
+    float v = 0.f;
+    if (c < L) v = g[row * L + c];
+    else if (c < 2 * L) v = s[row * L + (c - L)];
+    else if (c < 2 * L + d) v = x[row * d + (c - 2 * L)];
+    else if (c == 2 * L + d + 1) v = 1.f;
+    rec[item] = v;
+}
+
+// One wave per point: the lanes slice the point's 2L(1+d) filtered columns (same arithmetic as
+// slice_vec_kernel), park them in LDS, then lane k < d forms
+//   grad_x[k] = -2 sum_l ( s_l x_k wg_l - s_l wgx_{l,k} + g_l x_k ws_l - g_l wsx_{l,k} )      (py:122)
+// and lane l < L stores grad_src[l] = wg_l (py:123).
+template <int MAXCH>
+__global__ __launch_bounds__(kBlock) void slice_contract_kernel(const int *__restrict__ evid, const float *__restrict__ ew,
+                                                                const uint32_t *__restrict__ perm, int n, int own_begin,
+                                                                int n_own, int d1, const float4 *__restrict__ values,
+                                                                int nch, const float *__restrict__ rec, int recw, int L,
+                                                                int d, float denom, float *__restrict__ grad_x,
+                                                                float *__restrict__ grad_src, int ntiles, int remap)
+{
+    __shared__ float4 f4s[kBlock / 64][64 * MAXCH];
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = tile * (kBlock / 64) + wave;
+    if (pl >= n_own) return;                       // whole waves leave together; no workgroup barrier below
+    const int p = own_begin + pl;
+    float4 acc[MAXCH];
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) acc[q] = f4_zero();
+    int my_v = 0;
+    float my_w = 0.f;
+    if (lane < d1) { my_v = evid[(size_t)lane * n + p]; my_w = ew[(size_t)lane * n + p]; }   // d1 <= 33 < 64
+    int r = 0;
+    for (; r + 3 <= d1; r += 3) {
+        float4 gq[3][MAXCH];
+        float w[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int v = __shfl(my_v, r + u);
+            w[u] = __shfl(my_w, r + u);
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q)
+                gq[u][q] = (lane + 64 * q < nch) ? values[(size_t)v * nch + lane + 64 * q] : f4_zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q) {
+                acc[q].x += w[u] * gq[u][q].x / denom; acc[q].y += w[u] * gq[u][q].y / denom;
+                acc[q].z += w[u] * gq[u][q].z / denom; acc[q].w += w[u] * gq[u][q].w / denom;
+            }
+    }
+    for (; r < d1; ++r) {
+        const int v = __shfl(my_v, r);
+        const float w = __shfl(my_w, r);
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const int ch = lane + 64 * q;
+            if (ch < nch) {
+                const float4 gq = values[(size_t)v * nch + ch];
+                acc[q].x += w * gq.x / denom; acc[q].y += w * gq.y / denom;
+                acc[q].z += w * gq.z / denom; acc[q].w += w * gq.w / denom;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) f4s[wave][lane + 64 * q] = acc[q];
+    __builtin_amdgcn_wave_barrier();               // the LDS row is private to this wave
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the ds_writes above have landed
+    const float *f = reinterpret_cast<const float *>(f4s[wave]);
+    const float *rp = rec + (size_t)pl * recw;
+    const size_t row = perm ? (size_t)((int)perm[p] - own_begin) : (size_t)pl;
+    const int half = L * (1 + d);
+    if (lane < d) {
+        const float xk = rp[2 * L + lane];
+        float a = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const float sv = rp[L + l], gv = rp[l];
+            a += sv * xk * f[l] - sv * f[L + l * d + lane] + gv * xk * f[half + l] - gv * f[half + L + l * d + lane];
+        }
+        grad_x[row * d + lane] = -2.0f * a;
+    }
+    if (grad_src)
+        for (int l = lane; l < L; l += 64) grad_src[row * L + l] = f[l];
+}
+
+int backward_impl(plx_lattice *lat, const float *d_g, const float *d_src, const float *d_x, int L, float *d_grad_x,
+                  float *d_grad_src, hipStream_t stream)
+{
+    const int d = lat->d, W = 2 * L * (1 + d), vdp = values_stride(W), nch = vdp / 4;
+    const int n_own = (int)(lat->own_end - lat->own_begin);
+    const int recw = (2 * L + d + 2 + 3) & ~3;
+    PLX_TRY(ensure(lat->rec, (size_t)n_own * recw * 4));
+    PLX_TRY(ensure(lat->val_a, (size_t)lat->m * vdp * 4));
+    PLX_TRY(ensure(lat->val_b, (size_t)lat->m * vdp * 4));
+    const int nnz = (int)lat->nnz, nwide = ceil_div(nnz, kWideChunk), nwt = ceil_div(nwide, kBlock / 64);
+    PLX_TRY(ensure(lat->head_partial, (size_t)nwide * vdp * 4));
+    PLX_TRY(ensure(lat->tail_partial, (size_t)nwide * vdp * 4));
+    const uint32_t *perm = lat->lattice_rows ? nullptr : lat->perm.as<uint32_t>();
+    float *rec = lat->rec.as<float>();
+    lat->tev_n = 0;
+    tmark(lat, stream);
+    backward_pack_kernel<<<ceil_div((int64_t)n_own * recw, kBlock), kBlock, 0, stream>>>(
+        d_g, d_src, d_x, perm, (int)lat->own_begin, n_own, L, d, recw, rec);
+    // splat
+    float *va = lat->val_a.as<float>(), *vb = lat->val_b.as<float>();
+    float4 *v4 = reinterpret_cast<float4 *>(va);
+    float4 *h4 = reinterpret_cast<float4 *>(lat->head_partial.as<float>()), *t4 = reinterpret_cast<float4 *>(lat->tail_partial.as<float>());
+    const int *pt = lat->csr_pt.as<int>(), *vid = lat->sort_keys_out.as<int>();
+    const StackSource stack{rec, recw, L, d};
+    const size_t wide_lds = (size_t)(kBlock / 64) * 64 * recw * 4;   // <= 64 KB: plx_apply_backward bounds recw
+    const int grid = tile_grid(nwt, g_xcd_remap);
+    if (nch <= 64)
+        splat_wide_kernel<1, StackSource><<<grid, kBlock, wide_lds, stream>>>(pt, lat->csr_w.as<float>(), vid, stack, nch, nnz, v4, h4, t4, nwt, g_xcd_remap);
+    else
+        splat_wide_kernel<2, StackSource><<<grid, kBlock, wide_lds, stream>>>(pt, lat->csr_w.as<float>(), vid, stack, nch, nnz, v4, h4, t4, nwt, g_xcd_remap);
+    splat_fixup_kernel<<<ceil_div((int64_t)nwide * vdp, kBlock), kBlock, 0, stream>>>(
+        pt, vid, nwide, kWideChunk, nnz, vdp, lat->head_partial.as<float>(), lat->tail_partial.as<float>(), va);
+    tmark(lat, stream);
+    PLX_HIP_TRY(hipGetLastError());
+    int in_b = 0;
+    PLX_TRY(blur_impl(lat, va, vb, W, &in_b, stream));
+    const float4 *res = reinterpret_cast<const float4 *>(in_b ? vb : va);
+    const int nt = ceil_div(n_own, kBlock / 64);
+    const int sgrid = tile_grid(nt, g_xcd_remap);
+    if (nch <= 64)
+        slice_contract_kernel<1><<<sgrid, kBlock, 0, stream>>>(lat->evid.as<int>(), lat->ew.as<float>(), perm, (int)lat->n,
+                                                              (int)lat->own_begin, n_own, d + 1, res, nch, rec, recw, L, d,
+                                                              lat->slice_denom, d_grad_x, d_grad_src, nt, g_xcd_remap);
+    else
+        slice_contract_kernel<2><<<sgrid, kBlock, 0, stream>>>(lat->evid.as<int>(), lat->ew.as<float>(), perm, (int)lat->n,
+                                                              (int)lat->own_begin, n_own, d + 1, res, nch, rec, recw, L, d,
+                                                              lat->slice_denom, d_grad_x, d_grad_src, nt, g_xcd_remap);
+    tmark(lat, stream);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }

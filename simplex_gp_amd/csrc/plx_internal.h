@@ -106,6 +106,7 @@ struct plx_lattice {
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
     plx::DevBuf val_a, val_b;                 // float [m][vdp]   (vdp = value row stride, plx_values_stride)
     plx::DevBuf ssrc;                         // float [n_own][vdp] right-hand side in lattice order
+    plx::DevBuf rec;                          // float [n_own][2L+d+2 rounded up to 4] packed (g, src, x) records (backward)
 
     int32_t *h_pinned = nullptr;   // pinned host staging for {m, err}
     hipEvent_t ev[8] = {};
@@ -137,6 +138,8 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
 int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream);
+int backward_impl(plx_lattice *L, const float *d_g, const float *d_src, const float *d_x, int nrhs, float *d_grad_x,
+                  float *d_grad_src, hipStream_t stream);
 
 // record the next apply-timing event (no-op unless timing is on)
 inline void tmark(plx_lattice *L, hipStream_t stream)

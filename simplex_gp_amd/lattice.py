@@ -260,6 +260,30 @@ class Lattice:
         nv.check(rc, "plx_apply")
         return out
 
+    @staticmethod
+    def backward_fusable(nrhs, d):
+        """True when plx_apply_backward covers this shape: 125..512 columns and 2*nrhs + d <= 62."""
+        return 32 <= (2 * nrhs * (1 + d) + 3) // 4 <= 128 and 2 * nrhs + d <= 62
+
+    def apply_backward(self, grad_out, src, ref, want_grad_src=True):
+        """Position gradient of out = K(ref) src for a lattice built on `ref` with the DERIVATIVE taps
+        (bilateral_kernel.py:113-123), fused: returns (grad_ref [n, d], grad_src [n, nrhs] or None)."""
+        g = self._src(grad_out, self.n_owned)
+        src = self._src(src, self.n_owned)
+        ref = self._src(ref, self.n_owned)
+        if g.shape != src.shape or ref.shape[1] != self.d:
+            raise ValueError(f"Incompatible shapes {tuple(g.shape)}, {tuple(src.shape)}, {tuple(ref.shape)}")
+        grad_ref = torch.empty_like(ref)
+        grad_src = torch.empty_like(src) if want_grad_src else None
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_apply_backward(self._h, ctypes.c_void_p(g.data_ptr()), ctypes.c_void_p(src.data_ptr()),
+                                             ctypes.c_void_p(ref.data_ptr()), src.shape[1],
+                                             ctypes.c_void_p(grad_ref.data_ptr()),
+                                             ctypes.c_void_p(grad_src.data_ptr()) if want_grad_src else None,
+                                             _stream_ptr(self.device))
+        nv.check(rc, "plx_apply_backward")
+        return grad_ref, grad_src
+
     # -- introspection (parity tests) --------------------------------------
     def export(self, which):
         L = nv.lib()

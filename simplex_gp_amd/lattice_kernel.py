@@ -94,6 +94,7 @@ class LatticeFilterGeneral(Function):
     """
 
     method = None
+    fused_backward = True      # False: position gradient through plx_backward_stack / filter / plx_backward_contract
 
     @staticmethod
     def _filter():
@@ -122,7 +123,13 @@ class LatticeFilterGeneral(Function):
             if ctx.needs_input_grad[0] and not ctx.needs_input_grad[1]:
                 # K is treated as symmetric (py:110-111)
                 grad_source = filt(g.contiguous(), ref.contiguous(), ctx.coeffs)
-            if ctx.needs_input_grad[1] and LatticeFilterGeneral.method is None and g.is_cuda and g.dim() == 2:
+            native = LatticeFilterGeneral.method is None and g.is_cuda and g.dim() == 2
+            if ctx.needs_input_grad[1] and native and LatticeFilterGeneral.fused_backward and Lattice.backward_fusable(L, d):
+                # the whole of py:113-123 in one native call: the stacked matrix is never stored (plx_apply_backward)
+                rc_ = ref if ref.is_contiguous() else ref.contiguous()
+                lat = _cache.get(rc_, ctx.deriv_coeffs)
+                grad_reference, grad_source = lat.apply_backward(g, src, rc_, want_grad_src=ctx.needs_input_grad[0])
+            elif ctx.needs_input_grad[1] and native:
                 # same computation, the stack and the contraction each as one native pass (plx_backward_*)
                 import ctypes
                 from . import _native as nv
