@@ -39,6 +39,7 @@
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
+int g_order_zcurve = 1;  // 1: points ordered along the Z-curve of their rounded lattice coordinates; 0: lexicographically
 int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only and mirrors the hits
                               // (fine regime 7.2 -> 4.9 ms; an occupancy bitmap on top did not pay)
 int g_insert_dedupe = 1;      // wave-level skip of repeated keys in the hashed insert (0.38 -> 0.32 ms at m = 4e5)
@@ -152,6 +153,7 @@ __device__ __forceinline__ void elevate(const float (&pos)[D], const ScaleArgs &
 
 struct OrderArgs {
     int n_shards, bits, ncoord;      // ncoord = min(d+1, 16) leading coordinates are used
+    int zcurve;                      // g_order_zcurve
     long long base, extra;           // shard layout: first `extra` shards have base+1 rows
 };
 
@@ -173,15 +175,32 @@ __global__ __launch_bounds__(kBlock) void sortkey_kernel(const float *__restrict
         : (unsigned long long)((p < split) ? p / (oa.base + 1) : oa.extra + (p - split) / (oa.base > 0 ? oa.base : 1));
     unsigned long long key = shard;
     const int half = 1 << (oa.bits - 1), top = (1 << oa.bits) - 1;
+    int q[D1];
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
-        if (i < oa.ncoord) {
-            float c = rintf(el[i] * (1.0f / (float)D1));
-            c = fminf(fmaxf(c, -1.0e6f), 1.0e6f);            // NaN -> -1e6 (fmaxf), rejected later by embed
-            int q = (int)c + half;
-            q = q < 0 ? 0 : (q > top ? top : q);
-            key = (key << oa.bits) | (unsigned long long)q;
-        }
+        float c = rintf(el[i] * (1.0f / (float)D1));
+        c = fminf(fmaxf(c, -1.0e6f), 1.0e6f);                // NaN -> -1e6 (fmaxf), rejected later by embed
+        q[i] = (int)c;
+    }
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+        const int v = q[i] + half;
+        q[i] = v < 0 ? 0 : (v > top ? top : v);
+    }
+    if (oa.zcurve) {
+        // Z-order: bit b of every coordinate before bit b-1 of any.  Every blur axis changes all d+1
+        // coordinates, so under the lexicographic order each neighbour is about a slab of the leading
+        // coordinate away (median 13k-320k vertex ids at N = 1e6, d = 8, l = 0.69); along the Z-curve
+        // the medians are 6k-16k and the medium-regime blur is 3-5 % faster (tools/ab_order.py).
+        // Ordering by the blur-axis coordinates q_i - q_d instead was measured too: no gain.
+        for (int b = oa.bits - 1; b >= 0; --b)
+#pragma unroll
+            for (int i = 0; i < D1; ++i)
+                if (i < oa.ncoord) key = (key << 1) | (unsigned long long)((q[i] >> b) & 1);
+    } else {
+#pragma unroll
+        for (int i = 0; i < D1; ++i)
+            if (i < oa.ncoord) key = (key << oa.bits) | (unsigned long long)q[i];
     }
     keys[p] = key;
     iota[p] = (uint32_t)p;
@@ -675,6 +694,7 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     // ---- point order
     OrderArgs oa;
     oa.n_shards = L->n_shards;
+    oa.zcurve = g_order_zcurve;
     oa.ncoord = D1 < 16 ? D1 : 16;
     int shard_bits = 0;
     while ((1 << shard_bits) < L->n_shards) ++shard_bits;
