@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""A/B of the narrow multi-column splat: lane-group streaming kernel (plx_tune splat_group=1) vs segmented scan (0)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import simplex_gp_amd as plx
+from tools.ab_apply import timeit, RBF1, tune
+n, d = 1_000_000, 8
+g = torch.Generator().manual_seed(1234)
+x = torch.randn(n, d, generator=g)
+for ell in (1.0, 0.6931):
+    lat = plx.Lattice().build((x / ell).contiguous().cuda(), RBF1)
+    for vd in (2, 4, 11, 32):
+        v = torch.randn(n, vd, generator=g).cuda()
+        vals = lat.new_values(vd)
+        base = None
+        for mode in (0, 1):
+            tune("splat_group", mode)
+            ts = min(timeit(lambda: lat.splat(v, vals), iters=5) for _ in range(3))
+            res = lat.splat(v, vals).clone()
+            base = res if base is None else base
+            err = ((res - base).norm() / base.norm()).item()
+            print(f"ell={ell} m={lat.m} vd={vd:3d} splat_group={mode}: splat {ts:8.1f} us   rel diff vs scan {err:.1e}", flush=True)
+        tune("splat_group", 1)
+        del v, vals
+    lat.close()
