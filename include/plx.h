@@ -201,6 +201,21 @@ int plx_backward_stack(const float *d_g, const float *d_src, const float *d_x, i
                        float *d_out, void *stream);
 int plx_backward_contract(const float *d_g, const float *d_src, const float *d_x, const float *d_filtered,
                           int64_t n, int L, int d, float *d_grad_x, void *stream);
+/* out = a * (K src) + b * src with (a, b) = d_scale_shift[0..1] read on the device: the (s K + sigma^2 I) v of a GP
+ * solve in one call (the two scalars live in device memory so that no host synchronisation is needed to pass
+ * hyper-parameters that are device tensors).  d_out must not alias d_src. */
+int plx_apply_affine(plx_lattice *lat, const float *d_src, int vd, float *d_out, const float *d_scale_shift, void *stream);
+/* One batched-CG iteration's vector work with the coefficients formed on the device (all small arrays are float [vd],
+ * `active` holds 1.0 / 0.0):
+ *   plx_cg_step_update:    alpha = active ? rs / max(pAp, tiny) : 0;  X += alpha P;  R -= alpha AP;  rs_new = |R|^2
+ *   plx_cg_step_direction: beta = active ? rs_new / max(rs, tiny) : 0;  P = R + beta P;
+ *                          active_out = active and sqrt(rs_new) / b_norm > tol     (active_out != active) */
+int plx_cg_step_update(float *d_x, float *d_r, const float *d_p, const float *d_ap, const float *d_rs, const float *d_pap,
+                       const float *d_active, int64_t n, int vd, float *d_rs_new, float *d_alpha, float *d_work,
+                       void *stream);
+int plx_cg_step_direction(float *d_p, const float *d_r, const float *d_rs_new, const float *d_rs, const float *d_active,
+                          const float *d_b_norm, float tol, int64_t n, int vd, float *d_beta, float *d_active_out,
+                          void *stream);
 /* The two vector updates of a batched CG iteration, one pass each (row-major [n][vd], per-column scalars on the
  * device):  plx_cg_update: X += P*alpha, R -= AP*alpha, d_rs_new[c] = sum_r R[r][c]^2 (d_work as for plx_coldot);
  *           plx_cg_direction: P = R + P*beta. */

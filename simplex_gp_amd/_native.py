@@ -56,6 +56,9 @@ _SIGNATURES = {
     "plx_apply_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "plx_backward_stack": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "plx_backward_contract": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "plx_apply_affine": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "plx_cg_step_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "plx_cg_step_direction": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_direction": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "plx_export": (_i32, [_vp, _i32, _vp, _i64, _vp]),

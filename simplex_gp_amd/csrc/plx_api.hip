@@ -260,9 +260,25 @@ int plx_slice(plx_lattice *L, const float *d_values, int vd, float *d_out, void 
     return slice_impl(L, d_values, vd, d_out, (hipStream_t)stream);
 }
 
+static int apply_common(plx_lattice *L, const float *d_src, int vd, float *d_out, const float *d_affine, void *stream,
+                        const char *who);
+
+int plx_apply_affine(plx_lattice *L, const float *d_src, int vd, float *d_out, const float *d_scale_shift, void *stream)
+{
+    if (!d_scale_shift) { set_error("plx_apply_affine: NULL scale/shift"); return PLX_ERR_INVALID; }
+    if (d_src == d_out) { set_error("plx_apply_affine: d_out must not alias d_src (rows are written in a different order)"); return PLX_ERR_INVALID; }
+    return apply_common(L, d_src, vd, d_out, d_scale_shift, stream, "plx_apply_affine");
+}
+
 int plx_apply(plx_lattice *L, const float *d_src, int vd, float *d_out, void *stream)
 {
-    PLX_TRY(check_apply(L, d_src, d_out, vd, "plx_apply"));
+    return apply_common(L, d_src, vd, d_out, nullptr, stream, "plx_apply");
+}
+
+static int apply_common(plx_lattice *L, const float *d_src, int vd, float *d_out, const float *d_affine, void *stream,
+                        const char *who)
+{
+    PLX_TRY(check_apply(L, d_src, d_out, vd, who));
     DeviceGuard g(L->device);
     PLX_TRY(ensure(L->val_a, (size_t)L->m * values_stride(vd) * 4));
     PLX_TRY(ensure(L->val_b, (size_t)L->m * values_stride(vd) * 4));
@@ -272,7 +288,7 @@ int plx_apply(plx_lattice *L, const float *d_src, int vd, float *d_out, void *st
     PLX_TRY(splat_impl(L, d_src, vd, L->val_a.as<float>(), s));
     int in_b = 0;
     PLX_TRY(blur_impl(L, L->val_a.as<float>(), L->val_b.as<float>(), vd, &in_b, s));
-    return slice_impl(L, in_b ? L->val_b.as<float>() : L->val_a.as<float>(), vd, d_out, s);
+    return slice_impl(L, in_b ? L->val_b.as<float>() : L->val_a.as<float>(), vd, d_out, s, d_affine, d_src);
 }
 
 int plx_apply_backward(plx_lattice *L, const float *d_g, const float *d_src, const float *d_ref, int nrhs,

@@ -1064,7 +1064,8 @@ __global__ __launch_bounds__(kBlock) void slice_v1_kernel(const int *__restrict_
                                                           const float *__restrict__ ew,
                                                           const uint32_t *__restrict__ perm, int n, int own_begin,
                                                           int n_own, const float *__restrict__ values, float denom,
-                                                          float *__restrict__ out, int ntiles, int remap)
+                                                          float *__restrict__ out, int ntiles, int remap,
+                                                          const float *__restrict__ affine, const float *__restrict__ src)
 {
     const int tile = tile_index(ntiles, remap);
     if (tile < 0) return;
@@ -1084,6 +1085,7 @@ __global__ __launch_bounds__(kBlock) void slice_v1_kernel(const int *__restrict_
     float acc = 0.f;
 #pragma unroll
     for (int r = 0; r < D1; ++r) acc += w[r] * g[r] / denom;
+    if (affine) acc = affine[0] * acc + affine[1] * src[row];      // out = a K src + b src (plx_apply_affine)
     out[row] = acc;
 }
 
@@ -1093,7 +1095,8 @@ __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict
                                                            const uint32_t *__restrict__ perm, int n, int own_begin,
                                                            int n_own, int d1, const float4 *__restrict__ values,
                                                            int nch, int vd, float denom, float *__restrict__ out,
-                                                           int ntiles, int remap)
+                                                           int ntiles, int remap, const float *__restrict__ affine,
+                                                           const float *__restrict__ src)
 {
     const int tile = tile_index(ntiles, remap);
     if (tile < 0) return;
@@ -1111,6 +1114,14 @@ __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict
     const size_t row = perm ? (size_t)((int)perm[p] - own_begin) : (size_t)pl;
     float *o = out + row * vd + 4 * ch;
     const int left = vd - 4 * ch;
+    if (affine) {
+        const float a = affine[0], b = affine[1];
+        const float *sp = src + row * vd + 4 * ch;
+        acc.x = a * acc.x + b * sp[0];
+        if (left > 1) acc.y = a * acc.y + b * sp[1];
+        if (left > 2) acc.z = a * acc.z + b * sp[2];
+        if (left > 3) acc.w = a * acc.w + b * sp[3];
+    }
     if (left >= 4 && (vd & 3) == 0) {
         *reinterpret_cast<float4 *>(o) = acc;
     } else {
@@ -1121,7 +1132,8 @@ __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict
     }
 }
 
-int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream)
+int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream, const float *d_affine,
+               const float *d_src)
 {
     const int n_own = (int)(L->own_end - L->own_begin);
     if (n_own == 0) return PLX_OK;
@@ -1134,7 +1146,7 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
         const int grid = tile_grid(nt, g_xcd_remap);
         switch (L->d + 1) {
 #define PLX_CASE(D1) \
-    case D1: slice_v1_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, d_values, L->slice_denom, d_out, nt, g_xcd_remap); break;
+    case D1: slice_v1_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, d_values, L->slice_denom, d_out, nt, g_xcd_remap, d_affine, d_src); break;
             PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9)
             PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17)
             PLX_CASE(18) PLX_CASE(19) PLX_CASE(20) PLX_CASE(21) PLX_CASE(22) PLX_CASE(23) PLX_CASE(24) PLX_CASE(25)
@@ -1146,7 +1158,7 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
         const int nt = ceil_div((int64_t)n_own * nch, kBlock);
         slice_vec_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
             evid, ew, perm, n, ob, n_own, L->d + 1, reinterpret_cast<const float4 *>(d_values), nch, vd,
-            L->slice_denom, d_out, nt, g_xcd_remap);
+            L->slice_denom, d_out, nt, g_xcd_remap, d_affine, d_src);
     }
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());

@@ -137,7 +137,8 @@ int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream);
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
-int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream);
+int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream,
+               const float *d_affine = nullptr, const float *d_src = nullptr);
 int backward_impl(plx_lattice *L, const float *d_g, const float *d_src, const float *d_x, int nrhs, float *d_grad_x,
                   float *d_grad_src, hipStream_t stream);
 

@@ -87,6 +87,70 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(float *__restrict__ X
     }
 }
 
+// The same two updates with the CG coefficients formed on the device from the iteration's
+// scalars (no host round trip, none of the ten tiny elementwise launches a tensor-library
+// formulation of "alpha = active ? rs / pAp : 0" costs per iteration):
+//   step_update:     alpha = active ? rs / max(pAp, tiny) : 0;  X += alpha P;  R -= alpha AP;  partial |R|^2
+//   step_direction:  beta = active ? rs_new / max(rs, tiny) : 0;  P = R + beta P;
+//                    active' = active and sqrt(rs_new) / b_norm > tol
+__global__ __launch_bounds__(kBlock) void cg_step_update_kernel(float *__restrict__ X, float *__restrict__ R,
+                                                                const float *__restrict__ P, const float *__restrict__ AP,
+                                                                const float *__restrict__ rs, const float *__restrict__ pAp,
+                                                                const float *__restrict__ active, int64_t n, int vd,
+                                                                int logcw, float *__restrict__ partial,
+                                                                float *__restrict__ alpha_out)
+{
+    __shared__ float red[kBlock];
+    const int cw = 1 << logcw;
+    const int c = threadIdx.x & (cw - 1);
+    const int rl = threadIdx.x >> logcw;
+    const int rows_per_step = kBlock >> logcw;
+    const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(r0 + rows_per_block, n);
+    float acc = 0.f;
+    if (c < vd) {
+        const float a = active[c] > 0.f ? rs[c] / fmaxf(pAp[c], 1e-30f) : 0.f;
+        if (blockIdx.x == 0 && rl == 0) alpha_out[c] = a;
+        for (int64_t r = r0 + rl; r < r1; r += rows_per_step) {
+            const int64_t i = r * vd + c;
+            X[i] += P[i] * a;
+            const float res = R[i] - AP[i] * a;
+            R[i] = res;
+            acc += res * res;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c < vd) {
+        float s = 0.f;
+        for (int k = 0; k < rows_per_step; ++k) s += red[(k << logcw) + c];
+        partial[(size_t)blockIdx.x * vd + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void cg_step_direction_kernel(float *__restrict__ P, const float *__restrict__ R,
+                                                                   const float *__restrict__ rs_new,
+                                                                   const float *__restrict__ rs,
+                                                                   const float *__restrict__ active,
+                                                                   const float *__restrict__ b_norm, float tol,
+                                                                   int64_t total, int vd, float *__restrict__ beta_out,
+                                                                   float *__restrict__ active_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < total) {
+        const int c = (int)(i % vd);
+        const float b = active[c] > 0.f ? rs_new[c] / fmaxf(rs[c], 1e-30f) : 0.f;
+        P[i] = R[i] + P[i] * b;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < vd) {
+        const int c = threadIdx.x;
+        const bool on = active[c] > 0.f;
+        beta_out[c] = on ? rs_new[c] / fmaxf(rs[c], 1e-30f) : 0.f;
+        active_out[c] = (on && sqrtf(rs_new[c]) / b_norm[c] > tol) ? 1.f : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void cg_direction_kernel(float *__restrict__ P, const float *__restrict__ R,
                                                               const float *__restrict__ beta, int64_t total, int vd)
 {
@@ -176,6 +240,42 @@ extern "C" int plx_cg_update(float *d_x, float *d_r, const float *d_p, const flo
     hipStream_t s = (hipStream_t)stream;
     cg_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_alpha, n, vd, logcw, d_work);
     coldot_final_kernel<<<vd, kBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_cg_step_update(float *d_x, float *d_r, const float *d_p, const float *d_ap, const float *d_rs,
+                                  const float *d_pap, const float *d_active, int64_t n, int vd, float *d_rs_new,
+                                  float *d_alpha, float *d_work, void *stream)
+{
+    if (!d_x || !d_r || !d_p || !d_ap || !d_rs || !d_pap || !d_active || !d_rs_new || !d_alpha || !d_work) {
+        set_error("plx_cg_step_update: NULL argument");
+        return PLX_ERR_INVALID;
+    }
+    if (n < 0 || vd < 1 || vd > kBlock) { set_error("plx_cg_step_update: vd = %d outside 1..%d", vd, kBlock); return PLX_ERR_INVALID; }
+    int logcw = 0;
+    while ((1 << logcw) < vd) ++logcw;
+    hipStream_t s = (hipStream_t)stream;
+    cg_step_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_rs, d_pap, d_active, n, vd, logcw, d_work, d_alpha);
+    coldot_final_kernel<<<vd, kBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_cg_step_direction(float *d_p, const float *d_r, const float *d_rs_new, const float *d_rs,
+                                     const float *d_active, const float *d_b_norm, float tol, int64_t n, int vd,
+                                     float *d_beta, float *d_active_out, void *stream)
+{
+    if (!d_p || !d_r || !d_rs_new || !d_rs || !d_active || !d_b_norm || !d_beta || !d_active_out) {
+        set_error("plx_cg_step_direction: NULL argument");
+        return PLX_ERR_INVALID;
+    }
+    if (d_active == d_active_out) { set_error("plx_cg_step_direction: active and active_out must be different buffers"); return PLX_ERR_INVALID; }
+    if (n < 0 || vd < 1 || vd > kBlock) { set_error("plx_cg_step_direction: vd = %d outside 1..%d", vd, kBlock); return PLX_ERR_INVALID; }
+    const int64_t total = n * vd;
+    const int grid = total > 0 ? ceil_div(total, kBlock) : 1;
+    cg_step_direction_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(d_p, d_r, d_rs_new, d_rs, d_active, d_b_norm, tol, total,
+                                                                     vd, d_beta, d_active_out);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }

@@ -260,6 +260,21 @@ class Lattice:
         nv.check(rc, "plx_apply")
         return out
 
+    def apply_affine(self, src, scale_shift, out=None):
+        """out = a * K src + b * src with (a, b) = scale_shift (a 2-element float32 tensor on the device, read
+        there: no host synchronisation on hyper-parameters)."""
+        src = self._src(src, self.n_owned)
+        _check_f32_cuda(scale_shift, "scale_shift", ndim=1)
+        assert scale_shift.numel() == 2 and scale_shift.is_contiguous()
+        vd = src.shape[1]
+        if out is None:
+            out = torch.empty((self.n_owned, vd), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_apply_affine(self._h, ctypes.c_void_p(src.data_ptr()), vd, ctypes.c_void_p(out.data_ptr()),
+                                           ctypes.c_void_p(scale_shift.data_ptr()), _stream_ptr(self.device))
+        nv.check(rc, "plx_apply_affine")
+        return out
+
     @staticmethod
     def backward_fusable(nrhs, d):
         """True when plx_apply_backward covers this shape: 125..512 columns and 2*nrhs + d <= 62."""

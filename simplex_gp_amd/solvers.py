@@ -181,6 +181,8 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     """
     if precond is not None:
         return _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every)
+    if reduce is None and _native_ok(B):
+        return _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every)
     X = torch.zeros_like(B)
     R = B.clone().contiguous()
     P = R.clone()
@@ -206,6 +208,53 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     info = {"iterations": it, "residual": (rs.sqrt() / b_norm)}
     if want_tridiag:
         info["tridiag"] = _tridiag_from_cg(alphas, betas, B)
+    return X, info
+
+
+def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every):
+    """batched_cg on one GPU with the iteration's scalars kept on the device: per iteration one
+    MVM, one column dot, plx_cg_step_update and plx_cg_step_direction (alpha, beta and the
+    active mask are formed inside those kernels)."""
+    import ctypes
+    from . import _native as nv
+    lib = nv.lib()
+    n, t = B.shape
+    dev = B.device
+    X = torch.zeros_like(B)
+    R = B.clone().contiguous()
+    P = R.clone()
+    rs = _colsum(R, R)
+    b_norm = rs.sqrt().clamp_min(1e-30)
+    active = torch.ones(t, dtype=torch.float32, device=dev)
+    active_next = torch.empty_like(active)
+    rs_new = torch.empty_like(rs)
+    key = (dev.index, t)
+    work = _dot_work.get(key)
+    if work is None:
+        work = _dot_work[key] = torch.empty(int(lib.plx_coldot_work_floats(t)), dtype=torch.float32, device=dev)
+    kmax = max_iter
+    alphas = torch.zeros(kmax if want_tridiag else 1, t, dtype=torch.float32, device=dev)
+    betas = torch.zeros(kmax if want_tridiag else 1, t, dtype=torch.float32, device=dev)
+    p = lambda a: ctypes.c_void_p(a.data_ptr())          # noqa: E731
+    it = 0
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for it in range(1, max_iter + 1):
+            AP = matmul(P)
+            AP = AP if AP.is_contiguous() else AP.contiguous()
+            pAp = _colsum(P, AP)
+            row = it - 1 if want_tridiag else 0
+            nv.check(lib.plx_cg_step_update(p(X), p(R), p(P), p(AP), p(rs), p(pAp), p(active), n, t, p(rs_new),
+                                            p(alphas[row]), p(work), stream), "plx_cg_step_update")
+            nv.check(lib.plx_cg_step_direction(p(P), p(R), p(rs_new), p(rs), p(active), p(b_norm), float(tol), n, t,
+                                               p(betas[row]), p(active_next), stream), "plx_cg_step_direction")
+            rs, rs_new = rs_new, rs
+            active, active_next = active_next, active
+            if tol > 0 and (it % check_every == 0 or it == max_iter) and not bool(active.any()):
+                break
+    info = {"iterations": it, "residual": (rs.sqrt() / b_norm)}
+    if want_tridiag:
+        info["tridiag"] = _tridiag_from_cg(list(alphas[:it]), list(betas[:it]), B)
     return X, info
 
 
@@ -323,8 +372,8 @@ class LatticeGP(nn.Module):
                     # the factor's rows are in the caller's order: keep that order for the whole solve
                     lat.set_lattice_row_order(False)
                     return batched_cg(lambda V: lat.apply(V).mul_(s).addcmul_(V, noise), rhs, **cg_args)
-                sol, info = batched_cg(lambda V: lat.apply(V).mul_(s).addcmul_(V, noise),
-                                       lat.to_lattice_order(rhs), **cg_args)
+                ss = torch.stack([s.detach().reshape(()), noise.detach().reshape(())]).to(torch.float32).contiguous()
+                sol, info = batched_cg(lambda V: lat.apply_affine(V, ss), lat.to_lattice_order(rhs), **cg_args)
             finally:
                 lat.set_lattice_row_order(False)
             return lat.from_lattice_order(sol), info

@@ -403,3 +403,35 @@ def test_fused_backward_matches_unfused_and_oracle(plx, n, d, L):
     for name, a, b, c in (("grad_src", fused[0], unfused[0], ref[0]), ("grad_x", fused[1], unfused[1], ref[1])):
         assert rel_l2(a, b) <= 1e-6, (name, "fused vs unfused", rel_l2(a, b))
         assert rel_l2(a, c) <= 2e-5, (name, "fused vs oracle", rel_l2(a, c))
+
+
+def test_affine_apply_and_device_side_cg(plx):
+    """plx_apply_affine == s * apply + noise * v, in both row orders; the CG loop with device-side coefficients
+    (plx_cg_step_*) follows the tensor formulation (same iterates to rounding, same Lanczos tridiagonals)."""
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(21)
+    n, d, t = 50000, 4, 6
+    x = torch.randn(n, d, generator=g).cuda()
+    V = torch.randn(n, t, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    lat = plx.Lattice().build(x, taps)
+    ss = torch.tensor([0.7, 0.3], device="cuda")
+    for lattice_rows in (False, True):
+        lat.set_lattice_row_order(lattice_rows)
+        ref = lat.apply(V) * 0.7 + 0.3 * V
+        got = lat.apply_affine(V, ss)
+        assert rel_l2(got.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
+        one = lat.apply_affine(V[:, :1].contiguous(), ss)
+        assert rel_l2(one.cpu().numpy(), ref[:, :1].cpu().numpy()) <= 1e-6
+    from simplex_gp_amd._native import PlxError
+    with pytest.raises(PlxError):
+        lat.apply_affine(V, ss, out=V)
+    lat.set_lattice_row_order(False)
+    mm = lambda W: lat.apply_affine(W, ss)       # noqa: E731
+    Xa, ia = solvers.batched_cg(mm, V, max_iter=40, tol=1e-6, want_tridiag=True, check_every=1)
+    Xb, ib = solvers.batched_cg(mm, V, max_iter=40, tol=1e-6, want_tridiag=True, check_every=1, reduce=lambda s: s)
+    assert ia["iterations"] == ib["iterations"]
+    assert rel_l2(Xa.cpu().numpy(), Xb.cpu().numpy()) <= 1e-5
+    k = min(ia["tridiag"].shape[1], ib["tridiag"].shape[1])
+    assert torch.allclose(ia["tridiag"][:, :k, :k], ib["tridiag"][:, :k, :k], rtol=1e-3, atol=1e-4)
+    lat.close()
