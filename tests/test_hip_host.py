@@ -96,13 +96,13 @@ def test_lengthscale_gradient_on_gpu(plx):
     assert np.isfinite(g) and g != 0.0
 
 
-@pytest.mark.parametrize("shards", [2, 3])
-def test_owned_ranges_compose(plx, shards):
+@pytest.mark.parametrize("shards,vd", [(2, 3), (3, 3), (2, 7), (3, 20)])
+def test_owned_ranges_compose(plx, shards, vd):
     """plx_build with an owned row range (the multi-GPU structure), emulated on one GPU:
     per-shard splats add up to the full splat, per-shard slices tile the full output."""
     from simplex_gp_amd.distributed import shard_bounds
     g = torch.Generator().manual_seed(3)
-    n, d, vd = 20011, 4, 3
+    n, d = 20011, 4          # vd 3: scan splat, 7 and 20: lane-group splat, on partially covered vertex sets
     x = torch.randn(n, d, generator=g).cuda()
     v = torch.randn(n, vd, generator=g).cuda()
     taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
