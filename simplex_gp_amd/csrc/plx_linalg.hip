@@ -137,11 +137,20 @@ __global__ __launch_bounds__(kBlock) void cg_step_direction_kernel(float *__rest
                                                                    int64_t total, int vd, float *__restrict__ beta_out,
                                                                    float *__restrict__ active_out)
 {
+    // beta per column once per workgroup; the column of element i = blockIdx * kBlock + tid from 32-bit
+    // residues (a 64-bit i % vd per element costs more than the update itself)
+    __shared__ float sbeta[kBlock];
+    if ((int)threadIdx.x < vd) {
+        const int c = threadIdx.x;
+        sbeta[c] = active[c] > 0.f ? rs_new[c] / fmaxf(rs[c], 1e-30f) : 0.f;
+    }
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < total) {
-        const int c = (int)(i % vd);
-        const float b = active[c] > 0.f ? rs_new[c] / fmaxf(rs[c], 1e-30f) : 0.f;
-        P[i] = R[i] + P[i] * b;
+        const uint32_t uvd = (uint32_t)vd;
+        const uint32_t bm = ((blockIdx.x % uvd) * ((uint32_t)kBlock % uvd)) % uvd;      // wave-uniform
+        const uint32_t c = (bm + threadIdx.x) % uvd;
+        P[i] = R[i] + P[i] * sbeta[c];
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < vd) {
         const int c = threadIdx.x;
