@@ -30,6 +30,7 @@ static int g_xcd_remap = 1;    // 1: workgroup b works on tile (b % 8) * ceil(nb
 static int g_splat_direct = 1;  // vd = 1: gather from d_src through caller-row indices instead of a sorted copy:
                                 // 0 never, 1 for launch-bound sizes (<= 2e6 corners: saves a launch; at 9e6 corners
                                 // the sorted copy wins, 58 vs 60 us), 2 always
+static int g_blur_narrow = 1;   // vd 2..16 blur: row length compiled in, branch-free (0: blur_axis_kernel)
 static int g_blur_multi = 1;    // vd > 1 blur: 4 items per thread (0: one item per thread, blur_axis_kernel)
 static int g_splat_group = 1;   // vd 2..64: lane-group streaming splat (0: segmented-scan kernel)
 static int g_splat_wide = 1;    // row-parallel splat for rows of 32..128 chunks (vd 125..512)
@@ -43,7 +44,7 @@ extern int g_nbr_symmetric;
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"order_zcurve", &g_order_zcurve}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap}, {"blur_small", &g_blur_small}, {"blur_multi", &g_blur_multi}, {"splat_group", &g_splat_group},
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"order_zcurve", &g_order_zcurve}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap}, {"blur_small", &g_blur_small}, {"blur_multi", &g_blur_multi}, {"blur_narrow", &g_blur_narrow}, {"splat_group", &g_splat_group},
                           {"splat_direct", &g_splat_direct}, {"splat_wide", &g_splat_wide}, {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
@@ -905,6 +906,52 @@ __global__ __launch_bounds__(kBlock) void blur_axis_kernel(const V *__restrict__
     out[item] = acc;
 }
 
+// vd 2..16 (rows of 1..4 chunks, every CG iteration): the general kernel with the row length a
+// compile-time constant (the division by 3 alone made a 3-chunk pass slower per byte than a 2-chunk one),
+// 32-bit element indices (scalar base + 32-bit lane offset addressing) and no branches: an absent
+// neighbour re-reads the centre chunk and is dropped by a select.
+template <int ORDER, int ROWLEN>
+__global__ __launch_bounds__(kBlock) void blur_axis_narrow_kernel(const float4 *__restrict__ old, float4 *__restrict__ out,
+                                                                  const int *__restrict__ nbr, uint32_t total,
+                                                                  uint32_t mstride, TapArgs taps, int ntiles, int remap)
+{
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const uint32_t item = (uint32_t)tile * kBlock + threadIdx.x;
+    if (item >= total) return;
+    const uint32_t i = item / ROWLEN, ch = item - i * ROWLEN;
+    int nb[2 * ORDER];
+#pragma unroll
+    for (int s = 0; s < 2 * ORDER; ++s) nb[s] = nbr[(uint32_t)s * mstride + i];
+    const float4 c = old[item];
+    float4 g[2 * ORDER];
+#pragma unroll
+    for (int s = 0; s < 2 * ORDER; ++s) g[s] = old[nb[s] >= 0 ? (uint32_t)nb[s] * ROWLEN + ch : item];
+    float4 acc = f4_zero();
+#pragma unroll
+    for (int s = 0; s < ORDER; ++s) acc = f4_sel(nb[s] >= 0, f4_add(acc, f4_scale(taps.c[s], g[s])), acc);
+    acc = f4_add(acc, f4_scale(taps.c[ORDER], c));
+#pragma unroll
+    for (int s = 0; s < ORDER; ++s)
+        acc = f4_sel(nb[ORDER + s] >= 0, f4_add(acc, f4_scale(taps.c[ORDER + 1 + s], g[ORDER + s])), acc);
+    out[item] = acc;
+}
+
+template <int ORDER>
+static void launch_blur_narrow(const float4 *cur, float4 *nxt, const int *nb, int m, int64_t mstride, int rowlen,
+                               const TapArgs &taps, hipStream_t stream, int remap)
+{
+    const uint32_t total = (uint32_t)m * (uint32_t)rowlen;
+    const int nt = ceil_div((int64_t)total, kBlock);
+    const int grid = tile_grid(nt, remap);
+    switch (rowlen) {
+    case 1: blur_axis_narrow_kernel<ORDER, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, total, (uint32_t)mstride, taps, nt, remap); break;
+    case 2: blur_axis_narrow_kernel<ORDER, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, total, (uint32_t)mstride, taps, nt, remap); break;
+    case 3: blur_axis_narrow_kernel<ORDER, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, total, (uint32_t)mstride, taps, nt, remap); break;
+    default: blur_axis_narrow_kernel<ORDER, 4><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, total, (uint32_t)mstride, taps, nt, remap); break;
+    }
+}
+
 // vd > 1, the shipped kernel: IPT (vertex, chunk) items per thread, 256 apart, so that a thread has
 // all its id loads and centre chunks in flight, then all its gathers, then its stores (one item per
 // thread streamed at 4.0-4.6 TB/s with the gathers switched off, a copy kernel reaches 6.3).  The
@@ -1028,6 +1075,15 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             }
         } else if (vd == 1) {
             launch_blur_general<float>(cur, nxt, nb, m, L->mstride, 1, order, L->taps, stream);
+        } else if (order >= 1 && order <= 3 && vdp / 4 <= 4 && g_blur_narrow && (int64_t)d1 * 2 * order * L->mstride < (1ll << 32)) {
+            const float4 *c4 = reinterpret_cast<const float4 *>(cur);
+            float4 *n4 = reinterpret_cast<float4 *>(nxt);
+            // nb is already offset to this axis: plane offsets inside the kernel stay below 2 * order * mstride
+            switch (order) {
+            case 1: launch_blur_narrow<1>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
+            case 2: launch_blur_narrow<2>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
+            default: launch_blur_narrow<3>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
+            }
         } else if (order <= 3 && g_blur_multi && vdp / 4 >= 32) {   // narrower rows: no gain (vd 2..16 measured 0-30 % slower)
             constexpr int IPT = 4;
             const int rowlen = vdp / 4;
