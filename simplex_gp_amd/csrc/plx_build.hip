@@ -941,6 +941,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         AxisOffsets ao;
         int64_t total = 0;
         for (int a = 0; a < D1; ++a) { ao.off[a] = total; L->compact_off[a] = total; total += L->h_pinned[2 + a]; }
+        L->compact_off[D1] = total;
         const double fill = (double)total / ((double)m * taps2 * D1);
         if (g_compact_nbr == 2 || fill < 0.5) {
             PLX_TRY(ensure(L->cids, (size_t)total * 4 + 64));

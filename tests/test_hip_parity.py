@@ -368,3 +368,31 @@ def test_random_small_shapes(plx):
         assert err <= 5e-5, (n, d, vd, order, scale, kind, seed, err)
 
     run()
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_compacted_neighbour_table_equals_dense(plx, order):
+    """The wave-prefix compacted neighbour table (used on sparse lattices at vd = 1) gives bit-identical blur
+    results to the dense [d+1][2r][m] table, including vertex counts that are not multiples of 4 / 256."""
+    from simplex_gp_amd import _native as nv
+    rng = np.random.default_rng(50 + order)
+    half = {1: [0.34608543], 2: [0.08263808, 0.53616077], 3: [0.01831428, 0.16900772, 0.64117509]}[order]
+    taps = np.asarray(half + [1.0] + half[::-1], np.float32)
+    lib = nv.lib()
+    try:
+        for n, d, scale in [(3001, 3, 4.0), (20000, 5, 3.0), (777, 8, 2.0), (50000, 2, 30.0)]:
+            ref = torch.from_numpy((rng.standard_normal((n, d)) * scale).astype(np.float32)).cuda()
+            src = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).cuda()
+            outs, ms = [], []
+            for mode in (0, 2):
+                nv.check(lib.plx_tune(b"compact_nbr", mode), "plx_tune")
+                lat = plx.Lattice().build(ref, taps)
+                vals = lat.splat(src)
+                res = lat.blur(vals.clone(), vd=1)
+                outs.append(res.cpu().numpy().copy())
+                ms.append(lat.m)
+                lat.close()
+            assert ms[0] == ms[1]
+            assert np.array_equal(outs[0], outs[1]), (n, d, order)
+    finally:
+        nv.check(lib.plx_tune(b"compact_nbr", 1), "plx_tune")
