@@ -380,7 +380,10 @@ int plx_export(plx_lattice *L, int which, void *h_dst, int64_t bytes, void *stre
     }
     case PLX_ARRAY_ENTRY_VERTEX: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->evid.p, bytes, hipMemcpyDeviceToHost, s)); break;
     case PLX_ARRAY_ENTRY_WEIGHT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->ew.p, bytes, hipMemcpyDeviceToHost, s)); break;
-    case PLX_ARRAY_ROW_PTR: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->row_ptr.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    case PLX_ARRAY_ROW_PTR:
+        PLX_TRY(export_row_ptr(L, s));
+        PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->row_ptr.p, bytes, hipMemcpyDeviceToHost, s));
+        break;
     case PLX_ARRAY_CSR_POINT: {
         PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_pt.p, bytes, hipMemcpyDeviceToHost, s));
         PLX_HIP_TRY(hipStreamSynchronize(s));

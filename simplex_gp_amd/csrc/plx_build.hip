@@ -627,15 +627,13 @@ __global__ __launch_bounds__(kBlock) void csr_finalize_kernel(const uint32_t *__
                                                               const uint32_t *__restrict__ perm,
                                                               int *__restrict__ csr_pt,
                                                               int *__restrict__ csr_row,
-                                                              float *__restrict__ csr_w,
-                                                              int *__restrict__ row_ptr)
+                                                              float *__restrict__ csr_w)
 {
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= nnz) return;
     const uint32_t v = skeys[k];
     const uint32_t idx = svals[k];
     const uint32_t r = idx / (uint32_t)n;
-    // row_ptr[u] = first k with skeys[k] >= u; rows no owned point touches are empty
     const int prev = (k == 0) ? -1 : (int)skeys[k - 1];
     // sign bit of csr_pt marks the first entry of a vertex row (segment head)
     const uint32_t head = (prev != (int)v) ? 0x80000000u : 0u;
@@ -643,9 +641,23 @@ __global__ __launch_bounds__(kBlock) void csr_finalize_kernel(const uint32_t *__
     csr_pt[k] = (int)((p - (uint32_t)own_begin) | head);
     csr_row[k] = (int)((perm[p] - (uint32_t)own_begin) | head);   // the same point as the caller numbers its rows
     csr_w[k] = ew[idx];
-    for (int u = prev + 1; u <= (int)v; ++u) row_ptr[u] = k;
-    if (k == nnz - 1)
-        for (int u = (int)v + 1; u <= m; ++u) row_ptr[u] = nnz;
+}
+
+// row_ptr[u] = first k with skeys[k] >= u (rows that no owned point touches are empty).  No kernel on
+// the MVM path needs it (row heads are flagged in csr_pt), so it is produced only when exported;
+// filling it inside csr_finalize_kernel made the thread behind a gap walk it alone -- 8 ms per build
+// for one rank of an 8-rank job, whose own rows touch less than half of the merged vertex set.
+__global__ __launch_bounds__(kBlock) void row_ptr_kernel(const uint32_t *__restrict__ skeys, int nnz, int m,
+                                                         int *__restrict__ row_ptr)
+{
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u > m) return;
+    int lo = 0, hi = nnz;                          // lower bound of u in the sorted vertex ids
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (skeys[mid] < (uint32_t)u) lo = mid + 1; else hi = mid;
+    }
+    row_ptr[u] = lo;
 }
 
 // ----------------------------------------------------------------------------
@@ -903,7 +915,6 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     L->nchunks = ceil_div(L->nnz, kSplatChunk);
 
     PLX_TRY(ensure(L->nbr, (size_t)D1 * 2 * order * L->mstride * 4 + 4));
-    PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
     PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
     PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
     PLX_TRY(ensure(L->csr_row, (size_t)L->nnz * 4 + 64));
@@ -973,9 +984,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
             L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
             (int)L->own_begin, (int)L->nnz, m, L->perm.as<uint32_t>(), L->csr_pt.as<int>(), L->csr_row.as<int>(),
-            L->csr_w.as<float>(), L->row_ptr.as<int>());
-    } else {
-        PLX_HIP_TRY(hipMemsetAsync(L->row_ptr.p, 0, (size_t)(m + 1) * 4, stream));
+            L->csr_w.as<float>());
     }
     mark();
     PLX_HIP_TRY(hipGetLastError());
@@ -1052,6 +1061,16 @@ int build_merge_impl(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *
 #define PLX_CASE(D) case D: return merge_typed<D>(L, d_all_keys, h_counts, n_ranks, my_rank, stream);
     PLX_DIM_SWITCH()
 #undef PLX_CASE
+}
+
+int export_row_ptr(plx_lattice *L, hipStream_t stream)
+{
+    const int m = (int)L->m;
+    PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
+    row_ptr_kernel<<<ceil_div((int64_t)m + 1, kBlock), kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)L->nnz, m,
+                                                                            L->row_ptr.as<int>());
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
 }
 
 }  // namespace plx

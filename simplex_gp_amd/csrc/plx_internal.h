@@ -100,7 +100,7 @@ struct plx_lattice {
     plx::DevBuf csr_row;    // int32  [nnz]          the same points numbered as the caller's rows (vd = 1 splat
                             //                       gathers straight from d_src, no sorted copy)
     plx::DevBuf csr_w;      // float  [nnz]
-    plx::DevBuf row_ptr;    // int32  [m+1]
+    plx::DevBuf row_ptr;    // int32  [m+1]          produced on demand by plx_export (no kernel reads it)
 
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
@@ -125,6 +125,7 @@ int build_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);
 int build_local_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);
 int build_merge_impl(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
                      hipStream_t stream);
+int export_row_ptr(plx_lattice *L, hipStream_t stream);   // fills L->row_ptr on demand (plx_export only)
 // plx_sort.hip (rocPRIM radix sort of (vertex id, entry index) pairs)
 int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,

@@ -37,19 +37,25 @@ def all_reduce_sum(t, group=None):
     return t
 
 
-def all_gather_rows(t_local, group=None):
-    """Concatenate every rank's rows (row counts may differ) -> (tensor, counts)."""
+def all_gather_rows(t_local, group=None, extra=None):
+    """Concatenate every rank's rows (row counts may differ) -> (tensor, counts).
+    `extra`: a few integers per rank exchanged in the same small collective as the row counts
+    (returned as a third value, one list per rank); one host synchronisation in total."""
     world = dist.get_world_size(group)
-    n_local = torch.tensor([t_local.shape[0]], dtype=torch.int64, device=t_local.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
+    meta = torch.tensor([t_local.shape[0]] + [int(e) for e in (extra or [])], dtype=torch.int64, device=t_local.device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    table = torch.stack(metas, 0).tolist()
+    counts = [int(row[0]) for row in table]
     biggest = max(counts)
     padded = torch.zeros((biggest,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
     padded[: t_local.shape[0]] = t_local
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
-    return torch.cat([p[:k] for p, k in zip(parts, counts)], 0), counts
+    out = torch.cat([p[:k] for p, k in zip(parts, counts)], 0)
+    if extra is None:
+        return out, counts
+    return out, counts, [[int(v) for v in row[1:]] for row in table]
 
 
 class ShardedLatticeMVM:
@@ -90,12 +96,10 @@ class ShardedLatticeMVM:
             self.lattice.build(ref_local, coeffs)
             return self
         keys = self.lattice.build_local(ref_local, coeffs)
-        all_keys, counts = all_gather_rows(keys, group)            # the one collective of the build
+        # the one exchange of the build: vertex keys, with the key and row counts riding in its size message
+        all_keys, counts, rows = all_gather_rows(keys, group, extra=[ref_local.shape[0]])
         self.lattice.build_merge(all_keys, counts, self.rank)
-        rows = torch.tensor([ref_local.shape[0]], dtype=torch.int64, device=ref_local.device)
-        every = [torch.zeros_like(rows) for _ in range(self.world)]
-        dist.all_gather(every, rows, group=group)
-        every = [int(r.item()) for r in every]
+        every = [r[0] for r in rows]
         self.n = sum(every) if n_total is None else n_total
         self.lo = sum(every[: self.rank])
         self.hi = self.lo + every[self.rank]
