@@ -396,3 +396,28 @@ def test_compacted_neighbour_table_equals_dense(plx, order):
             assert np.array_equal(outs[0], outs[1]), (n, d, order)
     finally:
         nv.check(lib.plx_tune(b"compact_nbr", 1), "plx_tune")
+
+
+@pytest.mark.parametrize("vd", [1, 3, 7, 12, 40, 130])
+def test_long_vertex_rows_every_splat_kernel(plx, vd):
+    """Clouds whose points share a handful of simplices: every vertex row is hundreds to thousands of corners long,
+    so rows span many lane-group runs, waves and workgroups (in-wave segmented scan + head / tail partials + fix-up)
+    in each of the splat kernels (scan: vd 1-4, lane groups: 5-64, wide: >= 125)."""
+    rng = np.random.default_rng(200 + vd)
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    cases = []
+    n, d = 6001, 5
+    same = np.tile(rng.standard_normal((1, d)).astype(np.float32), (n, 1))              # one simplex: rows of n corners
+    cases.append(same)
+    few = rng.standard_normal((7, d)).astype(np.float32)[rng.integers(0, 7, n)]          # 7 distinct positions
+    cases.append(few + 1e-4 * rng.standard_normal((n, d)).astype(np.float32))
+    cases.append((rng.standard_normal((3000, 2)) * 0.05).astype(np.float32))            # a tight 2-D blob
+    oracle.set_exact_mode(False)
+    try:
+        for ref in cases:
+            src = rng.standard_normal((ref.shape[0], vd)).astype(np.float32)
+            want = oracle.filter(src, ref, taps)
+            got = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), torch.from_numpy(taps)).cpu().numpy()
+            assert rel_l2(got, want) <= TOL_ORACLE, (vd, ref.shape)
+    finally:
+        oracle.set_exact_mode(True)
