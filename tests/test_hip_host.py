@@ -435,3 +435,30 @@ def test_affine_apply_and_device_side_cg(plx):
     k = min(ia["tridiag"].shape[1], ib["tridiag"].shape[1])
     assert torch.allclose(ia["tridiag"][:, :k, :k], ib["tridiag"][:, :k, :k], rtol=1e-3, atol=1e-4)
     lat.close()
+
+
+def test_fused_entry_points_reject_bad_use(plx):
+    """plx_apply_backward / plx_apply_affine fail loudly (error code -> PlxError / ValueError), never silently."""
+    from simplex_gp_amd._native import PlxError
+    g = torch.Generator().manual_seed(8)
+    n, d, L = 4000, 8, 11
+    x = torch.randn(n, d, generator=g).cuda()
+    v = torch.randn(n, L, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    lat = plx.Lattice()
+    with pytest.raises((PlxError, ValueError)):         # not built yet
+        lat.apply_backward(v, v, x)
+    lat.build(x, taps, shard=(0, 2))                    # a sharded lattice needs the all-reduce between splat and blur
+    with pytest.raises(PlxError):
+        lat.apply_backward(v[: lat.n_owned], v[: lat.n_owned], x[: lat.n_owned])
+    lat.build(x, taps)
+    with pytest.raises(PlxError):                       # 2 * 1 * 9 = 18 columns: outside the fused range
+        lat.apply_backward(v[:, :1].contiguous(), v[:, :1].contiguous(), x)
+    with pytest.raises(ValueError):                     # shapes must agree
+        lat.apply_backward(v, v[:, :5].contiguous(), x)
+    with pytest.raises((TypeError, ValueError)):
+        lat.apply_affine(v, torch.tensor([1.0, 0.0]))   # scale/shift must live on the device
+    assert not plx.Lattice.backward_fusable(1, 8) and plx.Lattice.backward_fusable(11, 8)
+    gr, gs = lat.apply_backward(v, v, x, want_grad_src=False)
+    assert gs is None and gr.shape == (n, d) and torch.isfinite(gr).all()
+    lat.close()
