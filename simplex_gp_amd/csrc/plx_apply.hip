@@ -465,20 +465,21 @@ __global__ __launch_bounds__(kBlock) void splat_wide_kernel(const int *__restric
 // wave's corner range go through head / tail partials and splat_fixup_kernel.  The wave's corner indices,
 // weights and vertex ids are staged through LDS by coalesced loads (a group region holds its run plus the
 // corner after it, stride kGroupRun + 1 words: no bank conflicts between groups).
-constexpr int kGroupRun = 32;
+constexpr int kGroupRun = 32;      // corners per lane group
 
-template <int NCHP>
+template <class V, int NCHP, int RUN>
 __global__ __launch_bounds__(kBlock) void splat_group_kernel(const int *__restrict__ csr_pt, const float *__restrict__ csr_w,
                                                              const int *__restrict__ csr_vid,
-                                                             const float4 *__restrict__ ssrc, int nch, int nnz,
-                                                             float4 *__restrict__ values,
-                                                             float4 *__restrict__ head_partial,
-                                                             float4 *__restrict__ tail_partial, int ntiles, int remap,
+                                                             const V *__restrict__ ssrc, int nch, int nnz,
+                                                             V *__restrict__ values,
+                                                             V *__restrict__ head_partial,
+                                                             V *__restrict__ tail_partial, int ntiles, int remap,
                                                              int ablate)
 {
+    using O = VecOps<V>;
     constexpr int G = 64 / NCHP;                       // groups per wave
-    constexpr int WC = G * kGroupRun;                  // corners per wave = one chunk of the partial protocol
-    constexpr int RS = kGroupRun + 1;                  // LDS words per group region
+    constexpr int WC = G * RUN;                  // corners per wave = one chunk of the partial protocol
+    constexpr int RS = RUN + 1;                  // LDS words per group region
     constexpr int U = 8;                               // source rows in flight per lane
     __shared__ int lds_pt[kBlock / 64][G * RS];
     __shared__ float lds_w[kBlock / 64][G * RS];
@@ -497,21 +498,21 @@ __global__ __launch_bounds__(kBlock) void splat_group_kernel(const int *__restri
         const int pt = e < nnz ? csr_pt[e] : (int)0x80000000;          // past the data: reads as a row head
         const float w = in ? csr_w[e] : 0.f;
         const int vid = in ? csr_vid[e] : 0;
-        const int rg = r / kGroupRun, rj = r - rg * kGroupRun;
+        const int rg = r / RUN, rj = r - rg * RUN;
         if (r < WC) { lds_pt[wave][rg * RS + rj] = pt; lds_w[wave][rg * RS + rj] = w; lds_vid[wave][rg * RS + rj] = vid; }
-        if (rj == 0 && rg > 0) lds_pt[wave][(rg - 1) * RS + kGroupRun] = pt;
+        if (rj == 0 && rg > 0) lds_pt[wave][(rg - 1) * RS + RUN] = pt;
     }
     __builtin_amdgcn_wave_barrier();                   // LDS traffic of one wave is in order; keep the compiler from moving it
 
     const int g = lane / NCHP, cl = lane - g * NCHP;
     const bool col = cl < nch;
-    const int len = min(kGroupRun, nnz - (k0 + g * kGroupRun));   // <= 0: this group has no corners
+    const int len = min(RUN, nnz - (k0 + g * RUN));   // <= 0: this group has no corners
     const int *gp = lds_pt[wave] + g * RS;
     const float *gw = lds_w[wave] + g * RS;
     const int *gv = lds_vid[wave] + g * RS;
     const uint32_t coff = (uint32_t)min(cl, nch - 1);
 
-    float4 acc = f4_zero(), left_part = f4_zero();
+    V acc = O::zero(), left_part = O::zero();
     const bool from_left = len > 0 && gp[0] >= 0;      // the first corner continues the row of the run before
     bool left_closed = false, closed_any = false;
     int left_vid = 0;
@@ -519,12 +520,12 @@ __global__ __launch_bounds__(kBlock) void splat_group_kernel(const int *__restri
     // corners, and every divergent branch costs the whole wave its scalar bookkeeping (a first version
     // with nested ifs spent 35 scalar + 28 vector instructions per corner).  Corners past the end of
     // the run have weight 0 and never close.
-    for (int j = 0; j < kGroupRun; j += U) {
+    for (int j = 0; j < RUN; j += U) {
         int pr[U + 1], vd_[U];
         float w[U];
-        float4 row[U];
+        V row[U];
 #pragma unroll
-        for (int u = 0; u <= U; ++u) pr[u] = gp[min(j + u, kGroupRun)];
+        for (int u = 0; u <= U; ++u) pr[u] = gp[min(j + u, RUN)];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             w[u] = gw[j + u];
@@ -534,41 +535,41 @@ __global__ __launch_bounds__(kBlock) void splat_group_kernel(const int *__restri
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            acc = f4_add(acc, f4_scale(w[u], row[u]));
+            acc = O::add(acc, O::scale(w[u], row[u]));
             const bool closes = (j + u < len) && pr[u + 1] < 0;   // the next corner starts a row, or the data ends
             const bool first_left = closes && from_left && !closed_any;
-            left_part = f4_sel(first_left, acc, left_part);
+            left_part = O::sel(first_left, acc, left_part);
             left_vid = first_left ? vd_[u] : left_vid;
             left_closed = left_closed || first_left;
             if (closes && !first_left && col && !(ablate & 2)) values[(uint32_t)vd_[u] * (uint32_t)nch + (uint32_t)cl] = acc;
-            acc = f4_sel(closes, f4_zero(), acc);
+            acc = O::sel(closes, O::zero(), acc);
             closed_any = closed_any || closes;
         }
     }
     // segmented scan over the groups: (closes seen, sum since the last close)
     int icnt = closed_any ? 1 : 0;
-    float4 ival = acc;
+    V ival = acc;
 #pragma unroll
     for (int off = NCHP; off < 64; off <<= 1) {
         const int ocnt = __shfl_up(icnt, off);
-        const float4 oval = f4_shfl_up(ival, off);
+        const V oval = O::shfl_up(ival, off);
         if (lane >= off) {
-            ival = f4_sel(icnt > 0, ival, f4_add(oval, ival));
+            ival = O::sel(icnt > 0, ival, O::add(oval, ival));
             icnt += ocnt;
         }
     }
     int xcnt = __shfl_up(icnt, NCHP);
-    float4 xval = f4_shfl_up(ival, NCHP);
-    if (lane < NCHP) { xcnt = 0; xval = f4_zero(); }
+    V xval = O::shfl_up(ival, NCHP);
+    if (lane < NCHP) { xcnt = 0; xval = O::zero(); }
     const bool wave_from_left = lds_pt[wave][0] >= 0;
     if (left_closed && col) {
         // the row that entered this run from the left: what earlier groups hold of it + this group's part
-        float4 *dst = (xcnt == 0 && wave_from_left) ? head_partial + (size_t)wchunk * nch : values + (size_t)left_vid * nch;
-        dst[cl] = f4_add(xval, left_part);
+        V *dst = (xcnt == 0 && wave_from_left) ? head_partial + (size_t)wchunk * nch : values + (size_t)left_vid * nch;
+        dst[cl] = O::add(xval, left_part);
     }
-    if (g == G - 1 && col && lds_pt[wave][(G - 1) * RS + kGroupRun] >= 0) {
+    if (g == G - 1 && col && lds_pt[wave][(G - 1) * RS + RUN] >= 0) {
         // the row still open at the end of the wave's range
-        float4 *dst = (icnt == 0 && wave_from_left) ? head_partial : tail_partial;
+        V *dst = (icnt == 0 && wave_from_left) ? head_partial : tail_partial;
         dst[(size_t)wchunk * nch + cl] = ival;
     }
 }
@@ -637,6 +638,8 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     float *hp = L->head_partial.as<float>(), *tp = L->tail_partial.as<float>();
     const int nnz = (int)L->nnz, nch_total = vdp / 4, nchunks = (int)L->nchunks;
     if (vd == 1) {
+        // (one lane per run of corners -- splat_group_kernel<float, 1, 16> -- was measured 18-75 % slower here:
+        // the scan kernel's 16-byte index loads and coalesced stores win on single-column rows)
         splat_scan_kernel<float, 1><<<tile_grid(nchunks, g_xcd_remap), kSplatBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, g_splat_ablate, nchunks, g_xcd_remap);
     } else {
         const float4 *s4 = reinterpret_cast<const float4 *>(ss);
@@ -670,10 +673,10 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
             t4 = reinterpret_cast<float4 *>(L->tail_partial.as<float>());
             const int grid = tile_grid(nt, g_xcd_remap);
             switch (nchp) {
-            case 2: splat_group_kernel<2><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
-            case 4: splat_group_kernel<4><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
-            case 8: splat_group_kernel<8><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
-            default: splat_group_kernel<16><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
+            case 2: splat_group_kernel<float4, 2, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
+            case 4: splat_group_kernel<float4, 4, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
+            case 8: splat_group_kernel<float4, 8, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
+            default: splat_group_kernel<float4, 16, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
             }
             splat_fixup_kernel<<<ceil_div((int64_t)nwchunks * vdp, kBlock), kBlock, 0, stream>>>(
                 pt, vid, nwchunks, wc, nnz, vdp, L->head_partial.as<float>(), L->tail_partial.as<float>(), d_values);
