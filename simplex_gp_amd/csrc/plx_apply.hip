@@ -1099,7 +1099,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             case 2: launch_blur_narrow<2>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
             default: launch_blur_narrow<3>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
             }
-        } else if (order <= 3 && g_blur_multi && vdp / 4 >= 32) {   // narrower rows: no gain (vd 2..16 measured 0-30 % slower)
+        } else if (order >= 1 && order <= 3 && g_blur_multi && vdp / 4 >= 32) {   // narrower rows: no gain (vd 2..16 measured 0-30 % slower)
             constexpr int IPT = 4;
             const int rowlen = vdp / 4;
             const int nt = ceil_div((int64_t)m * rowlen, kBlock * IPT);

@@ -421,3 +421,22 @@ def test_long_vertex_rows_every_splat_kernel(plx, vd):
             assert rel_l2(got, want) <= TOL_ORACLE, (vd, ref.shape)
     finally:
         oracle.set_exact_mode(True)
+
+
+@pytest.mark.parametrize("ntaps", [1, 3, 5, 7])
+def test_every_tap_order_at_every_row_width(plx, ntaps):
+    """Order 0 (a single tap: the blur is the identity times c) up to order 3, through the single-column, narrow,
+    general and wide blur kernels (a fuzz run caught order 0 being sent to an order-3 instantiation at >= 125 columns)."""
+    rng = np.random.default_rng(300 + ntaps)
+    taps = np.array([0.1, 0.3, 0.6, 1.0, 0.6, 0.3, 0.1][3 - ntaps // 2: 4 + ntaps // 2], np.float32)
+    n, d = 1500, 3
+    ref = (rng.standard_normal((n, d)) * 2.0).astype(np.float32)
+    oracle.set_exact_mode(False)
+    try:
+        for vd in (1, 3, 7, 17, 40, 110, 130):
+            src = rng.standard_normal((n, vd)).astype(np.float32)
+            want = oracle.filter(src, ref, taps)
+            got = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), torch.from_numpy(taps)).cpu().numpy()
+            assert rel_l2(got, want) <= TOL_ORACLE, (ntaps, vd)
+    finally:
+        oracle.set_exact_mode(True)
