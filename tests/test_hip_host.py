@@ -199,7 +199,7 @@ def test_lattice_row_order_mode(plx):
     x = torch.randn(20000, 4, generator=g).cuda()
     taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
     lat = plx.Lattice().build(x, taps)
-    for vd in (1, 3):
+    for vd in (1, 3, 7, 40, 130):       # scan, lane-group and wide splat; single-column, narrow, general and wide blur
         v = torch.randn(20000, vd, generator=g).cuda()
         want = lat.apply(v).clone()
         lat.set_lattice_row_order(True)
