@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--nu", type=float, default=None, help="Matern smoothness (1.5 / 2.5); default RBF")
     ap.add_argument("--min-noise", type=float, default=1e-4)
+    ap.add_argument("--pre-size", type=int, default=0, help="rank of the pivoted-Cholesky preconditioner (the reference's configs use 100)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="model.pt")
     args = ap.parse_args()
@@ -48,7 +49,7 @@ def main():
               else plx.RBFLattice(order=args.order, ard_num_dims=args.d))
     model = solvers.LatticeGP(kernel, min_noise=args.min_noise).to(dev)
     t0 = time.perf_counter()
-    history, best = training.fit(model, tr, val=va, test=te, epochs=args.epochs, lr=args.lr, checkpoint=args.out,
+    history, best = training.fit(model, tr, val=va, test=te, epochs=args.epochs, lr=args.lr, pre_size=args.pre_size, checkpoint=args.out,
                                  log=lambda row: print(json.dumps({k: round(v, 4) if isinstance(v, float) else v
                                                                    for k, v in row.items()}), flush=True))
     torch.cuda.synchronize()
