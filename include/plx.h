@@ -232,10 +232,13 @@ int plx_copy_point_perm(plx_lattice *lat, void *d_dst, void *stream);
 /* size in bytes of an exportable array, or -1 */
 int64_t plx_export_bytes(const plx_lattice *lat, int which);
 
-/* Select a kernel variant by name (process-wide; for A/B measurements in one
- * process -- the defaults are the shipped configuration).  Keys: "sort_points"
- * (0 keeps the caller's point order), "blur_vpt" (vertices per thread at vd=1:
- * 2 or 4; anything else selects the general kernel), "splat_ablate" (diagnostics). */
+/* Select a kernel variant by name (process-wide, not synchronised with running builds / MVMs: for A/B measurements
+ * in one process -- the defaults are the shipped configuration).  Keys (default): "sort_points" (1; 0 keeps the
+ * caller's point order), "order_zcurve" (1; 0 = lexicographic point order), "insert_dedupe" (1), "nbr_symmetric" (1),
+ * "compact_nbr" (1 = when under half of the neighbour slots exist; 0 never, 2 always), "blur_vpt" (4; vertices per
+ * thread at vd = 1: 2 or 4, anything else selects the general kernel), "blur_small" (1), "blur_narrow" (1),
+ * "blur_multi" (1), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1), and the diagnostic
+ * "splat_ablate" / "blur_ablate" (0).  Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);
 
 /* Per-stage device time of the last plx_build on this lattice, in ms, in the
