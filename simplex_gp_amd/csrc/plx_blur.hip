@@ -1,0 +1,433 @@
+// plx_blur.hip -- the blur kernels of the per-MVM path: d+1 gather-accumulate passes over the precomputed neighbour table.  Reference: h:513-572.
+// Overview of the per-MVM path, value-row layout and shared helpers: plx_kernels.h.
+
+#include "plx_kernels.h"
+
+namespace plx {
+
+// ----------------------------------------------------------------------------
+// blur: one Jacobi pass along one lattice axis,
+//   out[i] = sum_{nid=-r..r} c[nid+r] * old[nbr(i, nid)]      (h:539-549)
+// accumulated from zero in tap order like the reference.
+
+// vd == 1: VPT consecutive vertices per thread, 4*VPT-byte loads from every plane
+template <int ORDER, int VPT>
+__global__ __launch_bounds__(kBlock) void blur_axis_v1_kernel(const float *__restrict__ old,
+                                                              float *__restrict__ out,
+                                                              const int *__restrict__ nbr, int m,
+                                                              int64_t mstride, TapArgs taps, int ablate, int ntiles,
+                                                              int remap)
+{
+    using ivec = typename std::conditional<VPT == 4, int4, int2>::type;
+    using fvec = typename std::conditional<VPT == 4, float4, float2>::type;
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int i0 = (tile * kBlock + threadIdx.x) * VPT;
+    if (i0 >= m) return;
+    if (i0 + VPT <= m) {
+        int nb[2 * ORDER][VPT];
+#pragma unroll
+        for (int s = 0; s < 2 * ORDER; ++s) {
+            ivec v;
+            if (ablate & 2) { int *q = reinterpret_cast<int *>(&v); for (int j = 0; j < VPT; ++j) q[j] = i0 + j; }
+            else v = *reinterpret_cast<const ivec *>(nbr + s * mstride + i0);
+            const int *pv = reinterpret_cast<const int *>(&v);
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) nb[s][j] = pv[j];
+        }
+        const fvec cv = *reinterpret_cast<const fvec *>(old + i0);
+        const float *pc = reinterpret_cast<const float *>(&cv);
+        float g[2 * ORDER][VPT];
+#pragma unroll
+        for (int s = 0; s < 2 * ORDER; ++s)
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) g[s][j] = nb[s][j] >= 0 ? ((ablate & 1) ? (float)nb[s][j] : old[nb[s][j]]) : 0.f;
+        fvec res;
+        float *pr = reinterpret_cast<float *>(&res);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < ORDER; ++s) acc += taps.c[s] * g[s][j];
+            acc += taps.c[ORDER] * pc[j];
+#pragma unroll
+            for (int s = 0; s < ORDER; ++s) acc += taps.c[ORDER + 1 + s] * g[ORDER + s][j];
+            pr[j] = acc;
+        }
+        *reinterpret_cast<fvec *>(out + i0) = res;
+    } else {
+        for (int i = i0; i < m; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < ORDER; ++s) {
+                const int nbi = nbr[s * mstride + i];
+                acc += taps.c[s] * (nbi >= 0 ? old[nbi] : 0.f);
+            }
+            acc += taps.c[ORDER] * old[i];
+#pragma unroll
+            for (int s = 0; s < ORDER; ++s) {
+                const int nbi = nbr[(ORDER + s) * mstride + i];
+                acc += taps.c[ORDER + 1 + s] * (nbi >= 0 ? old[nbi] : 0.f);
+            }
+            out[i] = acc;
+        }
+    }
+}
+
+// vd == 1 on a sparse lattice: the same pass over the COMPACTED neighbour table.  A thread
+// owns a quad of 4 vertices; its existing neighbour ids start at
+//   cbase[wave] + (sum of popcount(mask) over the lower lanes of the wave)
+// so a wave reads one contiguous run of ids instead of 2r full planes that are mostly -1.
+// inclusive prefix sum over the 64 lanes of a wave with DPP adds only (row_shr inside rows of 16,
+// row_bcast:15 / row_bcast:31 across rows): 6 vector instructions, no LDS crossbar round trips
+__device__ __forceinline__ int wave_inclusive_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1, shifted-in lanes read 0
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+template <int ORDER>
+__global__ __launch_bounds__(kBlock) void blur_axis_compact_kernel(const float *__restrict__ old,
+                                                                   float *__restrict__ out,
+                                                                   const uint32_t *__restrict__ cmask,
+                                                                   const uint32_t *__restrict__ cbase,
+                                                                   const int *__restrict__ cids, int m,
+                                                                   uint32_t nquads, TapArgs taps)
+{
+    constexpr int T2 = 2 * ORDER;
+    // 32-bit indices throughout (m < 2^31, at most (d+1) * 2r * m < 2^32 ids is checked by the caller):
+    // addresses are scalar base + 32-bit lane offset, no 64-bit vector arithmetic
+    const uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = q < nquads;
+    const uint32_t mask = live ? cmask[q] : 0u;
+    const int cnt = __popc(mask);
+    const int incl = wave_inclusive_sum(cnt);
+    if (!live) return;
+    uint32_t pos = cbase[q >> 6] + (uint32_t)(incl - cnt);
+    const uint32_t i0 = q * 4u;
+    const bool full = i0 + 4u <= (uint32_t)m;
+    // Only the existing neighbours are loaded: on the sparse lattices this kernel is for, 80-90 % of
+    // the slots are empty, and issuing their loads anyway (branch-free) was measured 30 % slower.
+    uint32_t nb[4][T2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < T2; ++s) {
+            const bool has = (mask >> (j * T2 + s)) & 1u;
+            nb[j][s] = has ? (uint32_t)cids[pos] : 0xFFFFFFFFu;
+            pos += has ? 1u : 0u;
+        }
+    float g[4][T2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int s = 0; s < T2; ++s) g[j][s] = nb[j][s] != 0xFFFFFFFFu ? old[nb[j][s]] : 0.f;
+    float c[4];
+    if (full) {
+        const float4 cv = *reinterpret_cast<const float4 *>(old + i0);
+        c[0] = cv.x; c[1] = cv.y; c[2] = cv.z; c[3] = cv.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = (i0 + j < (uint32_t)m) ? old[i0 + j] : 0.f;
+    }
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < ORDER; ++s) acc += taps.c[s] * g[j][s];
+        acc += taps.c[ORDER] * c[j];
+#pragma unroll
+        for (int s = 0; s < ORDER; ++s) acc += taps.c[ORDER + 1 + s] * g[j][ORDER + s];
+        r[j] = acc;
+    }
+    if (full) {
+        *reinterpret_cast<float4 *>(out + i0) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < (uint32_t)m) out[i0 + j] = r[j];
+    }
+}
+
+// vd == 1 on a lattice so small that both ping-pong copies of the vertex values fit in LDS (m <= kSmallM): every
+// pass is launch-bound there (a few us of host + device launch cost for < 1 us of work), so ONE workgroup runs all
+// d+1 passes with a barrier between them.  Same tap order as the per-axis kernels: bit-identical results.
+constexpr int kSmallM = 16384;
+
+template <int ORDER>
+__global__ __launch_bounds__(1024) void blur_small_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                          const int *__restrict__ nbr, int m, int64_t mstride,
+                                                          int d1, TapArgs taps)
+{
+    __shared__ float buf[2][kSmallM];
+    for (int i = threadIdx.x; i < m; i += 1024) buf[0][i] = in[i];
+    __syncthreads();
+    int cur = 0;
+    for (int axis = 0; axis < d1; ++axis) {
+        const int *nb = nbr + (size_t)axis * 2 * ORDER * mstride;
+        for (int i = threadIdx.x; i < m; i += 1024) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < ORDER; ++s) {
+                const int j = nb[s * mstride + i];
+                acc += taps.c[s] * (j >= 0 ? buf[cur][j] : 0.f);
+            }
+            acc += taps.c[ORDER] * buf[cur][i];
+#pragma unroll
+            for (int s = 0; s < ORDER; ++s) {
+                const int j = nb[(ORDER + s) * mstride + i];
+                acc += taps.c[ORDER + 1 + s] * (j >= 0 ? buf[cur][j] : 0.f);
+            }
+            buf[cur ^ 1][i] = acc;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int i = threadIdx.x; i < m; i += 1024) out[i] = buf[cur][i];
+}
+
+// general: one thread per (vertex, value element).  V = float handles any order at
+// vd = 1; V = float4 handles vd > 1 with rowlen = vdp/4 chunks per vertex (lanes of
+// one vertex read the same neighbour id and adjacent 16-byte chunks).
+template <class V, int ORDER>   // ORDER 0 = runtime order
+__global__ __launch_bounds__(kBlock) void blur_axis_kernel(const V *__restrict__ old, V *__restrict__ out,
+                                                           const int *__restrict__ nbr, int m, int64_t mstride,
+                                                           int rowlen, int order_rt, TapArgs taps, int ntiles, int remap,
+                                                           int ablate)
+{
+    using O = VecOps<V>;
+    const int order = ORDER > 0 ? ORDER : order_rt;
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    // 32-bit index arithmetic: a 64-bit division costs more VALU time than the whole rest of the thread
+    // (blur_impl checks m * rowlen < 2^31)
+    const uint32_t item = (uint32_t)tile * kBlock + threadIdx.x;
+    if (item >= (uint32_t)m * (uint32_t)rowlen) return;
+    const uint32_t iu = item / (uint32_t)rowlen;
+    const int i = (int)iu, ch = (int)(item - iu * (uint32_t)rowlen);
+    V acc = O::zero();
+#pragma unroll
+    for (int s = 0; s < order; ++s) {
+        const int nb = nbr[s * mstride + i];
+        if (nb >= 0) acc = O::add(acc, O::scale(taps.c[s], old[(ablate & 1) ? (size_t)item : (size_t)nb * rowlen + ch]));
+    }
+    acc = O::add(acc, O::scale(taps.c[order], old[item]));
+#pragma unroll
+    for (int s = 0; s < order; ++s) {
+        const int nb = nbr[(order + s) * mstride + i];
+        if (nb >= 0) acc = O::add(acc, O::scale(taps.c[order + 1 + s], old[(ablate & 1) ? (size_t)item : (size_t)nb * rowlen + ch]));
+    }
+    out[item] = acc;
+}
+
+// vd 2..16 (rows of 1..4 chunks, every CG iteration): the general kernel with the row length a
+// compile-time constant (the division by 3 alone made a 3-chunk pass slower per byte than a 2-chunk one),
+// 32-bit element indices (scalar base + 32-bit lane offset addressing) and no branches: an absent
+// neighbour re-reads the centre chunk and is dropped by a select.
+template <int ORDER, int ROWLEN>
+__global__ __launch_bounds__(kBlock) void blur_axis_narrow_kernel(const float4 *__restrict__ old, float4 *__restrict__ out,
+                                                                  const int *__restrict__ nbr, uint32_t total,
+                                                                  uint32_t mstride, TapArgs taps, int ntiles, int remap)
+{
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const uint32_t item = (uint32_t)tile * kBlock + threadIdx.x;
+    if (item >= total) return;
+    const uint32_t i = item / ROWLEN, ch = item - i * ROWLEN;
+    int nb[2 * ORDER];
+#pragma unroll
+    for (int s = 0; s < 2 * ORDER; ++s) nb[s] = nbr[(uint32_t)s * mstride + i];
+    const float4 c = old[item];
+    float4 g[2 * ORDER];
+#pragma unroll
+    for (int s = 0; s < 2 * ORDER; ++s) g[s] = old[nb[s] >= 0 ? (uint32_t)nb[s] * ROWLEN + ch : item];
+    float4 acc = f4_zero();
+#pragma unroll
+    for (int s = 0; s < ORDER; ++s) acc = f4_sel(nb[s] >= 0, f4_add(acc, f4_scale(taps.c[s], g[s])), acc);
+    acc = f4_add(acc, f4_scale(taps.c[ORDER], c));
+#pragma unroll
+    for (int s = 0; s < ORDER; ++s)
+        acc = f4_sel(nb[ORDER + s] >= 0, f4_add(acc, f4_scale(taps.c[ORDER + 1 + s], g[ORDER + s])), acc);
+    out[item] = acc;
+}
+
+template <int ORDER>
+static void launch_blur_narrow(const float4 *cur, float4 *nxt, const int *nb, int m, int64_t mstride, int rowlen,
+                               const TapArgs &taps, hipStream_t stream, int remap)
+{
+    const uint32_t total = (uint32_t)m * (uint32_t)rowlen;
+    const int nt = ceil_div((int64_t)total, kBlock);
+    const int grid = tile_grid(nt, remap);
+    switch (rowlen) {
+    case 1: blur_axis_narrow_kernel<ORDER, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, total, (uint32_t)mstride, taps, nt, remap); break;
+    case 2: blur_axis_narrow_kernel<ORDER, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, total, (uint32_t)mstride, taps, nt, remap); break;
+    case 3: blur_axis_narrow_kernel<ORDER, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, total, (uint32_t)mstride, taps, nt, remap); break;
+    default: blur_axis_narrow_kernel<ORDER, 4><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, total, (uint32_t)mstride, taps, nt, remap); break;
+    }
+}
+
+// vd > 1, the shipped kernel: IPT (vertex, chunk) items per thread, 256 apart, so that a thread has
+// all its id loads and centre chunks in flight, then all its gathers, then its stores (one item per
+// thread streamed at 4.0-4.6 TB/s with the gathers switched off, a copy kernel reaches 6.3).  The
+// vertex / chunk of the next item follow from the previous one without a division.
+template <int ORDER, int IPT>
+__global__ __launch_bounds__(kBlock) void blur_axis_multi_kernel(const float4 *__restrict__ old, float4 *__restrict__ out,
+                                                                 const int *__restrict__ nbr, int m, int64_t mstride,
+                                                                 int rowlen, TapArgs taps, int ntiles, int remap)
+{
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const uint32_t total = (uint32_t)m * (uint32_t)rowlen;
+    const uint32_t item0 = (uint32_t)tile * (kBlock * IPT) + threadIdx.x;
+    const uint32_t q256 = (uint32_t)kBlock / (uint32_t)rowlen, r256 = (uint32_t)kBlock - q256 * (uint32_t)rowlen;   // uniform
+    uint32_t i = item0 / (uint32_t)rowlen, ch = item0 - i * (uint32_t)rowlen;
+    uint32_t item[IPT], src[IPT][2 * ORDER];
+    bool live[IPT], have[IPT][2 * ORDER];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        item[k] = item0 + (uint32_t)k * kBlock;
+        live[k] = item[k] < total;
+        const uint32_t ii = live[k] ? i : 0u;
+#pragma unroll
+        for (int s = 0; s < 2 * ORDER; ++s) {
+            const int nb = nbr[s * mstride + ii];
+            have[k][s] = live[k] && nb >= 0;
+            src[k][s] = have[k][s] ? (uint32_t)nb * (uint32_t)rowlen + ch : (live[k] ? item[k] : 0u);   // absent: re-read the centre
+        }
+        ch += r256;
+        i += q256;
+        if (ch >= (uint32_t)rowlen) { ch -= (uint32_t)rowlen; i += 1; }
+    }
+    float4 c[IPT], g[IPT][2 * ORDER];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) c[k] = old[live[k] ? item[k] : 0u];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k)
+#pragma unroll
+        for (int s = 0; s < 2 * ORDER; ++s) g[k][s] = old[src[k][s]];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        float4 acc = f4_zero();
+#pragma unroll
+        for (int s = 0; s < ORDER; ++s)
+            if (have[k][s]) acc = f4_add(acc, f4_scale(taps.c[s], g[k][s]));
+        acc = f4_add(acc, f4_scale(taps.c[ORDER], c[k]));
+#pragma unroll
+        for (int s = 0; s < ORDER; ++s)
+            if (have[k][ORDER + s]) acc = f4_add(acc, f4_scale(taps.c[ORDER + 1 + s], g[k][ORDER + s]));
+        if (live[k]) out[item[k]] = acc;
+    }
+}
+
+template <int ORDER>
+static void launch_blur_v1(const float *cur, float *nxt, const int *nb, int m, int64_t mstride, const TapArgs &taps,
+                           hipStream_t stream)
+{
+    const int nt4 = ceil_div(ceil_div(m, 4), kBlock), nt2 = ceil_div(ceil_div(m, 2), kBlock);
+    if (g_blur_vpt == 4)
+        blur_axis_v1_kernel<ORDER, 4><<<tile_grid(nt4, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate, nt4, g_xcd_remap);
+    else
+        blur_axis_v1_kernel<ORDER, 2><<<tile_grid(nt2, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate, nt2, g_xcd_remap);
+}
+
+template <class V>
+static void launch_blur_general(const V *cur, V *nxt, const int *nb, int m, int64_t mstride, int rowlen, int order,
+                                const TapArgs &taps, hipStream_t stream)
+{
+    const int nt = ceil_div((int64_t)m * rowlen, kBlock);
+    const int grid = tile_grid(nt, g_xcd_remap);
+    switch (order) {
+    case 1: blur_axis_kernel<V, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
+    case 2: blur_axis_kernel<V, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
+    case 3: blur_axis_kernel<V, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
+    default: blur_axis_kernel<V, 0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
+    }
+}
+
+int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
+              hipStream_t stream)
+{
+    const int m = (int)L->m, d1 = L->d + 1, order = L->order;
+    const int vdp = values_stride(vd);
+    const bool v1 = (vd == 1 && order >= 1 && order <= 3 && (g_blur_vpt == 2 || g_blur_vpt == 4));
+    if (v1 && m <= kSmallM && g_blur_small) {
+        // result goes where the per-axis path would leave it, so callers see no difference
+        float *dst = (d1 & 1) ? d_scratch : d_values;
+        const int *nb = L->nbr.as<int>();
+        switch (order) {
+        case 1: blur_small_kernel<1><<<1, 1024, 0, stream>>>(d_values, dst, nb, m, L->mstride, d1, L->taps); break;
+        case 2: blur_small_kernel<2><<<1, 1024, 0, stream>>>(d_values, dst, nb, m, L->mstride, d1, L->taps); break;
+        default: blur_small_kernel<3><<<1, 1024, 0, stream>>>(d_values, dst, nb, m, L->mstride, d1, L->taps); break;
+        }
+        tmark(L, stream);
+        *result_in_scratch = (d1 & 1) ? 1 : 0;
+        PLX_HIP_TRY(hipGetLastError());
+        return PLX_OK;
+    }
+    if ((int64_t)m * (vdp > 1 ? vdp / 4 : 1) >= (1ll << 31)) {
+        set_error("blur: %d vertices x %d columns exceed the 31-bit element index of the blur kernels", m, vd);
+        return PLX_ERR_TOO_LARGE;
+    }
+    float *cur = d_values, *nxt = d_scratch;
+    for (int axis = 0; axis < d1; ++axis) {
+        const int *nb = L->nbr.as<int>() + (size_t)axis * 2 * order * L->mstride;
+        if (v1 && L->use_compact) {
+            const uint32_t *cm = L->cmask.as<uint32_t>() + (size_t)axis * L->nquads;
+            const uint32_t *cb = L->cbase.as<uint32_t>() + (size_t)axis * (L->nqwaves + 1);
+            const int *ci = L->cids.as<int>() + L->compact_off[axis];
+            const int grid = ceil_div(L->nqwaves * 64, kBlock);
+            switch (order) {
+            case 1: blur_axis_compact_kernel<1><<<grid, kBlock, 0, stream>>>(cur, nxt, cm, cb, ci, m, (uint32_t)L->nquads, L->taps); break;
+            case 2: blur_axis_compact_kernel<2><<<grid, kBlock, 0, stream>>>(cur, nxt, cm, cb, ci, m, (uint32_t)L->nquads, L->taps); break;
+            default: blur_axis_compact_kernel<3><<<grid, kBlock, 0, stream>>>(cur, nxt, cm, cb, ci, m, (uint32_t)L->nquads, L->taps); break;
+            }
+        } else if (v1) {
+            switch (order) {
+            case 1: launch_blur_v1<1>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
+            case 2: launch_blur_v1<2>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
+            default: launch_blur_v1<3>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
+            }
+        } else if (vd == 1) {
+            launch_blur_general<float>(cur, nxt, nb, m, L->mstride, 1, order, L->taps, stream);
+        } else if (order >= 1 && order <= 3 && vdp / 4 <= 4 && g_blur_narrow && (int64_t)d1 * 2 * order * L->mstride < (1ll << 32)) {
+            const float4 *c4 = reinterpret_cast<const float4 *>(cur);
+            float4 *n4 = reinterpret_cast<float4 *>(nxt);
+            // nb is already offset to this axis: plane offsets inside the kernel stay below 2 * order * mstride
+            switch (order) {
+            case 1: launch_blur_narrow<1>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
+            case 2: launch_blur_narrow<2>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
+            default: launch_blur_narrow<3>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
+            }
+        } else if (order >= 1 && order <= 3 && g_blur_multi && vdp / 4 >= 32) {   // narrower rows: no gain (vd 2..16 measured 0-30 % slower)
+            constexpr int IPT = 4;
+            const int rowlen = vdp / 4;
+            const int nt = ceil_div((int64_t)m * rowlen, kBlock * IPT);
+            // wide rows stream far more than they gather: plain tile order is 8 % faster there
+            const int remap = 0;
+            const int grid = tile_grid(nt, remap);
+            const float4 *c4 = reinterpret_cast<const float4 *>(cur);
+            float4 *n4 = reinterpret_cast<float4 *>(nxt);
+            switch (order) {
+            case 1: blur_axis_multi_kernel<1, IPT><<<grid, kBlock, 0, stream>>>(c4, n4, nb, m, L->mstride, rowlen, L->taps, nt, remap); break;
+            case 2: blur_axis_multi_kernel<2, IPT><<<grid, kBlock, 0, stream>>>(c4, n4, nb, m, L->mstride, rowlen, L->taps, nt, remap); break;
+            default: blur_axis_multi_kernel<3, IPT><<<grid, kBlock, 0, stream>>>(c4, n4, nb, m, L->mstride, rowlen, L->taps, nt, remap); break;
+            }
+        } else {
+            launch_blur_general<float4>(reinterpret_cast<const float4 *>(cur), reinterpret_cast<float4 *>(nxt), nb, m,
+                                        L->mstride, vdp / 4, order, L->taps, stream);
+        }
+        float *t = cur; cur = nxt; nxt = t;
+    }
+    tmark(L, stream);
+    *result_in_scratch = (cur == d_scratch) ? 1 : 0;
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+}  // namespace plx

@@ -134,7 +134,7 @@ int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t 
 int sort_pairs64_temp_bytes(int64_t n, int end_bit, size_t *bytes);
 int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                  const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit, hipStream_t stream);
-// plx_apply.hip
+// plx_splat.hip / plx_blur.hip / plx_slice.hip
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream);
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
@@ -142,6 +142,10 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
                const float *d_affine = nullptr, const float *d_src = nullptr);
 int backward_impl(plx_lattice *L, const float *d_g, const float *d_src, const float *d_x, int nrhs, float *d_grad_x,
                   float *d_grad_src, hipStream_t stream);
+int splat_stack_impl(plx_lattice *L, const float *d_g, const float *d_src, const float *d_x, int nrhs, float *d_values,
+                     hipStream_t stream);
+// floats per packed (g, src, x, 0, 1) record of the fused position gradient, a whole number of 16-byte vectors
+inline int backward_record_width(int nrhs, int d) { return (2 * nrhs + d + 2 + 3) & ~3; }
 
 // record the next apply-timing event (no-op unless timing is on)
 inline void tmark(plx_lattice *L, hipStream_t stream)

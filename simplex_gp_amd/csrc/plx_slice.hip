@@ -1,0 +1,238 @@
+// plx_slice.hip -- the slice kernels of the per-MVM path (h:497-510) and the fused position gradient (py:113-123).
+// Overview of the per-MVM path, value-row layout and shared helpers: plx_kernels.h.
+
+#include "plx_kernels.h"
+
+namespace plx {
+
+// ----------------------------------------------------------------------------
+// slice: out[row(p)][c] = sum_r w_r * values[v_r][c] / (1 + 2^-d)     (h:502-509)
+// p runs in lattice order; the result is scattered to the caller's row order.  The reference divides
+// every term; here every term is multiplied by the rounded reciprocal rden = 1 / (1 + 2^-d): an fp32
+// division is ~10 vector instructions, and 4(d+1) of them per thread were over half of the multi-column
+// kernel's instruction stream (vd = 11 slice 101 -> 75 us).  The two differ by <= 1 ulp per term.
+
+// vd == 1: all d+1 (id, weight) loads first, then all gathers, then the ordered sum
+template <int D1>
+__global__ __launch_bounds__(kBlock) void slice_v1_kernel(const int *__restrict__ evid,
+                                                          const float *__restrict__ ew,
+                                                          const uint32_t *__restrict__ perm, int n, int own_begin,
+                                                          int n_own, const float *__restrict__ values, float rden,
+                                                          float *__restrict__ out, int ntiles, int remap,
+                                                          const float *__restrict__ affine, const float *__restrict__ src)
+{
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int pl = tile * kBlock + threadIdx.x;
+    if (pl >= n_own) return;
+    const int p = own_begin + pl;
+    int v[D1];
+    float w[D1], g[D1];
+#pragma unroll
+    for (int r = 0; r < D1; ++r) {
+        v[r] = evid[(size_t)r * n + p];
+        w[r] = ew[(size_t)r * n + p];
+    }
+    const int row = perm ? (int)perm[p] - own_begin : pl;
+#pragma unroll
+    for (int r = 0; r < D1; ++r) g[r] = values[v[r]];
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < D1; ++r) acc += w[r] * g[r] * rden;
+    if (affine) acc = affine[0] * acc + affine[1] * src[row];      // out = a K src + b src (plx_apply_affine)
+    out[row] = acc;
+}
+
+// vd > 1: one thread per (point, 16-byte chunk)
+__global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict__ evid,
+                                                           const float *__restrict__ ew,
+                                                           const uint32_t *__restrict__ perm, int n, int own_begin,
+                                                           int n_own, int d1, const float4 *__restrict__ values,
+                                                           int nch, int vd, float rden, float *__restrict__ out,
+                                                           int ntiles, int remap, const float *__restrict__ affine,
+                                                           const float *__restrict__ src)
+{
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int64_t item = (int64_t)tile * kBlock + threadIdx.x;
+    if (item >= (int64_t)n_own * nch) return;
+    const int pl = (int)(item / nch), ch = (int)(item - (int64_t)pl * nch);
+    const int p = own_begin + pl;
+    float4 acc = f4_zero();
+    for (int r = 0; r < d1; ++r) {
+        const int v = evid[(size_t)r * n + p];
+        const float w = ew[(size_t)r * n + p];
+        const float4 g = values[(size_t)v * nch + ch];
+        acc.x += w * g.x * rden; acc.y += w * g.y * rden; acc.z += w * g.z * rden; acc.w += w * g.w * rden;
+    }
+    const size_t row = perm ? (size_t)((int)perm[p] - own_begin) : (size_t)pl;
+    float *o = out + row * vd + 4 * ch;
+    const int left = vd - 4 * ch;
+    if (affine) {
+        const float a = affine[0], b = affine[1];
+        const float *sp = src + row * vd + 4 * ch;
+        acc.x = a * acc.x + b * sp[0];
+        if (left > 1) acc.y = a * acc.y + b * sp[1];
+        if (left > 2) acc.z = a * acc.z + b * sp[2];
+        if (left > 3) acc.w = a * acc.w + b * sp[3];
+    }
+    if (left >= 4 && (vd & 3) == 0) {
+        *reinterpret_cast<float4 *>(o) = acc;
+    } else {
+        o[0] = acc.x;
+        if (left > 1) o[1] = acc.y;
+        if (left > 2) o[2] = acc.z;
+        if (left > 3) o[3] = acc.w;
+    }
+}
+
+int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream, const float *d_affine,
+               const float *d_src)
+{
+    const int n_own = (int)(L->own_end - L->own_begin);
+    if (n_own == 0) return PLX_OK;
+    const int *evid = L->evid.as<int>();
+    const float *ew = L->ew.as<float>();
+    const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
+    const int n = (int)L->n, ob = (int)L->own_begin;
+    if (vd == 1) {
+        const int nt = ceil_div(n_own, kBlock);
+        const int grid = tile_grid(nt, g_xcd_remap);
+        switch (L->d + 1) {
+#define PLX_CASE(D1) \
+    case D1: slice_v1_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, d_values, 1.0f / L->slice_denom, d_out, nt, g_xcd_remap, d_affine, d_src); break;
+            PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9)
+            PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17)
+            PLX_CASE(18) PLX_CASE(19) PLX_CASE(20) PLX_CASE(21) PLX_CASE(22) PLX_CASE(23) PLX_CASE(24) PLX_CASE(25)
+            PLX_CASE(26) PLX_CASE(27) PLX_CASE(28) PLX_CASE(29) PLX_CASE(30) PLX_CASE(31) PLX_CASE(32) PLX_CASE(33)
+#undef PLX_CASE
+        }
+    } else {
+        const int nch = values_stride(vd) / 4;
+        const int nt = ceil_div((int64_t)n_own * nch, kBlock);
+        slice_vec_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
+            evid, ew, perm, n, ob, n_own, L->d + 1, reinterpret_cast<const float4 *>(d_values), nch, vd,
+            1.0f / L->slice_denom, d_out, nt, g_xcd_remap, d_affine, d_src);
+    }
+    tmark(L, stream);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// fused position gradient (py:113-123): splat of the stacked matrix straight from
+// the packed records, the usual blur, then slice and contraction in one kernel --
+// neither the stacked matrix nor its filtered image ever reach memory.
+
+// One wave per point: the lanes slice the point's 2L(1+d) filtered columns (same arithmetic as
+// slice_vec_kernel), park them in LDS, then lane k < d forms
+//   grad_x[k] = -2 sum_l ( s_l x_k wg_l - s_l wgx_{l,k} + g_l x_k ws_l - g_l wsx_{l,k} )      (py:122)
+// and lane l < L stores grad_src[l] = wg_l (py:123).
+template <int MAXCH>
+__global__ __launch_bounds__(kBlock) void slice_contract_kernel(const int *__restrict__ evid, const float *__restrict__ ew,
+                                                                const uint32_t *__restrict__ perm, int n, int own_begin,
+                                                                int n_own, int d1, const float4 *__restrict__ values,
+                                                                int nch, const float *__restrict__ rec, int recw, int L,
+                                                                int d, float rden, float *__restrict__ grad_x,
+                                                                float *__restrict__ grad_src, int ntiles, int remap)
+{
+    __shared__ float4 f4s[kBlock / 64][64 * MAXCH];
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl = tile * (kBlock / 64) + wave;
+    if (pl >= n_own) return;                       // whole waves leave together; no workgroup barrier below
+    const int p = own_begin + pl;
+    float4 acc[MAXCH];
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) acc[q] = f4_zero();
+    int my_v = 0;
+    float my_w = 0.f;
+    if (lane < d1) { my_v = evid[(size_t)lane * n + p]; my_w = ew[(size_t)lane * n + p]; }   // d1 <= 33 < 64
+    int r = 0;
+    for (; r + 3 <= d1; r += 3) {
+        float4 gq[3][MAXCH];
+        float w[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int v = __shfl(my_v, r + u);
+            w[u] = __shfl(my_w, r + u);
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q)
+                gq[u][q] = (lane + 64 * q < nch) ? values[(size_t)v * nch + lane + 64 * q] : f4_zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int q = 0; q < MAXCH; ++q) {
+                acc[q].x += w[u] * gq[u][q].x * rden; acc[q].y += w[u] * gq[u][q].y * rden;
+                acc[q].z += w[u] * gq[u][q].z * rden; acc[q].w += w[u] * gq[u][q].w * rden;
+            }
+    }
+    for (; r < d1; ++r) {
+        const int v = __shfl(my_v, r);
+        const float w = __shfl(my_w, r);
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const int ch = lane + 64 * q;
+            if (ch < nch) {
+                const float4 gq = values[(size_t)v * nch + ch];
+                acc[q].x += w * gq.x * rden; acc[q].y += w * gq.y * rden;
+                acc[q].z += w * gq.z * rden; acc[q].w += w * gq.w * rden;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) f4s[wave][lane + 64 * q] = acc[q];
+    __builtin_amdgcn_wave_barrier();               // the LDS row is private to this wave
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the ds_writes above have landed
+    const float *f = reinterpret_cast<const float *>(f4s[wave]);
+    const float *rp = rec + (size_t)pl * recw;
+    const size_t row = perm ? (size_t)((int)perm[p] - own_begin) : (size_t)pl;
+    const int half = L * (1 + d);
+    if (lane < d) {
+        const float xk = rp[2 * L + lane];
+        float a = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const float sv = rp[L + l], gv = rp[l];
+            a += sv * xk * f[l] - sv * f[L + l * d + lane] + gv * xk * f[half + l] - gv * f[half + L + l * d + lane];
+        }
+        grad_x[row * d + lane] = -2.0f * a;
+    }
+    if (grad_src)
+        for (int l = lane; l < L; l += 64) grad_src[row * L + l] = f[l];
+}
+
+int backward_impl(plx_lattice *lat, const float *d_g, const float *d_src, const float *d_x, int L, float *d_grad_x,
+                  float *d_grad_src, hipStream_t stream)
+{
+    const int d = lat->d, W = 2 * L * (1 + d), vdp = values_stride(W), nch = vdp / 4;
+    const int n_own = (int)(lat->own_end - lat->own_begin);
+    const int recw = backward_record_width(L, d);
+    PLX_TRY(ensure(lat->val_a, (size_t)lat->m * vdp * 4));
+    PLX_TRY(ensure(lat->val_b, (size_t)lat->m * vdp * 4));
+    float *va = lat->val_a.as<float>(), *vb = lat->val_b.as<float>();
+    lat->tev_n = 0;
+    tmark(lat, stream);
+    PLX_TRY(splat_stack_impl(lat, d_g, d_src, d_x, L, va, stream));      // pack + splat of the never-stored stack
+    int in_b = 0;
+    PLX_TRY(blur_impl(lat, va, vb, W, &in_b, stream));
+    const float4 *res = reinterpret_cast<const float4 *>(in_b ? vb : va);
+    const uint32_t *perm = lat->lattice_rows ? nullptr : lat->perm.as<uint32_t>();
+    const float *rec = lat->rec.as<float>();
+    const int nt = ceil_div(n_own, kBlock / 64);
+    const int sgrid = tile_grid(nt, g_xcd_remap);
+    if (nch <= 64)
+        slice_contract_kernel<1><<<sgrid, kBlock, 0, stream>>>(lat->evid.as<int>(), lat->ew.as<float>(), perm, (int)lat->n,
+                                                              (int)lat->own_begin, n_own, d + 1, res, nch, rec, recw, L, d,
+                                                              1.0f / lat->slice_denom, d_grad_x, d_grad_src, nt, g_xcd_remap);
+    else
+        slice_contract_kernel<2><<<sgrid, kBlock, 0, stream>>>(lat->evid.as<int>(), lat->ew.as<float>(), perm, (int)lat->n,
+                                                              (int)lat->own_begin, n_own, d + 1, res, nch, rec, recw, L, d,
+                                                              1.0f / lat->slice_denom, d_grad_x, d_grad_src, nt, g_xcd_remap);
+    tmark(lat, stream);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+}  // namespace plx
