@@ -545,6 +545,9 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     } else if (vd == 1) {
         gather_in_v1_kernel<<<ceil_div(n_own, kBlock), kBlock, 0, stream>>>(d_src, perm, (int)L->own_begin, n_own,
                                                                             L->ssrc.as<float>());
+    } else if (L->lattice_rows && vd == vdp && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0) {
+        // rows already in lattice order and whole 16-byte vectors: splat straight from the caller's buffer
+        ss = d_src;
     } else {
         gather_in_kernel<<<ceil_div((int64_t)n_own * vdp, kBlock), kBlock, 0, stream>>>(
             d_src, perm, (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());

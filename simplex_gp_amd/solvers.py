@@ -373,7 +373,20 @@ class LatticeGP(nn.Module):
                     lat.set_lattice_row_order(False)
                     return batched_cg(lambda V: lat.apply(V).mul_(s).addcmul_(V, noise), rhs, **cg_args)
                 ss = torch.stack([s.detach().reshape(()), noise.detach().reshape(())]).to(torch.float32).contiguous()
-                sol, info = batched_cg(lambda V: lat.apply_affine(V, ss), lat.to_lattice_order(rhs), **cg_args)
+                # columns padded to a multiple of 4 with zero right-hand sides: rows become whole 16-byte vectors, so
+                # splat reads the CG vectors in place (no padding copy) and slice writes 16 bytes per lane; a zero
+                # column converges at once (alpha = beta = 0) and is dropped from the results
+                t = rhs.shape[1]
+                pad = (-t) % 4 if t > 1 else 0
+                rhs_l = lat.to_lattice_order(rhs)
+                if pad:
+                    rhs_l = torch.cat([rhs_l, rhs_l.new_zeros(rhs_l.shape[0], pad)], 1).contiguous()
+                sol, info = batched_cg(lambda V: lat.apply_affine(V, ss), rhs_l, **cg_args)
+                if pad:
+                    sol = sol[:, :t].contiguous()
+                    info = dict(info, residual=info["residual"][:t])
+                    if "tridiag" in info:
+                        info["tridiag"] = info["tridiag"][:t]
             finally:
                 lat.set_lattice_row_order(False)
             return lat.from_lattice_order(sol), info
