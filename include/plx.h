@@ -205,6 +205,12 @@ int plx_backward_contract(const float *d_g, const float *d_src, const float *d_x
  * solve in one call (the two scalars live in device memory so that no host synchronisation is needed to pass
  * hyper-parameters that are device tensors).  d_out must not alias d_src. */
 int plx_apply_affine(plx_lattice *lat, const float *d_src, int vd, float *d_out, const float *d_scale_shift, void *stream);
+/* plx_apply_affine that also returns d_dot[c] = <src[:, c], out[:, c]> (c < plx_values_stride(vd); padding entries are 0):
+ * the p^T A p of a CG iteration comes out of the slice kernel's registers instead of a second pass over both
+ * matrices.  2 <= vd <= 256.  d_work: plx_affine_dot_work_floats(lat, vd) floats of scratch. */
+int64_t plx_affine_dot_work_floats(const plx_lattice *lat, int vd);
+int plx_apply_affine_dot(plx_lattice *lat, const float *d_src, int vd, float *d_out, const float *d_scale_shift,
+                         float *d_dot, float *d_work, void *stream);
 /* One batched-CG iteration's vector work with the coefficients formed on the device (all small arrays are float [vd],
  * `active` holds 1.0 / 0.0):
  *   plx_cg_step_update:    alpha = active ? rs / max(pAp, tiny) : 0;  X += alpha P;  R -= alpha AP;  rs_new = |R|^2

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "plx_backward_stack": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "plx_backward_contract": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "plx_apply_affine": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
+    "plx_affine_dot_work_floats": (_i64, [_vp, _i32]),
+    "plx_apply_affine_dot": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "plx_cg_step_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "plx_cg_step_direction": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),

@@ -275,6 +275,39 @@ int plx_apply(plx_lattice *L, const float *d_src, int vd, float *d_out, void *st
     return apply_common(L, d_src, vd, d_out, nullptr, stream, "plx_apply");
 }
 
+static int affine_dot_tiles(const plx_lattice *L, int vd)
+{
+    const int64_t n_own = L->own_end - L->own_begin;
+    return ceil_div(n_own * (values_stride(vd) / 4), kBlock);
+}
+
+int64_t plx_affine_dot_work_floats(const plx_lattice *L, int vd)
+{
+    if (!L || !L->built || vd < 2 || vd > 256) return -1;
+    return (int64_t)affine_dot_tiles(L, vd) * values_stride(vd);
+}
+
+int plx_apply_affine_dot(plx_lattice *L, const float *d_src, int vd, float *d_out, const float *d_scale_shift,
+                         float *d_dot, float *d_work, void *stream)
+{
+    if (!d_scale_shift || !d_dot || !d_work) { set_error("plx_apply_affine_dot: NULL argument"); return PLX_ERR_INVALID; }
+    if (d_src == d_out) { set_error("plx_apply_affine_dot: d_out must not alias d_src"); return PLX_ERR_INVALID; }
+    if (vd < 2 || vd > 256) { set_error("plx_apply_affine_dot: vd = %d outside 2..256 (use plx_apply_affine + plx_coldot)", vd); return PLX_ERR_INVALID; }
+    PLX_TRY(check_apply(L, d_src, d_out, vd, "plx_apply_affine_dot"));
+    DeviceGuard g(L->device);
+    const int vdp = values_stride(vd);
+    PLX_TRY(ensure(L->val_a, (size_t)L->m * vdp * 4));
+    PLX_TRY(ensure(L->val_b, (size_t)L->m * vdp * 4));
+    hipStream_t s = (hipStream_t)stream;
+    L->tev_n = 0;
+    tmark(L, s);
+    PLX_TRY(splat_impl(L, d_src, vd, L->val_a.as<float>(), s));
+    int in_b = 0;
+    PLX_TRY(blur_impl(L, L->val_a.as<float>(), L->val_b.as<float>(), vd, &in_b, s));
+    PLX_TRY(slice_impl(L, in_b ? L->val_b.as<float>() : L->val_a.as<float>(), vd, d_out, s, d_scale_shift, d_src, d_work));
+    return coldot_final(d_work, affine_dot_tiles(L, vd), vdp, d_dot, s);
+}
+
 static int apply_common(plx_lattice *L, const float *d_src, int vd, float *d_out, const float *d_affine, void *stream,
                         const char *who)
 {

@@ -139,7 +139,9 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
 int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream,
-               const float *d_affine = nullptr, const float *d_src = nullptr);
+               const float *d_affine = nullptr, const float *d_src = nullptr, float *d_dot_partial = nullptr);
+// plx_linalg.hip: out[c] = sum over nblocks of partial[k * vd + c], fixed order
+int coldot_final(const float *d_partial, int nblocks, int vd, float *d_out, hipStream_t stream);
 int backward_impl(plx_lattice *L, const float *d_g, const float *d_src, const float *d_x, int nrhs, float *d_grad_x,
                   float *d_grad_src, hipStream_t stream);
 int splat_stack_impl(plx_lattice *L, const float *d_g, const float *d_src, const float *d_x, int nrhs, float *d_values,

@@ -213,6 +213,15 @@ __global__ __launch_bounds__(kBlock) void backward_contract_kernel(const float *
 
 }  // namespace plx
 
+namespace plx {
+int coldot_final(const float *d_partial, int nblocks, int vd, float *d_out, hipStream_t stream)
+{
+    coldot_final_kernel<<<vd, kBlock, 0, stream>>>(d_partial, nblocks, vd, d_out);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+}  // namespace plx
+
 using namespace plx;
 
 extern "C" int plx_backward_stack(const float *d_g, const float *d_src, const float *d_x, int64_t n, int L, int d,

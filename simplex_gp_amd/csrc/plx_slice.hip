@@ -50,44 +50,68 @@ __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict
                                                            int n_own, int d1, const float4 *__restrict__ values,
                                                            int nch, int vd, float rden, float *__restrict__ out,
                                                            int ntiles, int remap, const float *__restrict__ affine,
-                                                           const float *__restrict__ src)
+                                                           const float *__restrict__ src, float *__restrict__ dot_partial)
 {
+    __shared__ float4 red[kBlock];
     const int tile = tile_index(ntiles, remap);
-    if (tile < 0) return;
+    if (tile < 0) return;                                  // the whole workgroup leaves together
     const int64_t item = (int64_t)tile * kBlock + threadIdx.x;
-    if (item >= (int64_t)n_own * nch) return;
-    const int pl = (int)(item / nch), ch = (int)(item - (int64_t)pl * nch);
-    const int p = own_begin + pl;
-    float4 acc = f4_zero();
-    for (int r = 0; r < d1; ++r) {
-        const int v = evid[(size_t)r * n + p];
-        const float w = ew[(size_t)r * n + p];
-        const float4 g = values[(size_t)v * nch + ch];
-        acc.x += w * g.x * rden; acc.y += w * g.y * rden; acc.z += w * g.z * rden; acc.w += w * g.w * rden;
+    const bool live = item < (int64_t)n_own * nch;
+    float4 prod = f4_zero();
+    if (live) {
+        const int pl = (int)(item / nch), ch = (int)(item - (int64_t)pl * nch);
+        const int p = own_begin + pl;
+        float4 acc = f4_zero();
+        for (int r = 0; r < d1; ++r) {
+            const int v = evid[(size_t)r * n + p];
+            const float w = ew[(size_t)r * n + p];
+            const float4 g = values[(size_t)v * nch + ch];
+            acc.x += w * g.x * rden; acc.y += w * g.y * rden; acc.z += w * g.z * rden; acc.w += w * g.w * rden;
+        }
+        const size_t row = perm ? (size_t)((int)perm[p] - own_begin) : (size_t)pl;
+        float *o = out + row * vd + 4 * ch;
+        const int left = vd - 4 * ch;
+        if (affine) {
+            const float a = affine[0], b = affine[1];
+            const float *sp = src + row * vd + 4 * ch;
+            float4 sv = f4_zero();
+            sv.x = sp[0];
+            if (left > 1) sv.y = sp[1];
+            if (left > 2) sv.z = sp[2];
+            if (left > 3) sv.w = sp[3];
+            acc.x = a * acc.x + b * sv.x;
+            if (left > 1) acc.y = a * acc.y + b * sv.y;
+            if (left > 2) acc.z = a * acc.z + b * sv.z;
+            if (left > 3) acc.w = a * acc.w + b * sv.w;
+            // <src, out> per column for the CG caller (plx_apply_affine_dot); padding columns stay 0
+            prod = make_float4(sv.x * acc.x, left > 1 ? sv.y * acc.y : 0.f, left > 2 ? sv.z * acc.z : 0.f,
+                               left > 3 ? sv.w * acc.w : 0.f);
+        }
+        if (left >= 4 && (vd & 3) == 0) {
+            *reinterpret_cast<float4 *>(o) = acc;
+        } else {
+            o[0] = acc.x;
+            if (left > 1) o[1] = acc.y;
+            if (left > 2) o[2] = acc.z;
+            if (left > 3) o[3] = acc.w;
+        }
     }
-    const size_t row = perm ? (size_t)((int)perm[p] - own_begin) : (size_t)pl;
-    float *o = out + row * vd + 4 * ch;
-    const int left = vd - 4 * ch;
-    if (affine) {
-        const float a = affine[0], b = affine[1];
-        const float *sp = src + row * vd + 4 * ch;
-        acc.x = a * acc.x + b * sp[0];
-        if (left > 1) acc.y = a * acc.y + b * sp[1];
-        if (left > 2) acc.z = a * acc.z + b * sp[2];
-        if (left > 3) acc.w = a * acc.w + b * sp[3];
-    }
-    if (left >= 4 && (vd & 3) == 0) {
-        *reinterpret_cast<float4 *>(o) = acc;
-    } else {
-        o[0] = acc.x;
-        if (left > 1) o[1] = acc.y;
-        if (left > 2) o[2] = acc.z;
-        if (left > 3) o[3] = acc.w;
+    if (dot_partial) {
+        // one partial sum per (workgroup, column), added in thread order: reproducible
+        red[threadIdx.x] = prod;
+        __syncthreads();
+        if ((int)threadIdx.x < 4 * nch) {
+            const int ch = threadIdx.x >> 2, j = threadIdx.x & 3;
+            const int base = (int)(((int64_t)tile * kBlock) % nch);      // chunk index of thread 0
+            float s = 0.f;
+            for (int t = (ch - base + nch) % nch; t < kBlock; t += nch) s += reinterpret_cast<const float *>(&red[t])[j];
+            dot_partial[(size_t)tile * (4 * nch) + threadIdx.x] = s;
+        }
     }
 }
 
 int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream, const float *d_affine,
-               const float *d_src)
+               const float *d_src, float *d_dot_partial)
 {
     const int n_own = (int)(L->own_end - L->own_begin);
     if (n_own == 0) return PLX_OK;
@@ -112,7 +136,7 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
         const int nt = ceil_div((int64_t)n_own * nch, kBlock);
         slice_vec_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
             evid, ew, perm, n, ob, n_own, L->d + 1, reinterpret_cast<const float4 *>(d_values), nch, vd,
-            1.0f / L->slice_denom, d_out, nt, g_xcd_remap, d_affine, d_src);
+            1.0f / L->slice_denom, d_out, nt, g_xcd_remap, d_affine, d_src, d_dot_partial);
     }
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());

@@ -58,6 +58,7 @@ class Lattice:
         self._perm_cache = None
         self._own_begin = 0
         self.lattice_rows = False
+        self._dot_work = None
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -260,15 +261,30 @@ class Lattice:
         nv.check(rc, "plx_apply")
         return out
 
-    def apply_affine(self, src, scale_shift, out=None):
+    def apply_affine(self, src, scale_shift, out=None, want_dot=False):
         """out = a * K src + b * src with (a, b) = scale_shift (a 2-element float32 tensor on the device, read
-        there: no host synchronisation on hyper-parameters)."""
+        there: no host synchronisation on hyper-parameters).  want_dot: also return the column-wise <src, out>
+        (the p^T A p of a CG iteration), formed inside the slice kernel; needs 2..256 columns."""
         src = self._src(src, self.n_owned)
         _check_f32_cuda(scale_shift, "scale_shift", ndim=1)
         assert scale_shift.numel() == 2 and scale_shift.is_contiguous()
         vd = src.shape[1]
         if out is None:
             out = torch.empty((self.n_owned, vd), dtype=torch.float32, device=self.device)
+        if want_dot:
+            L = nv.lib()
+            need = int(L.plx_affine_dot_work_floats(self._h, vd))
+            if need < 0:
+                raise ValueError(f"apply_affine(want_dot=True) needs 2..256 columns on a built lattice, got {vd}")
+            if self._dot_work is None or self._dot_work.numel() < need:
+                self._dot_work = torch.empty(need, dtype=torch.float32, device=self.device)
+            dot = torch.empty(self.values_stride(vd), dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                rc = L.plx_apply_affine_dot(self._h, ctypes.c_void_p(src.data_ptr()), vd, ctypes.c_void_p(out.data_ptr()),
+                                            ctypes.c_void_p(scale_shift.data_ptr()), ctypes.c_void_p(dot.data_ptr()),
+                                            ctypes.c_void_p(self._dot_work.data_ptr()), _stream_ptr(self.device))
+            nv.check(rc, "plx_apply_affine_dot")
+            return out, dot[:vd]
         with torch.cuda.device(self.device):
             rc = nv.lib().plx_apply_affine(self._h, ctypes.c_void_p(src.data_ptr()), vd, ctypes.c_void_p(out.data_ptr()),
                                            ctypes.c_void_p(scale_shift.data_ptr()), _stream_ptr(self.device))

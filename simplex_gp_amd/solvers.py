@@ -163,7 +163,8 @@ class PivotedCholeskyPreconditioner:
         return self.Lt.t() @ g1 + math.sqrt(self.noise) * g2
 
 
-def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False, check_every=4, precond=None):
+def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False, check_every=4, precond=None,
+               matmul_dot=None):
     """Solve A X = B for all columns of B at once (A symmetric positive definite,
     known through `matmul`).  Stops when every column's residual norm is below
     `tol` x its right-hand-side norm, or after max_iter iterations.  The stopping
@@ -176,13 +177,16 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     tridiagonals are then those of P^-1/2 A P^-1/2 started at P^-1/2 B, and
     info["rz0"] holds B^T P^-1 B per column (the quadrature weight).
 
+    `matmul_dot` (optional, single-GPU HIP path): V -> (A V, column-wise <V, A V>) in one call, used
+    instead of matmul + a separate dot product.
+
     Returns (X, info); with want_tridiag, info["tridiag"] holds the per-column
     Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
     """
     if precond is not None:
         return _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every)
     if reduce is None and _native_ok(B):
-        return _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every)
+        return _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matmul_dot)
     X = torch.zeros_like(B)
     R = B.clone().contiguous()
     P = R.clone()
@@ -211,7 +215,7 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     return X, info
 
 
-def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every):
+def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matmul_dot=None):
     """batched_cg on one GPU with the iteration's scalars kept on the device: per iteration one
     MVM, one column dot, plx_cg_step_update and plx_cg_step_direction (alpha, beta and the
     active mask are formed inside those kernels)."""
@@ -240,9 +244,13 @@ def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every):
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         for it in range(1, max_iter + 1):
-            AP = matmul(P)
-            AP = AP if AP.is_contiguous() else AP.contiguous()
-            pAp = _colsum(P, AP)
+            if matmul_dot is not None:
+                AP, pAp = matmul_dot(P)
+                pAp = pAp.contiguous()
+            else:
+                AP = matmul(P)
+                AP = AP if AP.is_contiguous() else AP.contiguous()
+                pAp = _colsum(P, AP)
             row = it - 1 if want_tridiag else 0
             nv.check(lib.plx_cg_step_update(p(X), p(R), p(P), p(AP), p(rs), p(pAp), p(active), n, t, p(rs_new),
                                             p(alphas[row]), p(work), stream), "plx_cg_step_update")
@@ -381,7 +389,8 @@ class LatticeGP(nn.Module):
                 rhs_l = lat.to_lattice_order(rhs)
                 if pad:
                     rhs_l = torch.cat([rhs_l, rhs_l.new_zeros(rhs_l.shape[0], pad)], 1).contiguous()
-                sol, info = batched_cg(lambda V: lat.apply_affine(V, ss), rhs_l, **cg_args)
+                fused_dot = (lambda V: lat.apply_affine(V, ss, want_dot=True)) if 2 <= rhs_l.shape[1] <= 256 else None
+                sol, info = batched_cg(lambda V: lat.apply_affine(V, ss), rhs_l, matmul_dot=fused_dot, **cg_args)
                 if pad:
                     sol = sol[:, :t].contiguous()
                     info = dict(info, residual=info["residual"][:t])

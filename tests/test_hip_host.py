@@ -427,8 +427,23 @@ def test_affine_apply_and_device_side_cg(plx):
     with pytest.raises(PlxError):
         lat.apply_affine(V, ss, out=V)
     lat.set_lattice_row_order(False)
+    # the fused column dot <v, out> (plx_apply_affine_dot) against a separate reduction, widths with and without padding
+    for cols in (2, 3, 4, 6):
+        Vc = V[:, :cols].contiguous()
+        o2, dot = lat.apply_affine(Vc, ss, want_dot=True)
+        assert torch.equal(o2, lat.apply_affine(Vc, ss))
+        want = (Vc.double() * o2.double()).sum(0)
+        assert torch.allclose(dot.double(), want, rtol=1e-4, atol=1e-3), cols
+    with pytest.raises(ValueError):
+        lat.apply_affine(V[:, :1].contiguous(), ss, want_dot=True)
     mm = lambda W: lat.apply_affine(W, ss)       # noqa: E731
     Xa, ia = solvers.batched_cg(mm, V, max_iter=40, tol=1e-6, want_tridiag=True, check_every=1)
+    Xc, ic = solvers.batched_cg(mm, V, max_iter=40, tol=1e-6, want_tridiag=True, check_every=1,
+                                matmul_dot=lambda W: lat.apply_affine(W, ss, want_dot=True))
+    # a different summation order of p^T A p: the fp32 CG trajectories drift apart by a few 1e-5 over 40 iterations
+    assert ic["iterations"] == ia["iterations"] and rel_l2(Xc.cpu().numpy(), Xa.cpu().numpy()) <= 5e-4
+    ra, rc = (mm(Xa) - V).norm() / V.norm(), (mm(Xc) - V).norm() / V.norm()
+    assert float(rc) <= 1.5 * float(ra) + 1e-6
     Xb, ib = solvers.batched_cg(mm, V, max_iter=40, tol=1e-6, want_tridiag=True, check_every=1, reduce=lambda s: s)
     assert ia["iterations"] == ib["iterations"]
     assert rel_l2(Xa.cpu().numpy(), Xb.cpu().numpy()) <= 1e-5
