@@ -20,7 +20,8 @@ def oracle_filter(src, ref, coeffs):
 kernels = [plx.DiscretizedKernelFN(plx.rbf, 1), plx.DiscretizedKernelFN(plx.rbf, 2), plx.DiscretizedKernelFN(plx.rbf, 3),
            plx.DiscretizedKernelFN(lambda d2: plx.Matern.apply(d2, 1.5), 3)]
 worst = (0.0, None)
-nfused = 0
+nfused = ncancel = 0
+worst_terms = 0.0
 for c in range(cases):
     n = int(rng.choice([1, 5, 64, 300, 1025, 3000]))
     d = int(rng.integers(1, 13))
@@ -49,7 +50,7 @@ for c in range(cases):
         if a is None:
             continue
         err = float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-20))
-        if err > worst[0]:
+        if err > worst[0] and err <= 1e-4:
             worst = (err, (name, n, d, L, c))
         if name == "grad_x" and err > 1e-4:
             # py:122 is a difference of products, -2 sum(sx*wg - src*wgx + gx*ws - g*wsx): where points are isolated
@@ -60,8 +61,11 @@ for c in range(cases):
             rel_terms = float(np.linalg.norm(a.astype(np.float64) - b) / max(float(terms.norm()), 1e-20))
             print(f"case {c}: grad_x rel {err:.2e} but {rel_terms:.2e} of the cancelling terms", (n, d, L, scale), flush=True)
             if rel_terms <= 1e-5:
+                ncancel += 1
+                worst_terms = max(worst_terms, rel_terms)
                 continue
         if err > 1e-4 or not np.isfinite(a).all():
             print("FAIL", name, err, (n, d, L, scale, c), flush=True)
             sys.exit(1)
-print(f"{cases} cases ({nfused} through the fused kernel), worst rel-L2 {worst[0]:.2e} at {worst[1]}")
+print(f"{cases} cases ({nfused} through the fused kernel): worst rel-L2 {worst[0]:.2e} at {worst[1]}; {ncancel} grad_x cases with a "
+      f"vanishing true gradient judged against their cancelling terms, worst {worst_terms:.2e} of the terms")
