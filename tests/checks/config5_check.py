@@ -3,7 +3,7 @@
 order=3): parity of one MVM against the CPU oracle, MVM timing, and a few MLL training steps."""
 import json, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import solvers
 from oracle import oracle

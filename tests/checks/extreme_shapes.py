@@ -1,5 +1,6 @@
 import sys, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from oracle import oracle
 oracle.set_exact_mode(False)

@@ -4,7 +4,7 @@ allows, the three-call native form otherwise) against the reference formulation 
 oracle filter.  RBF orders 1-3 and Matern-1.5 order 3 (forward and derivative taps differ there)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from oracle import oracle
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100

@@ -4,7 +4,7 @@ d = 12, column counts that hit every splat / blur / slice kernel, all tap orders
 neighbour table forced on a third of the cases.  Prints the worst relative L2 error; exits 1 above 5e-5."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import _native as nv
 from oracle import oracle

@@ -2,7 +2,7 @@
 """One K.v at N = 1e7 (d = 8, l = 1): build / MVM time, memory, and rel-L2 against the CPU oracle."""
 import os, sys, time, json
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from oracle import oracle
 from tools.ab_apply import timeit, RBF1

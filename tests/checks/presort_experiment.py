@@ -2,7 +2,7 @@
 """Experiment: how much do the apply kernels gain if points arrive spatially sorted?"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from tools.ab_apply import timeit, RBF1
 
