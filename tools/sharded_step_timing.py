@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simplex_gp_amd as plx
 from tools.ab_apply import timeit, RBF1
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-n_local, d, ell = 1_000_000, 8, 1.0
+n_local, d, ell = (int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000), 8, 1.0
 g = torch.Generator().manual_seed(1234)
 x = torch.randn(n_local * W, d, generator=g) / ell
 v = torch.randn(n_local, 1, generator=g).cuda()
