@@ -1,43 +1,57 @@
 #!/usr/bin/env python3
 """bench.py -- lattice K.v MVMs/sec on MI355X (BASELINE.json metric).
 
-Workload (config.workload): BASELINE.json configs[2] -- synthetic N=1e6, d=8,
+Headline workload (config.workload): synthetic N=1e6 points per GPU, d=8,
 RBFLattice order=1 (taps [0.34608543, 1, 0.34608543]), vd=1, lengthscale 1.0,
-x ~ N(0, I) from torch.Generator().manual_seed(1234), run the way
-the reference's CG loop drives it: ONE lattice build per `--rebuild-every`
-(default 50) MVMs, i.e. the timed region of a default run is 1 build + 50
-applies.  A "step" is one K.v MVM through the C ABI (simplex_gp_amd ->
-libplx.so); step i rebuilds the lattice first when i % rebuild_every == 0, so
-no work is skipped: `value` = steps / wall time, inputs resident in HBM.
+x ~ N(0, I) from torch.Generator().manual_seed(1234), driven the way
+the reference's CG loop drives it (BASELINE.json configs[2]): ONE lattice build
+per `--rebuild-every` (default 50) MVMs.  A "step" is one K.v MVM through the C
+ABI (simplex_gp_amd -> libplx.so); step i rebuilds the lattice first when
+i % rebuild_every == 0.  `value` = steps / wall time of the timed region, inputs
+resident in HBM; the label reports how many builds the timed region contained.
 
-Also reported on the same JSON line (extra keys):
-  cold_mvms_per_s  every step = filter(src, ref, coeffs) = build + apply, what
-                   the reference does on every call (permutohedral.h:272)
-  warm_mvms_per_s  apply only
-  roofline         dominant kernel of the timed region: algorithmic bytes per
-                   launch (SURVEY 8d formulas) / mean launch time from hipEvents
-                   recorded by plx_apply on its own stream
-  fine             the same lattice shape at lengthscale 0.25 (m ~ 8.9e6), where
-                   the blur stage streams from HBM: blur roofline fraction
-  cpu_baseline     the reference's own CPU extension (oracle/_ref, built from
-                   /root/reference in the dev container) or, if absent, the C
-                   port (oracle/), timed on one full-size MVM on this host
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong|config4]
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): weak scaling,
-n = 1e6 points PER GPU.  Build: every rank embeds / inserts its own rows, one
-all-gather of the per-rank vertex keys, merge into one numbering.  MVM: splat own
-rows, one RCCL all-reduce of the vertex accumulators, replicated blur, slice own
-rows.  value = (n_total / 1e6) * MVMs/s, i.e. 1e6-point
-row blocks of K.v produced per second by the whole job.
+With --gpus N > 1 and no launcher in the environment, bench.py starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+process (before anything touches the GPU) and relays its JSON line and exit code.
+
+Extra keys on the same JSON line (one GPU):
+  warm_mvms_per_s / cold_mvms_per_s   apply only / build + apply per call (what the
+                   reference does on every call, permutohedral.h:272)
+  roofline         dominant stage of the timed region: algorithmic bytes
+                   / mean stage time from hipEvents recorded by plx_apply on its stream
+  stages           the same for all three stages
+  fine             the same shape at lengthscale 0.25 (m ~ 8.9e6): the blur streams
+                   from HBM there; its roofline fraction is the north-star target
+  config3_cg_ms    BASELINE.json configs[2]: N=1e6, d=8, lengthscale 0.6931, 50 CG
+                   iterations on (sK + sigma^2 I) with [y | 10 probes] incl. the build
+  config4          N=4e6 total, d=8, lengthscale 1 (configs[3]) sharded over the ranks
+  config5_mvm_us   MaternLattice(nu=1.5, order=3), N=10,623, d=18 stand-in: one MVM
+  cpu_baseline     the reference's own CPU extension (oracle/_ref) or the C port,
+                   one full-size MVM on this host, single thread
+
+Multi-GPU (one rank per GPU, RCCL): points are sharded by contiguous row blocks.
+Build: every rank embeds / inserts its own rows, ONE all-gather of the per-rank
+vertex keys, merge into one numbering.  MVM: splat own rows, ONE all-reduce of the
+vertex accumulators, replicated blur, slice own rows.
+  --scaling weak    (default) 1e6 points PER GPU; value = (n_total / 1e6) x MVMs/s,
+                    i.e. 1e6-point row blocks of K.v produced per second by the job;
+                    `mvms_per_s` is the plain rate of the n_total-point operator
+  --scaling strong  N=1e6 TOTAL (BASELINE.json's metric as written); value = MVMs/s
+  --scaling config4 N=4e6 TOTAL; value = MVMs/s
+Whatever the mode, a multi-GPU line also carries `strong` and `config4` legs, so
+that one 1/2/4/8 sweep yields all three curves.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -50,6 +64,39 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", dest="n", type=int, default=1_000_000, help="points per GPU (weak) / in total (strong)")
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--vd", type=int, default=1)
+    ap.add_argument("--ell", type=float, default=1.0)
+    ap.add_argument("--rebuild-every", type=int, default=50)
+    ap.add_argument("--scaling", choices=["weak", "strong", "config4"], default="weak")
+    ap.add_argument("--skip-cpu-baseline", dest="no_cpu_baseline", action="store_true")
+    ap.add_argument("--skip-fine", dest="no_fine", action="store_true")
+    ap.add_argument("--skip-configs", dest="no_configs", action="store_true", help="skip the config 3/4/5 legs")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
+    ap.add_argument("--dump", default=None, help="write every rank's output rows of one MVM to <DUMP>.rank<r>.npz (checked by tests/check_bench_dump.py)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the ranks as a child torchrun and relay its exit code.
+    Nothing in this process has touched the GPU (torch is not even imported yet), so no exec is involved."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: no launcher in the environment; starting", " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def alg_bytes(n, d, m, vd, r):
     """compulsory bytes per launch, fp32 values / int32 ids."""
     return {
@@ -60,6 +107,7 @@ def alg_bytes(n, d, m, vd, r):
 
 
 def synth(n, d, vd, seed=1234):
+    import torch
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(n, d, generator=g)
     v = torch.randn(n, vd, generator=g)
@@ -78,11 +126,10 @@ def time_region(fn, steps, sync, barrier):
 
 
 def kernel_times(lat, v, out, reps):
-    """Mean device time (ms) per LAUNCH of each apply kernel.  plx_apply records one
-    hipEvent pair per stage on its own stream; the blur stage is d+1 back-to-back
-    launches of one kernel, so stage / (d+1) is that kernel's mean launch time
-    (agrees with rocprofv3's per-kernel average to a few percent; per-launch
-    event pairs would add ~20 % of event overhead to a 25 us kernel)."""
+    """Mean device time (ms) per stage of plx_apply and per blur launch.  plx_apply records one hipEvent pair per
+    stage on its own stream; the blur stage is d+1 back-to-back launches of one kernel, so stage / (d+1) is that
+    kernel's mean launch time (agrees with rocprofv3's per-kernel average to a few percent; per-launch event pairs
+    would add ~20 % of event overhead to a 5 us kernel)."""
     lat.set_timing(True)
     acc = {"splat": [], "blur": [], "slice": []}
     for _ in range(reps):
@@ -95,54 +142,64 @@ def kernel_times(lat, v, out, reps):
             "slice": float(np.mean(acc["slice"]))}
 
 
-def roofline_for(kt, n, d, m, vd, r, ell=1.0):
+def roofline_for(lat, kt, n, d, m, vd, r, ell=1.0):
+    """roofline object for the dominant stage + per-stage table.  Kernel names are the ones libplx launched for this
+    lattice (plx_stage_kernels), i.e. what rocprofv3 --kernel-trace shows."""
     ab = alg_bytes(n, d, m, vd, r)
     per_mvm_ms = {"splat": kt["splat"], "blur_axis": kt["blur"] * (d + 1), "slice": kt["slice"]}
     dom = max(per_mvm_ms, key=per_mvm_ms.get)
     launch_ms = {"splat": kt["splat"], "blur_axis": kt["blur"], "slice": kt["slice"]}[dom]
     achieved = ab[dom] / (launch_ms * 1e-3) / 1e9
-    kernel = {"splat": "splat_scan_kernel (+gather_in, fix-up)", "blur_axis": "blur_axis kernel", "slice": "slice_v1_kernel"}[dom]
-    prefix = {"splat": "plx::splat_scan_kernel", "blur_axis": "plx::blur_axis", "slice": "plx::slice_v1_kernel"}[dom]
-    grid = {"splat": 8 * ((-(-n * (d + 1) // 1024) + 7) // 8) * 256,
-            "blur_axis": 8 * ((-(-(-(-m // 4)) // 256) + 7) // 8) * 256,
-            "slice": 8 * ((-(-n // 256) + 7) // 8) * 256}[dom]
-    pmc = pmc_traffic(prefix, grid, ell)
-    return {
-        "bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+    names = lat.stage_kernels(vd)
+    pmc = pmc_traffic(names[dom], ell)
+    roof = {
+        "bound": "hbm", "stage": dom, "kernel": " + ".join(names[dom]), "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
         "traffic": pmc["bytes"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,
         "bytes_per_launch": int(ab[dom]), "launch_us": round(launch_ms * 1e3, 2),
         "launches_per_mvm": (d + 1) if dom == "blur_axis" else 1,
         "note": ("cache-resident lattice: bound by the L2 request rate of 4-byte gathers, not HBM (DESIGN.md 4); "
                  "the HBM-bound regime is reported under 'fine'") if m * (d + 1) * 8 * r < 128e6 else "",
-    }, {
-        k: {"us_per_mvm": round(per_mvm_ms[k] * 1e3, 2), "alg_MB_per_mvm": round(ab[k] * ((d + 1) if k == "blur_axis" else 1) / 1e6, 2),
-            "GBps": round(ab[k] * ((d + 1) if k == "blur_axis" else 1) / (per_mvm_ms[k] * 1e-3) / 1e9, 1)}
-        for k in per_mvm_ms
     }
+    stages = {}
+    for k in per_mvm_ms:
+        mult = (d + 1) if k == "blur_axis" else 1
+        p = pmc_traffic(names[k], ell)
+        stages[k] = {"us_per_mvm": round(per_mvm_ms[k] * 1e3, 2), "alg_MB_per_mvm": round(ab[k] * mult / 1e6, 2),
+                     "GBps": round(ab[k] * mult / (per_mvm_ms[k] * 1e-3) / 1e9, 1),
+                     "frac": round(ab[k] * mult / (per_mvm_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "kernels": names[k],
+                     "traffic_MB_per_launch": round(p["bytes"] / 1e6, 1) if p else None}
+    return roof, stages
 
 
-def pmc_traffic(kernel_prefix, grid, ell):
-    """HBM bytes per launch of a kernel from the newest committed PMC table (profiles/*_pmc.json, written by
-    tools/summarize_profile.py from separate rocprofv3 --pmc passes), corrected as the microarch guide
-    prescribes for gfx950 (FETCH_SIZE x2 + WRITE_SIZE).  None when no table has that kernel at that grid."""
+def pmc_traffic(kernel_names, ell):
+    """HBM bytes per launch of a stage's kernels (summed) from the newest committed PMC table (profiles/*_pmc.json,
+    written by tools/summarize_profile.py from separate rocprofv3 --pmc passes of this same command), corrected as
+    the microarch guide prescribes for gfx950 (FETCH_SIZE x2 + WRITE_SIZE).  None when a kernel is not in the table."""
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
             table = json.load(open(path))["by_lengthscale"].get(str(ell), {})
         except Exception:                      # noqa: BLE001
             continue
-        for key, rec in table.items():
-            name, g = key.rsplit("|", 1)
-            if name.startswith(kernel_prefix) and int(g) == grid:
-                best = {"bytes": int((2 * rec["fetch_KB"] + rec["write_KB"]) * 1024), "source": os.path.basename(path)}
-    return best
+        total, found = 0.0, 0
+        for want in kernel_names:
+            for key, rec in table.items():
+                name = key.rsplit("|", 1)[0]
+                if name.startswith("plx::" + want) or name.startswith(want):
+                    total += (2 * rec["fetch_KB"] + rec["write_KB"]) * 1024
+                    found += 1
+                    break
+        if found == len(kernel_names) and found:
+            return {"bytes": int(total), "source": os.path.basename(path)}
+    return None
 
 
 def cpu_baseline(x, v, ell):
     """One full-size MVM on the host: the reference's own extension if oracle/_ref
     is present (kind "reference"), else the C port (kind "port")."""
+    import torch
     ref = (x / ell).contiguous()
     taps = torch.from_numpy(RBF1)
     try:
@@ -168,177 +225,321 @@ def cpu_baseline(x, v, ell):
                       f"lengthscale {ell}; best taken; single thread (the reference CPU path is single-threaded)"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--points", dest="n", type=int, default=1_000_000, help="points per GPU")
-    ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--vd", type=int, default=1)
-    ap.add_argument("--ell", type=float, default=1.0)
-    ap.add_argument("--rebuild-every", type=int, default=50)
-    ap.add_argument("--skip-cpu-baseline", dest="no_cpu_baseline", action="store_true")
-    ap.add_argument("--skip-fine", dest="no_fine", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
-    ap.add_argument("--dump", default=None, help="write every rank's output rows of one MVM to <DUMP>.rank<r>.npz (checked by tests/check_bench_dump.py)")
-    args = ap.parse_args()
+class Job:
+    """One sharded (or single-GPU) operator on synthetic rows: build / mvm closures for the timed loops."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+    def __init__(self, ctx, n_total, d, vd, ell, taps=RBF1):
+        import torch
+        from simplex_gp_amd.distributed import ShardedLatticeMVM, shard_bounds
+        self.ctx, self.n_total, self.d, self.vd, self.ell, self.taps = ctx, n_total, d, vd, ell, taps
+        x, v_all = synth(n_total, d, vd)
+        self.lo, self.hi = shard_bounds(n_total, ctx.world, ctx.rank)
+        # a rank keeps only its own rows on the device (the sharded build never needs the others)
+        self.ref = (x[self.lo:self.hi] / ell).contiguous().to(ctx.dev)
+        self.v = v_all[self.lo:self.hi].contiguous().to(ctx.dev)
+        self.out = torch.empty_like(self.v)
+        self.x_cpu, self.v_cpu = x, v_all
+        self.op = ShardedLatticeMVM.from_local_rows(self.ref, taps, n_total=n_total)
+        self.lat = self.op.lattice
+
+    def build(self):
+        self.op.rebuild(self.ref, self.taps)
+
+    def mvm(self):
+        if self.ctx.world == 1:
+            self.lat.apply(self.v, self.out)
         else:
-            dist.init_process_group(args.backend)
+            self.op.matmul(self.v, self.out)
+
+    def rate(self, steps, warmup=3):
+        """warm MVMs/s of the n_total operator (max over ranks of the wall time)."""
+        for _ in range(warmup):
+            self.mvm()
+        wall = self.ctx.max_over_ranks(time_region(lambda i: self.mvm(), steps, self.ctx.sync, self.ctx.barrier))
+        return steps / wall
+
+    def stage_us(self, reps=20):
+        """Per-stage device time of the sharded MVM on this rank (torch events on the current stream), max over ranks."""
+        import torch
+        acc = {}
+        for _ in range(reps):
+            ev = []
+
+            def mark(name, ev=ev):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+            self.op.matmul(self.v, self.out, marks=mark)
+            self.ctx.sync()
+            for (_, a), (name, b) in zip(ev, ev[1:]):
+                acc.setdefault(name, []).append(a.elapsed_time(b) * 1e3)
+        return {k: round(self.ctx.max_over_ranks(float(np.mean(v))), 2) for k, v in acc.items()}
+
+    def close(self):
+        self.lat.close()
+
+
+class Ctx:
+    def __init__(self, args):
+        import torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        ndev = torch.cuda.device_count()
+        self.dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+        torch.cuda.set_device(self.dev_index)
+        self.dev = torch.device("cuda", self.dev_index)
+        self.dist = None
+        self.backend = args.backend
+        if self.world > 1:
+            import torch.distributed as dist
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(args.backend)
+            self.dist = dist
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize(self.dev)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier(device_ids=[self.dev_index]) if self.backend == "nccl" else self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def config3_leg(ctx, n=1_000_000, d=8, iters=50):
+    """BASELINE.json configs[2] as the reference's training loop runs it (experiments/train_simplexgp.py:29-57):
+    50 CG iterations on (s K + sigma^2 I) with right-hand side [y | 10 Rademacher probes] (vd = 11), GPyTorch default
+    hyper-parameters (lengthscale = outputscale = softplus(0), noise softplus(0) + 1e-4).  One lattice build + 50
+    MVMs; the lengthscale is nudged per trial so that every trial rebuilds."""
+    import torch
+    import simplex_gp_amd as plx
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(n, d, generator=g).to(ctx.dev)
+    y = torch.randn(n, generator=g).to(ctx.dev)
+    Z = (torch.randint(0, 2, (n, 10), generator=g).float() * 2 - 1).to(ctx.dev)
+    rhs = torch.cat([y[:, None], Z], 1)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).to(ctx.dev)
+    best, best_warm, res, m = float("inf"), float("inf"), None, None
+    with torch.no_grad():
+        for trial in range(4):
+            model.kernel.lengthscale = 0.6931 * (1 + 1e-5 * trial)
+            ctx.sync()
+            t0 = time.perf_counter()
+            _, info = model.khat_solve(x, rhs, max_iter=iters, tol=0.0)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            _, info = model.khat_solve(x, rhs, max_iter=iters, tol=0.0)      # lattice cached: CG only
+            ctx.sync()
+            dtw = time.perf_counter() - t1
+            if trial > 0:
+                best, best_warm = min(best, dt), min(best_warm, dtw)
+            res = float(info["residual"].max())
+            m = list(plx.lattice_cache()._entries.values())[-1][0].m
+    plx.lattice_cache().clear()
+    return {"config3_cg_ms": round(best * 1e3, 2), "config3": {
+        "workload": f"N={n}, d={d}, vd=11, lengthscale 0.6931, {iters} CG iterations incl. one lattice build",
+        "ms_incl_build": round(best * 1e3, 2), "ms_cg_only": round(best_warm * 1e3, 2), "m_vertices": m,
+        "cg_iterations_per_s": round(iters / best_warm, 1), "final_rel_residual_max": res}}
+
+
+def config5_leg(ctx, n=10623, d=18):
+    """BASELINE.json configs[4] stand-in (UCI elevators is not available offline): MaternLattice(nu=1.5, order=3)
+    at N = 0.64 x 16,599 training points, d = 18: one warm MVM and one cold (build + apply) call."""
+    import torch
+    import simplex_gp_amd as plx
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(n, d, generator=g).to(ctx.dev)
+    v = torch.randn(n, 1, generator=g).to(ctx.dev)
+    k = plx.MaternLattice(nu=1.5, order=3, ard_num_dims=d)
+    taps = k.dkernel_fn.get_coeffs().numpy()
+    lat = plx.Lattice(ctx.dev)
+    lat.build(x, taps)
+    out = torch.empty_like(v)
+    for _ in range(5):
+        lat.apply(v, out)
+    reps = 50
+    wall = time_region(lambda i: lat.apply(v, out), reps, ctx.sync, lambda: None)
+    wall_cold = time_region(lambda i: (lat.build(x, taps), lat.apply(v, out)), 10, ctx.sync, lambda: None)
+    m = lat.m
+    lat.close()
+    return {"config5_mvm_us": round(wall / reps * 1e6, 1), "config5": {
+        "workload": f"MaternLattice(nu=1.5, order=3) stand-in for elevators: N={n}, d={d}, vd=1, lengthscale 1",
+        "m_vertices": m, "warm_mvm_us": round(wall / reps * 1e6, 1), "cold_call_us": round(wall_cold / 10 * 1e6, 1)}}
+
+
+def sharded_leg(ctx, n_total, d, ell, vds, steps):
+    """A fixed-total-size operator sharded over the ranks (strong scaling / config 4): plain MVMs/s per vd."""
+    out = {"n_total": n_total, "lengthscale": ell, "rccl_ranks": ctx.world}
+    for vd in vds:
+        job = Job(ctx, n_total, d, vd, ell)
+        out["m_vertices"] = job.op.m
+        out[f"mvms_per_s_vd{vd}"] = round(job.rate(steps), 1)
+        if ctx.world > 1:
+            out[f"stage_us_vd{vd}"] = job.stage_us(10)
+            out[f"allreduce_bytes_vd{vd}"] = job.op.exchange_bytes(vd)
+        job.close()
+        del job
+    return out
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(self_launch(args))
+    if env_world is not None and int(env_world) != args.gpus:
+        log(f"bench.py: WORLD_SIZE={env_world} but --gpus {args.gpus}: launch N ranks for --gpus N")
+        sys.exit(2)
+
+    import torch
+    ctx = Ctx(args)
+    world, rank, dist = ctx.world, ctx.rank, ctx.dist
 
     import simplex_gp_amd as plx
-    from simplex_gp_amd import _native as nv
 
-    def sync():
-        torch.cuda.synchronize(dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[dev_index]) if args.backend == "nccl" else dist.barrier()
-
-    n_local, d, vd, r = args.n, args.d, args.vd, 1
-    n_total = n_local * world
-    x, v_all = synth(n_total, d, vd)
-    lo, hi = rank * n_local, (rank + 1) * n_local
-    # a rank keeps only its own rows on the device (the sharded build never needs the others)
-    ref = (x[lo:hi] / args.ell).contiguous().to(dev) if world > 1 else (x / args.ell).contiguous().to(dev)
-    v = v_all[lo:hi].contiguous().to(dev)
-    out = torch.empty_like(v)
-
-    lat = plx.Lattice(dev)
-
-    def build():
-        """One lattice build.  Multi-GPU: every rank embeds / inserts only its own rows, the per-rank
-        vertex keys are all-gathered (the one collective of a build) and merged into one numbering."""
-        if world == 1:
-            lat.build(ref, RBF1)
-        else:
-            keys = lat.build_local(ref_local, RBF1)
-            all_keys, counts = all_gather_rows(keys)
-            lat.build_merge(all_keys, counts, rank)
-
-    if world > 1:
-        from simplex_gp_amd.distributed import all_gather_rows
-        ref_local = ref
-    build()
-    m = lat.m
-    values = scratch = None
-    if world > 1:
-        values, scratch = lat.new_values(vd), lat.new_values(vd)
-
-    def mvm():
-        if world == 1:
-            lat.apply(v, out)
-        else:
-            lat.splat(v, values)
-            dist.all_reduce(values)            # RCCL sum over xGMI: the one exchange of the path
-            res = lat.blur(values, scratch, vd=vd)
-            lat.slice(res, out, vd=vd)
+    d, vd, r = args.d, args.vd, 1
+    if args.scaling == "weak":
+        n_total = args.n * world
+    elif args.scaling == "strong":
+        n_total = args.n
+    else:
+        n_total = 4_000_000
+    job = Job(ctx, n_total, d, vd, args.ell)
+    lat, m = job.lat, job.op.m
+    n_local = job.hi - job.lo
 
     def step(i):
         if i % args.rebuild_every == 0:
-            build()
-        mvm()
+            job.build()
+        job.mvm()
 
     if args.dump:
         # rows of one MVM for an external checker (tests/check_bench_dump.py compares them with the CPU oracle);
         # bench.py itself only touches oracle/ in the cpu_baseline leg
-        mvm()
-        sync()
-        np.savez(f"{args.dump}.rank{rank}.npz", out=out.cpu().numpy(), lo=lo, hi=hi, n_total=n_total, d=d, vd=vd,
-                 ell=args.ell, m=m)
+        job.mvm()
+        ctx.sync()
+        np.savez(f"{args.dump}.rank{rank}.npz", out=job.out.cpu().numpy(), lo=job.lo, hi=job.hi, n_total=n_total, d=d,
+                 vd=vd, ell=args.ell, m=m)
 
     for i in range(args.warmup):
         step(i)
-    wall = time_region(step, args.steps, sync, barrier)
-    if dist is not None:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall = ctx.max_over_ranks(time_region(step, args.steps, ctx.sync, ctx.barrier))
+    builds = len([i for i in range(args.steps) if i % args.rebuild_every == 0])
     mvms_per_s = args.steps / wall
-    value = mvms_per_s * (n_total / 1e6) if world > 1 else mvms_per_s
+    weak_units = world > 1 and args.scaling == "weak"
+    value = mvms_per_s * (n_total / 1e6) if weak_units else mvms_per_s
+    scaling = "weak" if args.scaling == "weak" else "strong"
 
     result = {
-        "metric": "lattice K.v MVMs/sec, N=1e6 d=8 order=1 (1e6 points per GPU)",
+        "metric": "lattice K.v MVMs/sec, N=1e6 d=8 order=1" + (" (1e6 points per GPU)" if args.scaling == "weak" else ""),
         "value": round(value, 2), "unit": "MVMs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"N={n_local} points/GPU x {world} GPU(s), d={d}, vd={vd}, RBFLattice order=1, "
-                        f"lengthscale {args.ell}, x~N(0,I) seed 1234; one lattice build per "
-                        f"{args.rebuild_every} MVMs (CG loop, BASELINE.json configs[2])",
+            "workload": f"N={n_total} points over {world} GPU(s) ({n_local} on rank 0), d={d}, vd={vd}, RBFLattice "
+                        f"order=1, lengthscale {args.ell}, x~N(0,I) seed 1234; timed region = {builds} lattice "
+                        f"build(s) + {args.steps} MVMs (rebuild every {args.rebuild_every} MVMs: the CG loop of "
+                        f"BASELINE.json configs[2])",
             "n_total": n_total, "m_vertices": m, "rebuild_every": args.rebuild_every,
+            "builds_in_timed_region": builds, "scaling_mode": args.scaling,
             "parallelism": "single GPU" if world == 1 else f"points sharded x{world}; build: local + all-gather of vertex "
                                                               "keys + merge; MVM: RCCL all-reduce of vertex values, replicated blur",
-            "value_definition": "MVMs/s" if world == 1 else "(n_total/1e6) x MVMs/s of the n_total-point operator",
+            "value_definition": "(n_total/1e6) x MVMs/s of the n_total operator" if weak_units else "MVMs/s of the n_total operator",
         },
+        "mvms_per_s": round(mvms_per_s, 2),
     }
 
-    if world == 1:
-        # ---- warm / cold rates and per-kernel times on the same lattice
-        wall_warm = time_region(lambda i: mvm(), args.steps, sync, barrier)
-        wall_cold = time_region(lambda i: (lat.build(ref, RBF1), mvm()), max(5, args.steps // 5), sync, barrier)
+    if world > 1:
+        # ---- what the ranks spent where, the exchange, and the other two scaling curves
+        result["rccl_ranks"] = dist.get_world_size()
+        result["backend"] = args.backend
+        result["warm_mvms_per_s"] = round(job.rate(args.steps), 1)
+        result["stage_us"] = job.stage_us(20)
+        result["allreduce_bytes"] = job.op.exchange_bytes(vd)
+        result["build_key_bytes_exchanged"] = getattr(job.op, "key_bytes_exchanged", None)
+        job.close()
+        if not args.no_configs:
+            short = max(10, args.steps // 2)
+            if args.scaling != "strong":
+                result["strong"] = sharded_leg(ctx, args.n, d, args.ell, [1], short)
+            if args.scaling != "config4":
+                result["config4"] = sharded_leg(ctx, 4_000_000, d, 1.0, [1, 11], short)
+    else:
+        # ---- warm / cold rates and per-stage times on the same lattice
+        ref, v, out = job.ref, job.v, job.out
+        wall_warm = time_region(lambda i: job.mvm(), args.steps, ctx.sync, ctx.barrier)
+        ncold = max(5, args.steps // 5)
+        wall_cold = time_region(lambda i: (lat.build(ref, RBF1), job.mvm()), ncold, ctx.sync, ctx.barrier)
         lat.set_timing(True)
         lat.build(ref, RBF1)
         build_ms = lat.build_times_ms()
         lat.set_timing(False)
         kt = kernel_times(lat, v, out, reps=max(10, args.steps))
-        roof, stages = roofline_for(kt, n_local, d, m, vd, r, args.ell)
+        roof, stages = roofline_for(lat, kt, n_local, d, m, vd, r, args.ell)
         result["warm_mvms_per_s"] = round(args.steps / wall_warm, 1)
-        result["cold_mvms_per_s"] = round(max(5, args.steps // 5) / wall_cold, 1)
+        result["cold_mvms_per_s"] = round(ncold / wall_cold, 1)
         result["roofline"] = roof
         result["stages"] = stages
         result["build_ms"] = {k: round(t, 3) for k, t in build_ms.items()}
         result["lattice_device_MB"] = round(lat.device_bytes / 1e6, 1)
-        log("kernel times (ms):", kt)
+        log("stage times (ms):", kt)
         log("build (ms):", build_ms)
+        x_cpu, v_cpu = job.x_cpu, job.v_cpu
+        job.close()
 
         if not args.no_fine:
             # ---- fine regime: same points, lengthscale 0.25 -> m ~ 8.9e6, blur streams from HBM
-            ref_f = (x / 0.25).contiguous().to(dev)
-            lat_f = plx.Lattice(dev)
+            ref_f = (x_cpu / 0.25).contiguous().to(ctx.dev)
+            lat_f = plx.Lattice(ctx.dev)
             lat_f.set_timing(True)
             lat_f.build(ref_f, RBF1)
             fine_build = lat_f.build_times_ms()
             lat_f.set_timing(False)
             for _ in range(3):
                 lat_f.apply(v, out)
-            wf = time_region(lambda i: lat_f.apply(v, out), 20, sync, barrier)
+            wf = time_region(lambda i: lat_f.apply(v, out), 20, ctx.sync, ctx.barrier)
             ktf = kernel_times(lat_f, v, out, reps=10)
             abf = alg_bytes(n_local, d, lat_f.m, vd, r)
             blur_gbps = abf["blur_axis"] / (ktf["blur"] * 1e-3) / 1e9
-            _, stages_f = roofline_for(ktf, n_local, d, lat_f.m, vd, r)
+            _, stages_f = roofline_for(lat_f, ktf, n_local, d, lat_f.m, vd, r, 0.25)
+            names_f = lat_f.stage_kernels(vd)
+            pmc_f = pmc_traffic(names_f["blur_axis"], 0.25)
             result["fine"] = {
                 "lengthscale": 0.25, "m_vertices": lat_f.m, "warm_mvms_per_s": round(20 / wf, 1),
-                "blur_roofline": {"bound": "hbm", "kernel": "blur_axis_kernel", "achieved": round(blur_gbps, 1),
-                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(blur_gbps / HBM_PEAK_GBPS, 4),
-                                  "bytes_per_launch": int(abf["blur_axis"]), "launch_us": round(ktf["blur"] * 1e3, 2)},
+                "blur_roofline": {"bound": "hbm", "kernel": " + ".join(names_f["blur_axis"]),
+                                  "achieved": round(blur_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(blur_gbps / HBM_PEAK_GBPS, 4),
+                                  "bytes_per_launch": int(abf["blur_axis"]), "launch_us": round(ktf["blur"] * 1e3, 2),
+                                  "traffic": pmc_f["bytes"] if pmc_f else None,
+                                  "traffic_source": pmc_f["source"] if pmc_f else None,
+                                  "achieved_on_traffic": round(pmc_f["bytes"] / (ktf["blur"] * 1e-3) / 1e9, 1) if pmc_f else None},
                 "stages": stages_f, "build_ms": {k: round(t, 3) for k, t in fine_build.items()},
                 "lattice_device_MB": round(lat_f.device_bytes / 1e6, 1),
             }
-            log("fine kernel times (ms):", ktf)
+            log("fine stage times (ms):", ktf)
             lat_f.close()
             del ref_f
 
+        if not args.no_configs and args.scaling == "weak" and args.n == 1_000_000 and d == 8:
+            result.update(config3_leg(ctx))
+            result["config4"] = sharded_leg(ctx, 4_000_000, d, 1.0, [1, 11], 20)
+            result.update(config5_leg(ctx))
+
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(x[:n_local], v_all[:n_local], args.ell)
+            result["cpu_baseline"] = cpu_baseline(x_cpu[:n_local], v_cpu[:n_local], args.ell)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -243,9 +243,19 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  * caller's point order), "order_zcurve" (1; 0 = lexicographic point order), "insert_dedupe" (1), "nbr_symmetric" (1),
  * "compact_nbr" (1 = when under half of the neighbour slots exist; 0 never, 2 always), "blur_vpt" (4; vertices per
  * thread at vd = 1: 2 or 4, anything else selects the general kernel), "blur_small" (1), "blur_narrow" (1),
- * "blur_multi" (1), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1), and the diagnostic
+ * "blur_multi" (1), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1), "block_path" (1 = block
+ * tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable), "block_threads" (1024; or 512), and the diagnostic
  * "splat_ablate" / "blur_ablate" (0).  Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);
+
+/* Names of the kernels the last plx_splat / plx_blur / plx_slice (or plx_apply) on this lattice launched, as
+ * "splat=a+b;blur_axis=c;slice=d" -- the names rocprofv3 --kernel-trace shows (without template arguments), so that a
+ * bench line can name what actually ran. */
+int plx_last_kernels(const plx_lattice *lat, char *buf, int cap);
+/* Block rows of the lattice's block tables (the single-column splat / slice path of coarse lattices: owned points
+ * are cut into blocks, a block row = one distinct vertex of one block), or 0 when the lattice uses the
+ * vertex-sorted CSR path instead. */
+int64_t plx_block_rows(const plx_lattice *lat);
 
 /* Per-stage device time of the last plx_build on this lattice, in ms, in the
  * order {order+embed, insert, number, ids, neighbours, csr}; 0 when timing is off.

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "plx_export_bytes": (_i64, [_vp, _i32]),
     "plx_copy_point_perm": (_i32, [_vp, _vp, _vp]),
     "plx_tune": (_i32, [ctypes.c_char_p, _i32]),
+    "plx_last_kernels": (_i32, [_vp, ctypes.c_char_p, _i32]),
+    "plx_block_rows": (_i64, [_vp]),
     "plx_set_timing": (_i32, [_vp, _i32]),
     "plx_build_times": (_i32, [_vp, _f32p]),
     "plx_apply_times": (_i32, [_vp, _f32p, _i32, ctypes.POINTER(_i32)]),

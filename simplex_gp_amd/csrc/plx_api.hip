@@ -41,7 +41,8 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
             &L->sort_keys_in, &L->sort_keys_out, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->row_ptr,
             &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
-            &L->sortkey_in, &L->sortkey_out};
+            &L->sortkey_in, &L->sortkey_out,
+            &L->bc_pt, &L->bc_w, &L->srow, &L->brow_ptr, &L->brow_vid, &L->s2_idx, &L->s2_ptr, &L->partial};
 }
 
 struct DeviceGuard {
@@ -91,10 +92,11 @@ int plx_create(int device, plx_lattice **out)
         delete L;
         return PLX_ERR_HIP;
     }
+    // on failure plx_destroy releases whatever was created so far (events not yet created are null)
     for (auto &e : L->ev)
-        if (hipEventCreate(&e) != hipSuccess) { set_error("plx_create: hipEventCreate failed"); return PLX_ERR_HIP; }
+        if (hipEventCreate(&e) != hipSuccess) { e = nullptr; plx_destroy(L); set_error("plx_create: hipEventCreate failed"); return PLX_ERR_HIP; }
     for (auto &e : L->tev)
-        if (hipEventCreate(&e) != hipSuccess) { set_error("plx_create: hipEventCreate failed"); return PLX_ERR_HIP; }
+        if (hipEventCreate(&e) != hipSuccess) { e = nullptr; plx_destroy(L); set_error("plx_create: hipEventCreate failed"); return PLX_ERR_HIP; }
     *out = L;
     return PLX_OK;
 }
@@ -418,13 +420,17 @@ int plx_export(plx_lattice *L, int which, void *h_dst, int64_t bytes, void *stre
         PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->row_ptr.p, bytes, hipMemcpyDeviceToHost, s));
         break;
     case PLX_ARRAY_CSR_POINT: {
+        PLX_TRY(ensure_csr(L, s));
         PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_pt.p, bytes, hipMemcpyDeviceToHost, s));
         PLX_HIP_TRY(hipStreamSynchronize(s));
         int32_t *dst = (int32_t *)h_dst;   // strip the segment-head flag kept in the sign bit
         for (int64_t i = 0; i < bytes / 4; ++i) dst[i] &= 0x7FFFFFFF;
         return PLX_OK;
     }
-    case PLX_ARRAY_CSR_WEIGHT: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_w.p, bytes, hipMemcpyDeviceToHost, s)); break;
+    case PLX_ARRAY_CSR_WEIGHT:
+        PLX_TRY(ensure_csr(L, s));
+        PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->csr_w.p, bytes, hipMemcpyDeviceToHost, s));
+        break;
     case PLX_ARRAY_POINT_PERM: PLX_HIP_TRY(hipMemcpyAsync(h_dst, L->perm.p, bytes, hipMemcpyDeviceToHost, s)); break;
     }
     PLX_HIP_TRY(hipStreamSynchronize(s));
@@ -468,6 +474,15 @@ int plx_apply_times(plx_lattice *L, float *h_ms, int cap, int *count)
     *count = k < cap ? k : cap;
     return PLX_OK;
 }
+
+int plx_last_kernels(const plx_lattice *L, char *buf, int cap)
+{
+    if (!L || !buf || cap < 1) return PLX_ERR_INVALID;
+    snprintf(buf, (size_t)cap, "splat=%s;blur_axis=%s;slice=%s", L->kn_splat, L->kn_blur, L->kn_slice);
+    return PLX_OK;
+}
+
+int64_t plx_block_rows(const plx_lattice *L) { return (L && L->built && L->use_blocks) ? L->n_brows : 0; }
 
 int plx_build_times(const plx_lattice *L, float *h_ms6)
 {

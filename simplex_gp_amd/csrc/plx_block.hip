@@ -1,0 +1,472 @@
+// plx_block.hip -- block-structured splat / slice for single-column right-hand sides (vd = 1) on lattices
+// whose vertices are shared by many simplex corners (the coarse / medium regimes: m <= nnz / 2).
+//
+// Reference: splat value accumulation h:478-479, slice h:497-510.
+//
+// Why: with one column, splat and slice are 4-byte gathers -- 9e6 of them per side at N = 1e6, d = 8 -- and a
+// gather that misses the 32 KB vector L1 costs one L2 request however few bytes it wants; both stages ran at the
+// L2 request rate (round 1: splat 0.16, slice 0.32 of the HBM roofline with every array cache resident).  The
+// points are in lattice order, so a run of consecutive points shares most of its vertices: at N = 1e6, d = 8,
+// lengthscale 1 a block of 1820 points (16,380 corners) touches ~3,600 distinct vertices.  So:
+//
+//   build   the owned points are cut into blocks of P points; the corners of a block are sorted by vertex
+//           ("block rows": one per distinct vertex of the block, R_b in total, ~0.22 nnz above), every corner
+//           keeps a 15-bit block-local point index + a row-end flag (bc_pt), its weight (bc_w), and -- point
+//           major, for slice -- the 16-bit block-local row it belongs to (srow);
+//   splat   (1) one workgroup per block stages its P source values in LDS (this is also where the caller's
+//           row order is undone: no separate gather-in pass), streams its corners (6 bytes each, 16 per
+//           thread), forms w * src from LDS and reduces them by block row with a segmented scan whose tree is
+//           fixed (bitwise reproducible) -> partial[R_b]; rows never cross a block, so there is no fix-up pass;
+//           (2) one thread per vertex adds that vertex's partials in block order (rows longer than 32 by the
+//           whole wave) -> values[m]: R_b gathers instead of nnz;
+//   slice   one workgroup per block gathers the values of its block rows into LDS (R_b gathers in total), then
+//           every point reads its d+1 (row, weight) pairs and the values from LDS.
+//
+// No MFMA: this is a gather / segmented-reduce path, bound by the corner stream (6 B per corner per side).
+
+#include "plx_kernels.h"
+
+namespace plx {
+
+int g_block_path = 1;        // 0 never, 1 when the lattice qualifies (see build_blocks), 2 whenever representable
+int g_block_threads = 1024;  // threads per block workgroup (512 or 1024); a block holds threads * kBlkE corners
+
+constexpr int kBlkE = 16;        // corners per thread of splat_block_kernel
+constexpr int kLongRow = 32;     // splat_combine_kernel: vertex rows longer than this are summed by the whole wave
+
+// exclusive scan of one int per thread over a kBlock-thread workgroup
+__device__ __forceinline__ int wg_exclusive_scan(int val, int *total)
+{
+    __shared__ int wsum[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = val;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        const int s = wsum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - val;
+}
+
+// ----------------------------------------------------------------------------
+// build
+
+// sort key of an owned corner: (block of its point, vertex id); value: the corner itself
+__global__ __launch_bounds__(kBlock) void blk_keys_kernel(const int *__restrict__ evid, int n, int own_begin, int n_own,
+                                                          int P, int vbits, uint32_t *__restrict__ keys,
+                                                          uint32_t *__restrict__ vals)
+{
+    const int pl = blockIdx.x * kBlock + threadIdx.x;
+    if (pl >= n_own) return;
+    const int r = blockIdx.y;
+    const size_t dst = (size_t)r * n_own + pl;
+    keys[dst] = ((uint32_t)(pl / P) << vbits) | (uint32_t)evid[(size_t)r * n + own_begin + pl];
+    vals[dst] = (uint32_t)dst;
+}
+
+// rows (distinct vertices) of every block
+__global__ __launch_bounds__(kBlock) void blk_count_kernel(const uint32_t *__restrict__ skeys, int nnz, int cpb,
+                                                           int *__restrict__ rows)
+{
+    const int b = blockIdx.x;
+    const int k0 = b * cpb, k1 = min(k0 + cpb, nnz);
+    int cnt = 0;
+    for (int k = k0 + threadIdx.x; k < k1; k += kBlock) cnt += (k == k0 || skeys[k] != skeys[k - 1]) ? 1 : 0;
+    int total;
+    wg_exclusive_scan(cnt, &total);
+    if (threadIdx.x == 0) rows[b] = total;
+}
+
+// rows[] -> exclusive offsets (rows[nblocks] = total); counters[0] = total, counters[1] = largest block
+__global__ __launch_bounds__(kBlock) void blk_scan_kernel(int *__restrict__ rows, int nblocks, int *__restrict__ counters)
+{
+    __shared__ int wmax[kBlock / 64];
+    int carry = 0, biggest = 0;
+    for (int base = 0; base < nblocks; base += kBlock) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nblocks) ? rows[i] : 0;
+        biggest = max(biggest, v);
+        int total;
+        const int ex = wg_exclusive_scan(v, &total);
+        if (i < nblocks) rows[i] = carry + ex;
+        carry += total;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) biggest = max(biggest, __shfl_xor(biggest, off));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = biggest;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int mx = 0;
+        for (int w = 0; w < kBlock / 64; ++w) mx = max(mx, wmax[w]);
+        rows[nblocks] = carry;
+        counters[0] = carry;
+        counters[1] = mx;
+    }
+}
+
+// per-corner records in (block, vertex) order, block-row vertex ids, and the point-major row index of every corner
+__global__ __launch_bounds__(kBlock) void blk_fill_kernel(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
+                                                          const float *__restrict__ ew, int n, int own_begin, int n_own,
+                                                          int nnz, int cpb, int P, uint32_t vmask,
+                                                          const int *__restrict__ brow_ptr, uint16_t *__restrict__ bc_pt,
+                                                          float *__restrict__ bc_w, int *__restrict__ brow_vid,
+                                                          uint16_t *__restrict__ srow, int64_t sstride)
+{
+    const int b = blockIdx.x;
+    const int k0 = b * cpb, k1 = min(k0 + cpb, nnz);
+    const int base = brow_ptr[b];
+    int carry = 0;
+    for (int kk = k0; kk < k1; kk += kBlock) {           // same trip count in every thread (barriers inside)
+        const int k = kk + threadIdx.x;
+        const bool live = k < k1;
+        const uint32_t key = live ? skeys[k] : 0u;
+        const int head = (live && (k == k0 || key != skeys[k - 1])) ? 1 : 0;
+        int total;
+        const int ex = wg_exclusive_scan(head, &total);
+        if (live) {
+            const int lrow = carry + ex + head - 1;      // block row of this corner
+            const uint32_t sv = svals[k];
+            const uint32_t r = sv / (uint32_t)n_own, pl = sv - r * (uint32_t)n_own;
+            const bool end = (k + 1 == k1) || skeys[k + 1] != key;
+            bc_pt[k] = (uint16_t)((pl - (uint32_t)b * (uint32_t)P) | (end ? 0x8000u : 0u));
+            bc_w[k] = ew[(size_t)r * n + own_begin + pl];
+            if (head) brow_vid[base + lrow] = (int)(key & vmask);
+            srow[(size_t)r * sstride + pl] = (uint16_t)lrow;
+        }
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void blk_iota_kernel(const int *__restrict__ brow_vid, int nrows,
+                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j < nrows) { keys[j] = (uint32_t)brow_vid[j]; vals[j] = (uint32_t)j; }
+}
+
+// s2_ptr[u] = first k with skeys[k] >= u: the block rows of vertex u are s2_idx[s2_ptr[u] .. s2_ptr[u+1])
+__global__ __launch_bounds__(kBlock) void blk_rowptr_kernel(const uint32_t *__restrict__ skeys, int nrows, int m,
+                                                            int *__restrict__ s2_ptr)
+{
+    const int u = blockIdx.x * kBlock + threadIdx.x;
+    if (u > m) return;
+    int lo = 0, hi = nrows;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (skeys[mid] < (uint32_t)u) lo = mid + 1; else hi = mid;
+    }
+    s2_ptr[u] = lo;
+}
+
+// Block tables for the owned points of a built lattice (evid / ew / perm final).  Leaves L->use_blocks.
+int build_blocks(plx_lattice *L, hipStream_t stream)
+{
+    L->use_blocks = false;
+    const int d1 = L->d + 1;
+    const int n = (int)L->n, n_own = (int)(L->own_end - L->own_begin);
+    const int64_t nnz = L->nnz, m = L->m;
+    if (g_block_path == 0 || nnz == 0 || m == 0) return PLX_OK;
+    // the path pays when corners share vertices: with m > nnz / 2 most block rows hold a single corner and the
+    // two-stage splat only adds a pass (the sparse regime keeps the vertex-sorted CSR path)
+    if (g_block_path == 1 && 2 * m > nnz) return PLX_OK;
+    const int T = (g_block_threads == 512) ? 512 : 1024;
+    const int C = T * kBlkE;
+    int P = (C / d1) & ~7;                       // points per block: whole 16-byte vectors of every per-corner array
+    if (P < 8) return PLX_OK;
+    if (P > 32760) P = 32760;                    // 15-bit block-local point index
+    const int cpb = P * d1;                      // corners per (full) block
+    const int64_t nblocks = (n_own + P - 1) / P;
+    int vbits = 1, bbits = 0;
+    while ((1ll << vbits) < m) ++vbits;
+    while ((1ll << bbits) < nblocks) ++bbits;
+    if (vbits + bbits > 32) return PLX_OK;       // (block, vertex) does not fit a 32-bit sort key: CSR path
+    L->blk_P = P; L->blk_T = T; L->blk_cpb = cpb; L->nblocks = nblocks;
+    L->srow_stride = ((int64_t)n_own + 7) & ~7ll;
+
+    size_t temp_bytes = 0;
+    PLX_TRY(sort_pairs_temp_bytes(nnz, vbits + bbits, &temp_bytes));
+    PLX_TRY(ensure(L->sort_keys_in, (size_t)nnz * 4));
+    PLX_TRY(ensure(L->sort_keys_out, (size_t)nnz * 4 + 16));
+    PLX_TRY(ensure(L->sort_vals_in, (size_t)nnz * 4));
+    PLX_TRY(ensure(L->sort_vals_out, (size_t)nnz * 4));
+    PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
+    PLX_TRY(ensure(L->bc_pt, (size_t)nnz * 2 + 64));
+    PLX_TRY(ensure(L->bc_w, (size_t)nnz * 4 + 64));
+    PLX_TRY(ensure(L->srow, (size_t)d1 * L->srow_stride * 2 + 64));
+    PLX_TRY(ensure(L->brow_ptr, (size_t)(nblocks + 1) * 4));
+
+    blk_keys_kernel<<<dim3(ceil_div(n_own, kBlock), d1), kBlock, 0, stream>>>(
+        L->evid.as<int>(), n, (int)L->own_begin, n_own, P, vbits, L->sort_keys_in.as<uint32_t>(),
+        L->sort_vals_in.as<uint32_t>());
+    PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(), L->sort_keys_out.as<uint32_t>(),
+                       L->sort_vals_in.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), nnz, vbits + bbits, stream));
+    blk_count_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)nnz, cpb,
+                                                              L->brow_ptr.as<int>());
+    blk_scan_kernel<<<1, kBlock, 0, stream>>>(L->brow_ptr.as<int>(), (int)nblocks, L->counters.as<int>() + 40);
+    PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned + 40, L->counters.as<int>() + 40, 8, hipMemcpyDeviceToHost, stream));
+    PLX_HIP_TRY(hipStreamSynchronize(stream));          // R_b sizes the row tables
+    const int64_t nrows = L->h_pinned[40];
+    L->n_brows = nrows;
+    L->blk_max_rows = L->h_pinned[41];
+    if (g_block_path == 1 && 10 * nrows > 7 * nnz) return PLX_OK;   // too little sharing inside blocks: CSR path
+    PLX_TRY(ensure(L->brow_vid, (size_t)nrows * 4 + 16));
+    PLX_TRY(ensure(L->s2_idx, (size_t)nrows * 4 + 16));
+    PLX_TRY(ensure(L->s2_ptr, (size_t)(m + 2) * 4));
+    PLX_TRY(ensure(L->partial, (size_t)nrows * 4 + 16));
+    blk_fill_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(
+        L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n, (int)L->own_begin, n_own,
+        (int)nnz, cpb, P, (uint32_t)((1ull << vbits) - 1), L->brow_ptr.as<int>(), L->bc_pt.as<uint16_t>(),
+        L->bc_w.as<float>(), L->brow_vid.as<int>(), L->srow.as<uint16_t>(), L->srow_stride);
+    // vertex -> its block rows
+    size_t temp2 = 0;
+    PLX_TRY(sort_pairs_temp_bytes(nrows, vbits, &temp2));
+    PLX_TRY(ensure(L->sort_temp, temp2 + 16));
+    blk_iota_kernel<<<ceil_div(nrows, kBlock), kBlock, 0, stream>>>(L->brow_vid.as<int>(), (int)nrows,
+                                                                    L->sort_keys_in.as<uint32_t>(),
+                                                                    L->sort_vals_in.as<uint32_t>());
+    PLX_TRY(sort_pairs(L->sort_temp.p, temp2, L->sort_keys_in.as<uint32_t>(), L->sort_keys_out.as<uint32_t>(),
+                       L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, stream));
+    blk_rowptr_kernel<<<ceil_div(m + 1, kBlock), kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)nrows, (int)m,
+                                                                      L->s2_ptr.as<int>());
+    PLX_HIP_TRY(hipGetLastError());
+    L->use_blocks = true;
+    return PLX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// splat, stage 1: one workgroup per block.
+
+template <int E>
+__global__ __launch_bounds__(1024) void splat_block_kernel(const uint16_t *__restrict__ bc_pt, const float *__restrict__ bc_w,
+                                                           const int *__restrict__ brow_ptr, const float *__restrict__ src,
+                                                           const uint32_t *__restrict__ perm, int own_begin, int n_own,
+                                                           int nnz, int P, int cpb, float *__restrict__ partial)
+{
+    extern __shared__ float lds_src[];                  // [P] source values of the block's points
+    __shared__ int w_cnt[16];
+    __shared__ float w_tail[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int p0 = b * P, np = min(P, n_own - p0);
+    const int k0 = b * cpb, nc = min(cpb, nnz - k0);
+    const int kb = tid * E;
+
+    // corner records first: their latency overlaps the window gather below
+    uint32_t ptw[E / 2];
+    float w[E];
+    if (kb + E <= nc) {
+#pragma unroll
+        for (int q = 0; q < E / 8; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(bc_pt + k0 + kb + 8 * q);
+            ptw[4 * q] = a.x; ptw[4 * q + 1] = a.y; ptw[4 * q + 2] = a.z; ptw[4 * q + 3] = a.w;
+        }
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const float4 f = *reinterpret_cast<const float4 *>(bc_w + k0 + kb + 4 * q);
+            w[4 * q] = f.x; w[4 * q + 1] = f.y; w[4 * q + 2] = f.z; w[4 * q + 3] = f.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; j += 2) {
+            const uint32_t a = (kb + j < nc) ? bc_pt[k0 + kb + j] : 0u;
+            const uint32_t c = (kb + j + 1 < nc) ? bc_pt[k0 + kb + j + 1] : 0u;
+            ptw[j / 2] = a | (c << 16);
+            w[j] = (kb + j < nc) ? bc_w[k0 + kb + j] : 0.f;
+            w[j + 1] = (kb + j + 1 < nc) ? bc_w[k0 + kb + j + 1] : 0.f;
+        }
+    }
+    // source window; perm == nullptr: rows are already in lattice order
+    for (int i = tid; i < np; i += blockDim.x) {
+        const int row = perm ? (int)perm[own_begin + p0 + i] - own_begin : p0 + i;
+        lds_src[i] = src[row];
+    }
+    __syncthreads();
+
+    // products, and this thread's scan element: (row ends seen, sum since the last row end)
+    float prod[E];
+    int cnt = 0;
+    float tail = 0.f;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t pt = (ptw[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+        prod[j] = w[j] * lds_src[pt & 0x7FFFu];
+        const bool end = (pt & 0x8000u) != 0;
+        tail = end ? 0.f : tail + prod[j];
+        cnt += end ? 1 : 0;
+    }
+    // inclusive scan over the wave: combine(l, r) = (l.cnt + r.cnt, r.cnt ? r.tail : l.tail + r.tail)
+    int icnt = cnt;
+    float itail = tail;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int ocnt = __shfl_up(icnt, off);
+        const float otail = __shfl_up(itail, off);
+        if (lane >= off) {
+            itail = icnt > 0 ? itail : otail + itail;
+            icnt += ocnt;
+        }
+    }
+    if (lane == 63) { w_cnt[wave] = icnt; w_tail[wave] = itail; }
+    int xcnt = __shfl_up(icnt, 1);
+    float xtail = __shfl_up(itail, 1);
+    if (lane == 0) { xcnt = 0; xtail = 0.f; }
+    __syncthreads();
+    int pcnt = 0;
+    float ptail = 0.f;
+    for (int wv = 0; wv < wave; ++wv) {                // waves before this one, left to right
+        const int c = w_cnt[wv];
+        const float t = w_tail[wv];
+        ptail = c > 0 ? t : ptail + t;
+        pcnt += c;
+    }
+    float run = xcnt > 0 ? xtail : ptail + xtail;       // what the open row holds when it reaches this thread
+    float *dst = partial + brow_ptr[b] + pcnt + xcnt;   // first row that ends in this thread
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const bool end = ((ptw[j / 2] >> (16 * (j & 1))) & 0x8000u) != 0;
+        run += prod[j];
+        if (end) { *dst++ = run; run = 0.f; }
+    }
+}
+
+// splat, stage 2: values[v] = sum of v's block-row partials, in block order
+__global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__restrict__ s2_ptr, const int *__restrict__ s2_idx,
+                                                               const float *__restrict__ partial, int m,
+                                                               float *__restrict__ values, int ntiles, int remap)
+{
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int v = tile * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = 0;
+    if (v < m) { lo = s2_ptr[v]; hi = s2_ptr[v + 1]; }
+    const int len = hi - lo;
+    float acc = 0.f;
+    if (len <= kLongRow) {
+        int k = lo;
+        for (; k + 4 <= hi; k += 4) {
+            const int i0 = s2_idx[k], i1 = s2_idx[k + 1], i2 = s2_idx[k + 2], i3 = s2_idx[k + 3];
+            const float g0 = partial[i0], g1 = partial[i1], g2 = partial[i2], g3 = partial[i3];
+            acc = (((acc + g0) + g1) + g2) + g3;
+        }
+        for (; k < hi; ++k) acc += partial[s2_idx[k]];
+    }
+    // long rows: the whole wave, lanes striding the row, then a fixed butterfly
+    unsigned long long todo = __ballot(len > kLongRow);
+    while (todo) {
+        const int who = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int l = __shfl(lo, who), h = __shfl(hi, who);
+        float part = 0.f;
+        for (int k = l + lane; k < h; k += 64) part += partial[s2_idx[k]];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+        if (lane == who) acc = part;
+    }
+    if (v < m) values[v] = acc;
+}
+
+int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream)
+{
+    const int n_own = (int)(L->own_end - L->own_begin);
+    const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
+    const size_t lds = (size_t)L->blk_P * 4;
+    splat_block_kernel<kBlkE><<<(unsigned)L->nblocks, L->blk_T, lds, stream>>>(
+        L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->brow_ptr.as<int>(), d_src, perm, (int)L->own_begin, n_own,
+        (int)L->nnz, L->blk_P, L->blk_cpb, L->partial.as<float>());
+    const int nt = ceil_div(L->m, kBlock);
+    splat_combine_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
+        L->s2_ptr.as<int>(), L->s2_idx.as<int>(), L->partial.as<float>(), (int)L->m, d_values, nt, g_xcd_remap);
+    L->kn_splat = "splat_block_kernel+splat_combine_kernel";
+    tmark(L, stream);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+// ----------------------------------------------------------------------------
+// slice: one workgroup per block; out = sum_r w_r * values[v_r] / (1 + 2^-d) with the block's vertex values staged
+// in LDS.  Same arithmetic and order as slice_v1_kernel (plx_slice.hip).
+
+template <int D1>
+__global__ __launch_bounds__(1024) void slice_block_kernel(const uint16_t *__restrict__ srow, int64_t sstride,
+                                                           const float *__restrict__ ew, int n,
+                                                           const int *__restrict__ brow_ptr, const int *__restrict__ brow_vid,
+                                                           const float *__restrict__ values, const uint32_t *__restrict__ perm,
+                                                           int own_begin, int n_own, int P, float rden,
+                                                           float *__restrict__ out, const float *__restrict__ affine,
+                                                           const float *__restrict__ src)
+{
+    extern __shared__ float lds_val[];                  // values of the block's rows
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int p0 = b * P, np = min(P, n_own - p0);
+    const int base = brow_ptr[b], rows = brow_ptr[b + 1] - base;
+    // the first point's replay records: in flight while the rows are gathered
+    uint32_t v[D1];
+    float w[D1];
+    int i = tid;
+    if (i < np) {
+#pragma unroll
+        for (int r = 0; r < D1; ++r) {
+            v[r] = srow[(size_t)r * sstride + p0 + i];
+            w[r] = ew[(size_t)r * n + own_begin + p0 + i];
+        }
+    }
+    for (int j = tid; j < rows; j += blockDim.x) lds_val[j] = values[brow_vid[base + j]];
+    __syncthreads();
+    while (i < np) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < D1; ++r) acc += w[r] * lds_val[v[r]] * rden;
+        const int row = perm ? (int)perm[own_begin + p0 + i] - own_begin : p0 + i;
+        if (affine) acc = affine[0] * acc + affine[1] * src[row];      // out = a K src + b src (plx_apply_affine)
+        out[row] = acc;
+        i += blockDim.x;
+        if (i < np) {
+#pragma unroll
+            for (int r = 0; r < D1; ++r) {
+                v[r] = srow[(size_t)r * sstride + p0 + i];
+                w[r] = ew[(size_t)r * n + own_begin + p0 + i];
+            }
+        }
+    }
+}
+
+int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStream_t stream, const float *d_affine,
+                     const float *d_src)
+{
+    const int n_own = (int)(L->own_end - L->own_begin);
+    const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
+    const size_t lds = (size_t)L->blk_max_rows * 4;
+    const float rden = 1.0f / L->slice_denom;
+    switch (L->d + 1) {
+#define PLX_CASE(D1)                                                                                                    \
+    case D1:                                                                                                            \
+        slice_block_kernel<D1><<<(unsigned)L->nblocks, L->blk_T, lds, stream>>>(                                        \
+            L->srow.as<uint16_t>(), L->srow_stride, L->ew.as<float>(), (int)L->n, L->brow_ptr.as<int>(),                \
+            L->brow_vid.as<int>(), d_values, perm, (int)L->own_begin, n_own, L->blk_P, rden, d_out, d_affine, d_src);  \
+        break;
+        PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9)
+        PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17)
+        PLX_CASE(18) PLX_CASE(19) PLX_CASE(20) PLX_CASE(21) PLX_CASE(22) PLX_CASE(23) PLX_CASE(24) PLX_CASE(25)
+        PLX_CASE(26) PLX_CASE(27) PLX_CASE(28) PLX_CASE(29) PLX_CASE(30) PLX_CASE(31) PLX_CASE(32) PLX_CASE(33)
+#undef PLX_CASE
+    }
+    L->kn_slice = "slice_block_kernel";
+    tmark(L, stream);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+}  // namespace plx

@@ -365,6 +365,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
         case 2: blur_small_kernel<2><<<1, 1024, 0, stream>>>(d_values, dst, nb, m, L->mstride, d1, L->taps); break;
         default: blur_small_kernel<3><<<1, 1024, 0, stream>>>(d_values, dst, nb, m, L->mstride, d1, L->taps); break;
         }
+        L->kn_blur = "blur_small_kernel";
         tmark(L, stream);
         *result_in_scratch = (d1 & 1) ? 1 : 0;
         PLX_HIP_TRY(hipGetLastError());
@@ -387,14 +388,17 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             case 2: blur_axis_compact_kernel<2><<<grid, kBlock, 0, stream>>>(cur, nxt, cm, cb, ci, m, (uint32_t)L->nquads, L->taps); break;
             default: blur_axis_compact_kernel<3><<<grid, kBlock, 0, stream>>>(cur, nxt, cm, cb, ci, m, (uint32_t)L->nquads, L->taps); break;
             }
+            L->kn_blur = "blur_axis_compact_kernel";
         } else if (v1) {
             switch (order) {
             case 1: launch_blur_v1<1>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             case 2: launch_blur_v1<2>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             default: launch_blur_v1<3>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             }
+            L->kn_blur = "blur_axis_v1_kernel";
         } else if (vd == 1) {
             launch_blur_general<float>(cur, nxt, nb, m, L->mstride, 1, order, L->taps, stream);
+            L->kn_blur = "blur_axis_kernel";
         } else if (order >= 1 && order <= 3 && vdp / 4 <= 4 && g_blur_narrow && (int64_t)d1 * 2 * order * L->mstride < (1ll << 32)) {
             const float4 *c4 = reinterpret_cast<const float4 *>(cur);
             float4 *n4 = reinterpret_cast<float4 *>(nxt);
@@ -404,6 +408,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             case 2: launch_blur_narrow<2>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
             default: launch_blur_narrow<3>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
             }
+            L->kn_blur = "blur_axis_narrow_kernel";
         } else if (order >= 1 && order <= 3 && g_blur_multi && vdp / 4 >= 32) {   // narrower rows: no gain (vd 2..16 measured 0-30 % slower)
             constexpr int IPT = 4;
             const int rowlen = vdp / 4;
@@ -418,9 +423,11 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             case 2: blur_axis_multi_kernel<2, IPT><<<grid, kBlock, 0, stream>>>(c4, n4, nb, m, L->mstride, rowlen, L->taps, nt, remap); break;
             default: blur_axis_multi_kernel<3, IPT><<<grid, kBlock, 0, stream>>>(c4, n4, nb, m, L->mstride, rowlen, L->taps, nt, remap); break;
             }
+            L->kn_blur = "blur_axis_multi_kernel";
         } else {
             launch_blur_general<float4>(reinterpret_cast<const float4 *>(cur), reinterpret_cast<float4 *>(nxt), nb, m,
                                         L->mstride, vdp / 4, order, L->taps, stream);
+            L->kn_blur = "blur_axis_kernel";
         }
         float *t = cur; cur = nxt; nxt = t;
     }

@@ -900,6 +900,42 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
     return PLX_OK;
 }
 
+// The vertex-sorted splat CSR of the current build (csr_pt / csr_row / csr_w, sorted vertex ids in sort_keys_out):
+// stable radix sort of the owned corners by vertex id.  Needed by the multi-column splat kernels, the fused
+// backward, the structure exports and every lattice without block tables; built once per lattice build, on demand.
+int ensure_csr(plx_lattice *L, hipStream_t stream)
+{
+    if (L->csr_ready) return PLX_OK;
+    const int n = (int)L->n, n_own = (int)(L->own_end - L->own_begin), m = (int)L->m, D1 = L->d + 1;
+    PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
+    PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
+    PLX_TRY(ensure(L->csr_row, (size_t)L->nnz * 4 + 64));
+    if (L->nnz > 0) {
+        int end_bit = 1;
+        while ((1ll << end_bit) < (int64_t)m) ++end_bit;
+        size_t temp_bytes = 0;
+        PLX_TRY(sort_pairs_temp_bytes(L->nnz, end_bit, &temp_bytes));
+        PLX_TRY(ensure(L->sort_keys_in, (size_t)L->nnz * 4));
+        PLX_TRY(ensure(L->sort_keys_out, (size_t)L->nnz * 4 + 16));
+        PLX_TRY(ensure(L->sort_vals_in, (size_t)L->nnz * 4));
+        PLX_TRY(ensure(L->sort_vals_out, (size_t)L->nnz * 4));
+        PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
+        csr_keys_kernel<<<dim3(ceil_div(n_own, kBlock), D1), kBlock, 0, stream>>>(
+            L->evid.as<int>(), n, (int)L->own_begin, n_own, L->sort_keys_in.as<uint32_t>(),
+            L->sort_vals_in.as<uint32_t>());
+        PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(),
+                           L->sort_keys_out.as<uint32_t>(), L->sort_vals_in.as<uint32_t>(),
+                           L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, stream));
+        csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
+            L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
+            (int)L->own_begin, (int)L->nnz, m, L->perm.as<uint32_t>(), L->csr_pt.as<int>(), L->csr_row.as<int>(),
+            L->csr_w.as<float>());
+    }
+    PLX_HIP_TRY(hipGetLastError());
+    L->csr_ready = true;
+    return PLX_OK;
+}
+
 // ---- stage 3: gather tables over the final vertex numbering -------------------------------------
 template <int D>
 static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
@@ -915,9 +951,6 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     L->nchunks = ceil_div(L->nnz, kSplatChunk);
 
     PLX_TRY(ensure(L->nbr, (size_t)D1 * 2 * order * L->mstride * 4 + 4));
-    PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
-    PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
-    PLX_TRY(ensure(L->csr_row, (size_t)L->nnz * 4 + 64));
 
     if (order > 0) {
         dim3 ngrid(ceil_div(m, kBlock), D1);
@@ -964,28 +997,12 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     }
     mark();
 
-    // splat CSR over the owned points
-    if (L->nnz > 0) {
-        int end_bit = 1;
-        while ((1ll << end_bit) < (int64_t)m) ++end_bit;
-        size_t temp_bytes = 0;
-        PLX_TRY(sort_pairs_temp_bytes(L->nnz, end_bit, &temp_bytes));
-        PLX_TRY(ensure(L->sort_keys_in, (size_t)L->nnz * 4));
-        PLX_TRY(ensure(L->sort_keys_out, (size_t)L->nnz * 4));
-        PLX_TRY(ensure(L->sort_vals_in, (size_t)L->nnz * 4));
-        PLX_TRY(ensure(L->sort_vals_out, (size_t)L->nnz * 4));
-        PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
-        csr_keys_kernel<<<dim3(ceil_div(n_own, kBlock), D1), kBlock, 0, stream>>>(
-            L->evid.as<int>(), n, (int)L->own_begin, n_own, L->sort_keys_in.as<uint32_t>(),
-            L->sort_vals_in.as<uint32_t>());
-        PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(),
-                           L->sort_keys_out.as<uint32_t>(), L->sort_vals_in.as<uint32_t>(),
-                           L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, stream));
-        csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
-            L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
-            (int)L->own_begin, (int)L->nnz, m, L->perm.as<uint32_t>(), L->csr_pt.as<int>(), L->csr_row.as<int>(),
-            L->csr_w.as<float>());
-    }
+    // splat / slice tables over the owned points: block tables for single-column right-hand sides on lattices whose
+    // corners share vertices (plx_block.hip); the vertex-sorted CSR of the other kernels is built on first use
+    // (ensure_csr), or right away when there are no block tables
+    L->csr_ready = false;
+    PLX_TRY(build_blocks(L, stream));
+    if (!L->use_blocks) PLX_TRY(ensure_csr(L, stream));
     mark();
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -1066,6 +1083,7 @@ int build_merge_impl(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *
 int export_row_ptr(plx_lattice *L, hipStream_t stream)
 {
     const int m = (int)L->m;
+    PLX_TRY(ensure_csr(L, stream));
     PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
     row_ptr_kernel<<<ceil_div((int64_t)m + 1, kBlock), kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)L->nnz, m,
                                                                             L->row_ptr.as<int>());

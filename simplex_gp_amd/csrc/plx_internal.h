@@ -101,12 +101,34 @@ struct plx_lattice {
                             //                       gathers straight from d_src, no sorted copy)
     plx::DevBuf csr_w;      // float  [nnz]
     plx::DevBuf row_ptr;    // int32  [m+1]          produced on demand by plx_export (no kernel reads it)
+    bool csr_ready = false;      // csr_* / sort_keys_out hold the vertex-sorted splat CSR of this build (built on first
+                                 // use: only the multi-column kernels, the exports and lattices without block tables
+                                 // need it -- plx::ensure_csr)
+
+    // block tables (plx_block.hip): vd = 1 splat / slice on lattices whose corners share vertices.  The owned
+    // points, in lattice order, are cut into blocks of blk_P points; a block's corners are sorted by vertex.
+    bool use_blocks = false;
+    int blk_P = 0, blk_T = 0, blk_cpb = 0;     // points per block, threads per block workgroup, corners per full block
+    int blk_max_rows = 0;                      // most distinct vertices in one block (LDS rows of the slice kernel)
+    int64_t nblocks = 0, n_brows = 0;          // blocks, block rows (sum over blocks of distinct vertices)
+    int64_t srow_stride = 0;                   // plane stride of srow (n_own rounded up to 8)
+    plx::DevBuf bc_pt;      // uint16 [nnz]          block-local point of every corner, (block, vertex) order; bit 15: last of its row
+    plx::DevBuf bc_w;       // float  [nnz]          its barycentric weight
+    plx::DevBuf srow;       // uint16 [d+1][srow_stride]  block-local row of corner r of owned point p (slice)
+    plx::DevBuf brow_ptr;   // int32  [nblocks+1]    first block row of every block
+    plx::DevBuf brow_vid;   // int32  [n_brows]      vertex of every block row
+    plx::DevBuf s2_idx;     // int32  [n_brows]      block rows sorted by vertex
+    plx::DevBuf s2_ptr;     // int32  [m+1]          block rows of vertex v: s2_idx[s2_ptr[v] .. s2_ptr[v+1])
+    plx::DevBuf partial;    // float  [n_brows]      per-MVM block-row sums
 
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
     plx::DevBuf val_a, val_b;                 // float [m][vdp]   (vdp = value row stride, plx_values_stride)
     plx::DevBuf ssrc;                         // float [n_own][vdp] right-hand side in lattice order
     plx::DevBuf rec;                          // float [n_own][2L+d+2 rounded up to 4] packed (g, src, x) records (backward)
+
+    // kernels launched by the last splat / blur / slice on this lattice (names as rocprofv3 shows them, '+'-joined)
+    const char *kn_splat = "", *kn_blur = "", *kn_slice = "";
 
     int32_t *h_pinned = nullptr;   // pinned host staging for {m, err}
     hipEvent_t ev[8] = {};
@@ -126,6 +148,12 @@ int build_local_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);
 int build_merge_impl(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
                      hipStream_t stream);
 int export_row_ptr(plx_lattice *L, hipStream_t stream);   // fills L->row_ptr on demand (plx_export only)
+int ensure_csr(plx_lattice *L, hipStream_t stream);       // vertex-sorted splat CSR of the current build, built once on demand
+// plx_block.hip (block tables + the vd = 1 kernels that use them)
+int build_blocks(plx_lattice *L, hipStream_t stream);
+int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);
+int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStream_t stream, const float *d_affine,
+                     const float *d_src);
 // plx_sort.hip (rocPRIM radix sort of (vertex id, entry index) pairs)
 int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,

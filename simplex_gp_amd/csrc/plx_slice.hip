@@ -114,7 +114,8 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
                const float *d_src, float *d_dot_partial)
 {
     const int n_own = (int)(L->own_end - L->own_begin);
-    if (n_own == 0) return PLX_OK;
+    if (n_own == 0) { L->kn_slice = ""; tmark(L, stream); return PLX_OK; }
+    if (vd == 1 && L->use_blocks) return slice_block_impl(L, d_values, d_out, stream, d_affine, d_src);
     const int *evid = L->evid.as<int>();
     const float *ew = L->ew.as<float>();
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
@@ -131,7 +132,9 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
             PLX_CASE(26) PLX_CASE(27) PLX_CASE(28) PLX_CASE(29) PLX_CASE(30) PLX_CASE(31) PLX_CASE(32) PLX_CASE(33)
 #undef PLX_CASE
         }
+        L->kn_slice = "slice_v1_kernel";
     } else {
+        L->kn_slice = "slice_vec_kernel";
         const int nch = values_stride(vd) / 4;
         const int nt = ceil_div((int64_t)n_own * nch, kBlock);
         slice_vec_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(

@@ -526,8 +526,12 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     const int n_own = (int)(L->own_end - L->own_begin);
     if (L->nnz == 0) {
         PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));
+        L->kn_splat = "";
+        tmark(L, stream);
         return PLX_OK;
     }
+    if (vd == 1 && L->use_blocks) return splat_block_impl(L, d_src, d_values, stream);
+    PLX_TRY(ensure_csr(L, stream));
     const bool all_rows_touched = (L->n_shards == 1 && !L->partial_cover);
     if (!all_rows_touched) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));
     PLX_TRY(ensure(L->head_partial, (size_t)L->nchunks * vdp * 4));
@@ -536,6 +540,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
     const float *ss = L->ssrc.as<float>();
     const int *pt = L->csr_pt.as<int>();
+    bool gathered = false;
     const bool direct = g_splat_direct == 2 || (g_splat_direct == 1 && L->nnz <= 2000000);
     if (vd == 1 && (L->lattice_rows || direct)) {
         // single column: no padding needed, so gather straight from the caller's buffer -- through the
@@ -543,12 +548,14 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         ss = d_src;
         if (!L->lattice_rows) pt = L->csr_row.as<int>();
     } else if (vd == 1) {
+        gathered = true;
         gather_in_v1_kernel<<<ceil_div(n_own, kBlock), kBlock, 0, stream>>>(d_src, perm, (int)L->own_begin, n_own,
                                                                             L->ssrc.as<float>());
     } else if (L->lattice_rows && vd == vdp && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0) {
         // rows already in lattice order and whole 16-byte vectors: splat straight from the caller's buffer
         ss = d_src;
     } else {
+        gathered = true;
         gather_in_kernel<<<ceil_div((int64_t)n_own * vdp, kBlock), kBlock, 0, stream>>>(
             d_src, perm, (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());
     }
@@ -577,6 +584,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
                 splat_wide_kernel<2, RowSource><<<grid, kBlock, 0, stream>>>(pt, w, vid, rows, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap);
             splat_fixup_kernel<<<ceil_div((int64_t)nwide * vdp, kBlock), kBlock, 0, stream>>>(
                 pt, vid, nwide, kWideChunk, nnz, vdp, L->head_partial.as<float>(), L->tail_partial.as<float>(), d_values);
+            L->kn_splat = gathered ? "gather_in_kernel+splat_wide_kernel+splat_fixup_kernel" : "splat_wide_kernel+splat_fixup_kernel";
             tmark(L, stream);
             PLX_HIP_TRY(hipGetLastError());
             return PLX_OK;
@@ -599,6 +607,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
             }
             splat_fixup_kernel<<<ceil_div((int64_t)nwchunks * vdp, kBlock), kBlock, 0, stream>>>(
                 pt, vid, nwchunks, wc, nnz, vdp, L->head_partial.as<float>(), L->tail_partial.as<float>(), d_values);
+            L->kn_splat = gathered ? "gather_in_kernel+splat_group_kernel+splat_fixup_kernel" : "splat_group_kernel+splat_fixup_kernel";
             tmark(L, stream);
             PLX_HIP_TRY(hipGetLastError());
             return PLX_OK;
@@ -614,6 +623,8 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     }
     splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, kSplatChunk, nnz, vdp,
                                                                                          hp, tp, d_values);
+    L->kn_splat = vd == 1 ? (gathered ? "gather_in_v1_kernel+splat_scan_kernel+splat_fixup_kernel" : "splat_scan_kernel+splat_fixup_kernel")
+                          : (gathered ? "gather_in_kernel+splat_scan_kernel+splat_fixup_kernel" : "splat_scan_kernel+splat_fixup_kernel");
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -646,6 +657,7 @@ int splat_stack_impl(plx_lattice *lat, const float *d_g, const float *d_src, con
     const int d = lat->d, W = 2 * L * (1 + d), vdp = values_stride(W), nch = vdp / 4;
     const int n_own = (int)(lat->own_end - lat->own_begin);
     const int recw = backward_record_width(L, d);
+    PLX_TRY(ensure_csr(lat, stream));
     const int nnz = (int)lat->nnz, nwide = ceil_div(nnz, kWideChunk), nwt = ceil_div(nwide, kBlock / 64);
     PLX_TRY(ensure(lat->rec, (size_t)n_own * recw * 4));
     PLX_TRY(ensure(lat->head_partial, (size_t)nwide * vdp * 4));
@@ -666,6 +678,7 @@ int splat_stack_impl(plx_lattice *lat, const float *d_g, const float *d_src, con
         splat_wide_kernel<2, StackSource><<<grid, kBlock, wide_lds, stream>>>(pt, lat->csr_w.as<float>(), vid, stack, nch, nnz, v4, h4, t4, nwt, g_xcd_remap);
     splat_fixup_kernel<<<ceil_div((int64_t)nwide * vdp, kBlock), kBlock, 0, stream>>>(
         pt, vid, nwide, kWideChunk, nnz, vdp, lat->head_partial.as<float>(), lat->tail_partial.as<float>(), d_values);
+    lat->kn_splat = "backward_pack_kernel+splat_wide_kernel+splat_fixup_kernel";
     tmark(lat, stream);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;

@@ -90,6 +90,15 @@ class ShardedLatticeMVM:
         self.lattice = lattice if lattice is not None else Lattice(ref_local.device)
         self._vd = None
         self._values = self._scratch = None
+        self._n_total = n_total
+        self.rebuild(ref_local, coeffs)
+        return self
+
+    def rebuild(self, ref_local, coeffs):
+        """Re-run the sharded build for new positions / taps on the same lattice object (device buffers are
+        recycled): local structure, ONE all-gather of the per-rank vertex keys, merge.  Used by every
+        hyper-parameter step of a training loop and by bench.py's rebuild cadence."""
+        self._vd = None                      # m may change: the accumulators are re-allocated on the next MVM
         if self.world == 1:
             self.n = ref_local.shape[0]
             self.lo, self.hi = 0, self.n
@@ -97,12 +106,13 @@ class ShardedLatticeMVM:
             return self
         keys = self.lattice.build_local(ref_local, coeffs)
         # the one exchange of the build: vertex keys, with the key and row counts riding in its size message
-        all_keys, counts, rows = all_gather_rows(keys, group, extra=[ref_local.shape[0]])
+        all_keys, counts, rows = all_gather_rows(keys, self.group, extra=[ref_local.shape[0]])
         self.lattice.build_merge(all_keys, counts, self.rank)
         every = [r[0] for r in rows]
-        self.n = sum(every) if n_total is None else n_total
+        self.n = sum(every) if self._n_total is None else self._n_total
         self.lo = sum(every[: self.rank])
         self.hi = self.lo + every[self.rank]
+        self.key_bytes_exchanged = int(all_keys.numel() * all_keys.element_size())
         return self
 
     @property
@@ -120,7 +130,9 @@ class ShardedLatticeMVM:
             self._vd = vd
         return self._values, self._scratch
 
-    def matmul(self, v_local, out=None):
+    def matmul(self, v_local, out=None, marks=None):
+        """One sharded MVM.  `marks`: an optional list that receives a callable-produced stamp after each of the
+        four stages (splat, exchange, blur, slice) -- bench.py passes a recorder of device events."""
         if v_local.shape[0] != self.hi - self.lo:
             raise ValueError(f"rank {self.rank} owns rows [{self.lo}, {self.hi}) but got {v_local.shape[0]} rows")
         squeeze = v_local.dim() == 1
@@ -128,11 +140,21 @@ class ShardedLatticeMVM:
             v_local = v_local.unsqueeze(-1)
         vd = v_local.shape[1]
         values, scratch = self._workspace(vd)
+        mark = marks if marks is not None else (lambda name: None)
+        mark("start")
         self.lattice.splat(v_local, values)
+        mark("splat")
         all_reduce_sum(values, self.group)               # the one exchange step
+        mark("exchange")
         blurred = self.lattice.blur(values, scratch, vd=vd)
+        mark("blur")
         res = self.lattice.slice(blurred, out, vd=vd)
+        mark("slice")
         return res.squeeze(-1) if squeeze else res
+
+    def exchange_bytes(self, vd):
+        """Payload of the per-MVM all-reduce: the vertex accumulator, m x values_stride(vd) floats."""
+        return int(self.m) * int(self.lattice.values_stride(vd)) * 4
 
     __call__ = matmul
 
@@ -141,3 +163,15 @@ class ShardedLatticeMVM:
         if self.world == 1:
             return t_local
         return all_gather_rows(t_local.contiguous(), self.group)[0]
+
+
+def sharded_solve(op, rhs_local, outputscale, noise, **cg_args):
+    """(s K + sigma^2 I)^-1 rhs over a row-sharded operator `op` (a ShardedLatticeMVM): batched CG whose MVM is the
+    sharded one (own-row splat, vertex all-reduce, blur, own-row slice) and whose dot products are summed over the
+    ranks.  rhs_local / the result are this rank's rows.  Every rank must call it (collectives inside)."""
+    from .solvers import batched_cg
+    s, noise = float(outputscale), float(noise)
+
+    def mm(V):
+        return op.matmul(V).mul_(s).add_(V, alpha=noise)
+    return batched_cg(mm, rhs_local, reduce=lambda t: all_reduce_sum(t, op.group), **cg_args)

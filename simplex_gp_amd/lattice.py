@@ -183,6 +183,22 @@ class Lattice:
         nv.check(nv.lib().plx_build_times(self._h, buf), "plx_build_times")
         return dict(zip(("embed", "insert", "number", "ids", "neighbours", "csr"), list(buf)))
 
+    def stage_kernels(self, vd=None):
+        """Kernels launched by the last splat / blur / slice on this lattice: {"splat": [...], "blur_axis": [...],
+        "slice": [...]} (names as rocprofv3 shows them, without template arguments)."""
+        buf = ctypes.create_string_buffer(512)
+        nv.check(nv.lib().plx_last_kernels(self._h, buf, 512), "plx_last_kernels")
+        out = {}
+        for part in buf.value.decode().split(";"):
+            k, _, names = part.partition("=")
+            out[k] = [x for x in names.split("+") if x]
+        return out
+
+    @property
+    def block_rows(self):
+        """Rows of the block tables (0: the lattice uses the vertex-sorted CSR path)."""
+        return int(nv.lib().plx_block_rows(self._h))
+
     def apply_times_ms(self):
         """Stage times of the last apply(): dict(splat, blur, slice) in ms (blur = all d+1 launches)."""
         cap = 8

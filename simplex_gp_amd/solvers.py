@@ -9,8 +9,10 @@ the lattice operator the way the reference's scripts do:
 Every CG iteration is one K.v MVM with vd = 1 + num_probes on a lattice that is
 built once per hyper-parameter setting (lattice_kernel.cached_filter).
 
-For sharded operators pass `reduce=distributed.all_reduce_sum` so that the dot
-products are summed over ranks.
+batched_cg also runs over a row-sharded operator: pass the sharded `matmul` and
+`reduce=distributed.all_reduce_sum` so that the dot products are summed over
+ranks (distributed.sharded_solve).  The marginal likelihood below is
+single-process.
 """
 import math
 
@@ -163,8 +165,22 @@ class PivotedCholeskyPreconditioner:
         return self.Lt.t() @ g1 + math.sqrt(self.noise) * g2
 
 
+_FROZEN_BELOW = 1e-10     # a column whose relative residual is below this never moves again (GPyTorch: stop_updating_after)
+
+
+def _iteration_floor(max_iter, want_tridiag, min_iter, min_tridiag_iter):
+    """No column is frozen and the loop does not stop before this many iterations: GPyTorch's linear_cg runs at least
+    min(10, max_iter - 1) iterations, and at least max_lanczos_quadrature_iterations (20) when tridiagonals are
+    requested -- with the reference's training tolerance cg_tolerance(1.0) (experiments/train_simplexgp.py:34) that
+    floor is what gives the solve and the SLQ log-det any accuracy at all."""
+    floor = min(min_iter, max(max_iter - 1, 0))
+    if want_tridiag:
+        floor = max(floor, min(min_tridiag_iter, max(max_iter - 1, 0)))
+    return floor
+
+
 def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False, check_every=4, precond=None,
-               matmul_dot=None):
+               matmul_dot=None, min_iter=10, min_tridiag_iter=20):
     """Solve A X = B for all columns of B at once (A symmetric positive definite,
     known through `matmul`).  Stops when every column's residual norm is below
     `tol` x its right-hand-side norm, or after max_iter iterations.  The stopping
@@ -180,13 +196,17 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     `matmul_dot` (optional, single-GPU HIP path): V -> (A V, column-wise <V, A V>) in one call, used
     instead of matmul + a separate dot product.
 
+    `min_iter` / `min_tridiag_iter`: iteration floor as in GPyTorch's linear_cg (see _iteration_floor); before it only
+    columns that have converged to rounding level (relative residual < 1e-10) are frozen.
+
     Returns (X, info); with want_tridiag, info["tridiag"] holds the per-column
     Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
     """
+    floor = _iteration_floor(max_iter, want_tridiag, min_iter, min_tridiag_iter)
     if precond is not None:
-        return _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every)
+        return _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every, floor)
     if reduce is None and _native_ok(B):
-        return _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matmul_dot)
+        return _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matmul_dot, floor)
     X = torch.zeros_like(B)
     R = B.clone().contiguous()
     P = R.clone()
@@ -206,7 +226,7 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
             betas.append(beta)
         _cg_direction(P, R, beta)
         rs = rs_new
-        active = active & (rs.sqrt() / b_norm > tol)
+        active = active & (rs.sqrt() / b_norm > (tol if it >= floor else min(tol, _FROZEN_BELOW)))
         if tol > 0 and (it % check_every == 0 or it == max_iter) and not bool(active.any()):
             break
     info = {"iterations": it, "residual": (rs.sqrt() / b_norm)}
@@ -215,7 +235,7 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     return X, info
 
 
-def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matmul_dot=None):
+def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matmul_dot=None, floor=0):
     """batched_cg on one GPU with the iteration's scalars kept on the device: per iteration one
     MVM, one column dot, plx_cg_step_update and plx_cg_step_direction (alpha, beta and the
     active mask are formed inside those kernels)."""
@@ -254,7 +274,8 @@ def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matm
             row = it - 1 if want_tridiag else 0
             nv.check(lib.plx_cg_step_update(p(X), p(R), p(P), p(AP), p(rs), p(pAp), p(active), n, t, p(rs_new),
                                             p(alphas[row]), p(work), stream), "plx_cg_step_update")
-            nv.check(lib.plx_cg_step_direction(p(P), p(R), p(rs_new), p(rs), p(active), p(b_norm), float(tol), n, t,
+            step_tol = float(tol) if it >= floor else min(float(tol), _FROZEN_BELOW)
+            nv.check(lib.plx_cg_step_direction(p(P), p(R), p(rs_new), p(rs), p(active), p(b_norm), step_tol, n, t,
                                                p(betas[row]), p(active_next), stream), "plx_cg_step_direction")
             rs, rs_new = rs_new, rs
             active, active_next = active_next, active
@@ -285,7 +306,7 @@ def _tridiag_from_cg(alphas, betas, B):
     return T
 
 
-def _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every):
+def _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every, floor=0):
     X = torch.zeros_like(B)
     R = B.clone().contiguous()
     Z = precond.solve(R).contiguous()
@@ -310,7 +331,7 @@ def _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_
             betas.append(beta)
         _cg_direction(P, Z, beta)
         rz = rz_new
-        active = active & (rr.sqrt() / b_norm > tol)
+        active = active & (rr.sqrt() / b_norm > (tol if it >= floor else min(tol, _FROZEN_BELOW)))
         if tol > 0 and (it % check_every == 0 or it == max_iter) and not bool(active.any()):
             break
     info = {"iterations": it, "residual": (rr.sqrt() / b_norm), "rz0": rz0}
@@ -408,8 +429,7 @@ class LatticeGP(nn.Module):
                                                  device=x.device, dtype=x.dtype)
 
 
-def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, reduce=None,
-                            n_total=None, pre_size=0):
+def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, pre_size=0):
     """Per-datapoint log marginal likelihood (the quantity GPyTorch's
     ExactMarginalLogLikelihood returns) of a LatticeGP, differentiable with
     respect to every hyper-parameter.
@@ -425,16 +445,16 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     probes are drawn from N(0, P), logdet = logdet P + SLQ of P^-1/2 (sK + sigma^2 I) P^-1/2,
     and the log-det gradient pairs w_i with P^-1 z_i  (E[P^-1 z z^T] = I).
     """
-    n_local = y.shape[0]
-    n = n_local if n_total is None else n_total
+    # Single-process only: the kernel operator below is built from `x` alone.  A row-sharded job has to go through
+    # distributed.ShardedLatticeMVM (whose vertex all-reduce couples the ranks); distributed.sharded_solve does the
+    # solve that way, a sharded marginal likelihood with gradients is not implemented.
+    n = n_local = y.shape[0]
     r = (y - model.mean).reshape(-1, 1)
     g = torch.Generator(device=y.device).manual_seed(seed)      # on the device: 1e7 CPU draws cost ~0.1 s per step
     K = model.kernel(x, x)
     mm = model.khat_matmul(x, K)
     precond = None
     if pre_size > 0:
-        if reduce is not None:
-            raise NotImplementedError("the pivoted-Cholesky preconditioner is single-process (rows of K are not sharded)")
         precond = model.preconditioner(x, pre_size, K=K)
     with torch.no_grad():
         if precond is None:
@@ -442,10 +462,9 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
         else:
             Z = precond.sample(num_probes, generator=g)
         rhs = torch.cat([r.detach(), Z], 1)
-        sol, info = model.khat_solve(x, rhs, K=K, max_iter=max_cg_iter, tol=cg_tol, reduce=reduce, want_tridiag=True,
-                                     precond=precond)
+        sol, info = model.khat_solve(x, rhs, K=K, max_iter=max_cg_iter, tol=cg_tol, want_tridiag=True, precond=precond)
         u, W = sol[:, :1], sol[:, 1:]
-        quad = _colsum(r.detach(), u, reduce).sum()
+        quad = _colsum(r.detach(), u).sum()
         if precond is None:
             logdet = slq_logdet(info["tridiag"][1:], n)
         else:
@@ -455,7 +474,7 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     KV = mm(torch.cat([u, Z], 1))                                # differentiable MVM
     s_quad = -(u * r).sum() + 0.5 * (u * KV[:, :1]).sum()
     s_logdet = -0.5 * (W * KV[:, 1:]).sum() / num_probes
-    surrogate = s_quad + s_logdet       # sharded runs: the caller all-reduces the parameter gradients
+    surrogate = s_quad + s_logdet
     out = (value.to(surrogate.dtype) + (surrogate - surrogate.detach())) / n
     out.cg_info = info
     return out

@@ -70,6 +70,65 @@ def test_sharded_mvm_matches_single_process(tmp_path, world):
     assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-6
 
 
+def _local_rows_worker(rank, world, port, n, d, vd, outdir):
+    """The path bench.py --gpus N takes: every rank holds only its rows, local build -> all-gather of the vertex
+    keys -> merge -> sharded MVM; then a sharded CG solve on top of it."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.oracle_lattice_adapter import OracleLattice
+    from simplex_gp_amd.distributed import sharded_solve
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(12)
+        x = torch.randn(n, d, generator=g)
+        v = torch.randn(n, vd, generator=g)
+        lo, hi = shard_bounds(n, world, rank)
+        op = ShardedLatticeMVM.from_local_rows(x[lo:hi].contiguous(), RBF1, lattice=OracleLattice(), n_total=n)
+        assert (op.lo, op.hi, op.n) == (lo, hi, n)
+        assert op.key_bytes_exchanged > 0 and op.exchange_bytes(vd) == op.m * vd * 4
+        out_local = op.matmul(v[lo:hi])
+        full = op.gather_rows(out_local)
+        # rebuilding on the same object (new positions) keeps working: what a training loop / bench cadence does
+        op.rebuild((x[lo:hi] * 1.5).contiguous(), RBF1)
+        full2 = op.gather_rows(op.matmul(v[lo:hi]))
+        op.rebuild(x[lo:hi].contiguous(), RBF1)
+        sol, info = sharded_solve(op, v[lo:hi].contiguous(), outputscale=0.7, noise=0.3, max_iter=200, tol=1e-6)
+        sol_full = op.gather_rows(sol)
+        if rank == 0:
+            np.save(os.path.join(outdir, "out.npy"), full.numpy())
+            np.save(os.path.join(outdir, "out2.npy"), full2.numpy())
+            np.save(os.path.join(outdir, "sol.npy"), sol_full.numpy())
+            np.save(os.path.join(outdir, "m.npy"), np.array(op.m))
+            np.save(os.path.join(outdir, "res.npy"), info["residual"].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_build_from_local_rows_matches_oracle(tmp_path, world):
+    from oracle import oracle
+    n, d, vd = 1001, 3, 2
+    mp.spawn(_local_rows_worker, args=(world, _free_port(), n, d, vd, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, d, generator=g)
+    v = torch.randn(n, vd, generator=g)
+    oracle.set_exact_mode(False)
+    try:
+        want, m = oracle.filter(v.numpy(), x.numpy(), RBF1, return_m=True)
+        want2 = oracle.filter(v.numpy(), (x * 1.5).numpy(), RBF1)
+        assert int(np.load(tmp_path / "m.npy")) == m                      # the merged vertex set IS the full lattice's
+        for got, ref in ((np.load(tmp_path / "out.npy"), want), (np.load(tmp_path / "out2.npy"), want2)):
+            assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-6
+        # the sharded solve satisfies the single-process operator equation
+        sol = np.load(tmp_path / "sol.npy")
+        back = 0.7 * oracle.filter(sol, x.numpy(), RBF1) + 0.3 * sol
+        assert np.linalg.norm(back - v.numpy()) / np.linalg.norm(v.numpy()) <= 1e-4
+        assert float(np.load(tmp_path / "res.npy").max()) <= 1e-6
+    finally:
+        oracle.set_exact_mode(True)
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 1000, 1001):
         for world in (1, 2, 3, 8):

@@ -210,10 +210,15 @@ def test_large_vs_reference_probes(plx, golden_dir, name):
     err_clean = rel_l2(out, clean)
     print(name, "rel-L2 vs duplicate-free oracle", err_clean)
     assert err_clean <= TOL_ORACLE
-    # against the reference itself: 1e-4, except where the reference's own hash-growth
-    # quirk (one orphaned vertex per doubling) moves its output by more than that --
-    # measured with the oracle in both modes: 1.56e-4 and 1.95e-4 on these two inputs.
-    tol = 3e-4 if name in ("n1e5_d4_ell0.25", "n1e6_d8_ell0.6931") else TOL_REFERENCE
+    # against the reference itself: 1e-4, except where the reference's own hash-growth quirk (one orphaned vertex per
+    # table doubling, h:105 vs h:61-63) moves ITS output by more than that.  The widening is measured here, with the
+    # oracle in both modes on this very input -- never a literal: tol = max(1e-4, quirk + 1e-5).
+    exact = oracle.filter(v.numpy(), ref.numpy(), z[f"{name}/taps"])          # exact_mode: the reference, bit for bit
+    quirk = rel_l2(clean, exact)
+    assert np.linalg.norm(exact[:512] - head) == 0.0                           # the oracle IS the reference here
+    tol = max(TOL_REFERENCE, quirk + TOL_ORACLE)
+    print(name, "reference quirk (oracle clean vs exact)", quirk, "-> tolerance", tol)
+    assert rel_l2(out, exact) <= tol
     assert e_head <= tol and e_str <= tol
     assert abs(l2 / float(z[f"{name}/out_l2"]) - 1) <= tol
     lat.close()
@@ -440,3 +445,75 @@ def test_every_tap_order_at_every_row_width(plx, ntaps):
             assert rel_l2(got, want) <= TOL_ORACLE, (ntaps, vd)
     finally:
         oracle.set_exact_mode(True)
+
+
+@pytest.mark.parametrize("threads", [512, 1024])
+def test_block_tables_equal_csr_path(plx, threads):
+    """vd = 1 through the block tables (plx_block.hip: block-local splat + per-vertex combine, LDS-staged slice) against
+    the vertex-sorted CSR kernels and the oracle: caller row order, lattice row order, the affine epilogue, an owned
+    row range (sharded structure) and shapes where blocks are ragged (n not a multiple of the block, d + 1 not a
+    divisor of the block's corner count)."""
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    rng = np.random.default_rng(77)
+    shapes = [(50, 1, 1.0), (4099, 2, 1.0), (30011, 4, 1.0), (20000, 8, 2.0), (9000, 18, 4.0), (6001, 5, 1e3), (100003, 3, 0.5)]
+    try:
+        for n, d, scale in shapes:
+            ref = (rng.standard_normal((n, d)) / scale).astype(np.float32)
+            src = rng.standard_normal((n, 1)).astype(np.float32)
+            oracle.set_exact_mode(False)
+            want = oracle.filter(src, ref, taps)
+            oracle.set_exact_mode(True)
+            x, s = torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda()
+            nv.check(lib.plx_tune(b"block_path", 0), "plx_tune")
+            a = plx.Lattice().build(x, taps)
+            assert a.block_rows == 0
+            out_a = a.apply(s).clone()
+            va = a.splat(s).clone()
+            nv.check(lib.plx_tune(b"block_path", 2), "plx_tune")
+            nv.check(lib.plx_tune(b"block_threads", threads), "plx_tune")
+            b = plx.Lattice().build(x, taps)
+            assert b.block_rows > 0 and b.m == a.m
+            assert b.stage_kernels() is not None
+            out_b = b.apply(s).clone()
+            assert "splat_block_kernel" in b.stage_kernels()["splat"] and b.stage_kernels()["slice"] == ["slice_block_kernel"]
+            assert rel_l2(out_b.cpu().numpy(), want) <= TOL_ORACLE, (n, d)
+            assert rel_l2(out_b.cpu().numpy(), out_a.cpu().numpy()) <= 2e-6, (n, d)
+            # stage by stage: same vertex numbering in both builds
+            vb = b.splat(s)
+            assert rel_l2(vb.cpu().numpy(), va.cpu().numpy()) <= 2e-6
+            blurred = a.blur(va.clone(), vd=1)
+            assert torch.equal(b.slice(blurred, vd=1), a.slice(blurred, vd=1))        # same arithmetic, same order
+            assert torch.equal(b.apply(s), out_b)                                       # reproducible bits
+            # affine epilogue and lattice row order
+            ss = torch.tensor([0.7, 0.3], device="cuda")
+            assert rel_l2(b.apply_affine(s, ss).cpu().numpy(), (0.7 * out_b + 0.3 * s).cpu().numpy()) <= 1e-6
+            b.set_lattice_row_order(True)
+            out_l = b.from_lattice_order(b.apply(b.to_lattice_order(s)))
+            b.set_lattice_row_order(False)
+            assert torch.equal(out_l, out_b)
+            # multi-column right-hand sides on a lattice with block tables use the CSR built on demand
+            s3 = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32)).cuda()
+            assert rel_l2(b.apply(s3).cpu().numpy(), a.apply(s3).cpu().numpy()) <= 1e-6
+            # an owned row range: per-shard splats add up, per-shard slices tile the output
+            if n >= 4099:
+                from simplex_gp_amd.distributed import shard_bounds
+                total, parts = None, []
+                for r in range(3):
+                    lo, hi = shard_bounds(n, 3, r)
+                    lat = plx.Lattice().build(x, taps, shard=(r, 3))
+                    assert lat.block_rows > 0
+                    part = lat.splat(s[lo:hi])
+                    total = part.clone() if total is None else total + part
+                    parts.append((lat, lo, hi))
+                got = torch.empty_like(out_b)
+                for lat, lo, hi in parts:
+                    got[lo:hi] = lat.slice(lat.blur(total.clone(), vd=1), vd=1)
+                    lat.close()
+                assert rel_l2(got.cpu().numpy(), want) <= TOL_ORACLE, (n, d)
+            a.close()
+            b.close()
+    finally:
+        nv.check(lib.plx_tune(b"block_path", 1), "plx_tune")
+        nv.check(lib.plx_tune(b"block_threads", 1024), "plx_tune")

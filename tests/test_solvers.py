@@ -41,6 +41,51 @@ def test_batched_cg_and_slq_on_dense_spd():
     assert abs(est - exact) < 0.05 * abs(exact) + 1.0
 
 
+def test_cg_iteration_floor_like_gpytorch():
+    """With the reference's training tolerance (cg_tolerance(1.0), train_simplexgp.py:34) a CG that freezes a column
+    as soon as its residual is below its right-hand side would stop after one step and hand SLQ a 1x1 tridiagonal.
+    GPyTorch's linear_cg keeps iterating for min(10, max_iter-1) steps, 20 when tridiagonals are requested."""
+    g = torch.Generator().manual_seed(3)
+    n = 300
+    Q = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = Q @ Q.T / n + 0.05 * torch.eye(n, dtype=torch.float64)
+    Z = (torch.randint(0, 2, (n, 32), generator=g).double() * 2 - 1)
+    exact = float(torch.logdet(A))
+    _, info = solvers.batched_cg(lambda V: A @ V, Z, max_iter=500, tol=1.0, want_tridiag=True)
+    assert info["iterations"] >= 20 and info["tridiag"].shape[-1] >= 20
+    loose = float(solvers.slq_logdet(info["tridiag"], n))
+    _, info_t = solvers.batched_cg(lambda V: A @ V, Z, max_iter=500, tol=1e-10, want_tridiag=True)
+    tight = float(solvers.slq_logdet(info_t["tridiag"], n))
+    assert abs(loose - tight) < 0.05 * abs(tight) and abs(tight - exact) < 0.1 * abs(exact)
+    # without tridiagonals: 10 iterations at least; with the floor switched off the old one-step behaviour is back
+    X, info = solvers.batched_cg(lambda V: A @ V, Z[:, :4], max_iter=500, tol=1.0)
+    assert 10 <= info["iterations"] <= 12
+    _, info0 = solvers.batched_cg(lambda V: A @ V, Z[:, :4], max_iter=500, tol=1.0, min_iter=0, check_every=1)
+    assert info0["iterations"] <= 4
+    # max_iter below the floor is respected; exactly converged columns freeze early instead of dividing 0 / 0
+    _, info = solvers.batched_cg(lambda V: A @ V, Z[:, :4], max_iter=5, tol=1.0)
+    assert info["iterations"] <= 5
+    I = torch.eye(6, dtype=torch.float64)
+    X, info = solvers.batched_cg(lambda V: 2.0 * V, I[:, :3].clone(), max_iter=50, tol=1e-3)
+    assert torch.allclose(X, 0.5 * I[:, :3]) and torch.isfinite(X).all()
+
+
+def test_mll_at_training_tolerance_is_close_to_tight_mll(cpu_method):
+    """train/mll is computed at cg_tol = 1 (configs/simplexgp.yml): with the iteration floor it must agree with the
+    tightly converged value, otherwise the training curve means nothing."""
+    torch.manual_seed(0)
+    n = 400
+    x = torch.rand(n, 2) * 3
+    y = torch.sin(2 * x[:, 0]) * torch.cos(x[:, 1]) + 0.1 * torch.randn(n)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1), min_noise=1e-2)
+    with torch.no_grad():
+        loose = float(solvers.marginal_log_likelihood(model, x, y, num_probes=20, cg_tol=1.0, max_cg_iter=500, seed=1))
+        tight = float(solvers.marginal_log_likelihood(model, x, y, num_probes=20, cg_tol=1e-6, max_cg_iter=500, seed=1))
+    assert abs(loose - tight) < 0.05 * abs(tight) + 0.02, (loose, tight)
+    with pytest.raises(TypeError):
+        solvers.marginal_log_likelihood(model, x, y, reduce=lambda t: t)         # sharded MLL: not offered (docstring)
+
+
 def _dense_spd(n, noise, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(n, 1, generator=g, dtype=torch.float64) * 4
