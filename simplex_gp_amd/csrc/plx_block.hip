@@ -17,8 +17,8 @@
 //           row order is undone: no separate gather-in pass), streams its corners (6 bytes each, 16 per
 //           thread), forms w * src from LDS and reduces them by block row with a segmented scan whose tree is
 //           fixed (bitwise reproducible) -> partial[R_b]; rows never cross a block, so there is no fix-up pass;
-//           (2) one thread per vertex adds that vertex's partials in block order (rows longer than 32 by the
-//           whole wave) -> values[m]: R_b gathers instead of nnz;
+//           (2) the block rows, sorted by vertex, are reduced by vertex with the same kind of scan, one wave per
+//           256 rows -> values[m]: R_b gathers instead of nnz;
 //   slice   one workgroup per block gathers the values of its block rows into LDS (R_b gathers in total), then
 //           every point reads its d+1 (row, weight) pairs and the values from LDS.
 //
@@ -29,10 +29,13 @@
 namespace plx {
 
 int g_block_path = 1;        // 0 never, 1 when the lattice qualifies (see build_blocks), 2 whenever representable
-int g_block_threads = 1024;  // threads per block workgroup (512 or 1024); a block holds threads * kBlkE corners
+int g_block_ablate = 0;      // diagnostics only: 1 combine without the partial gathers, 2 combine without idx loads too,
+                             // 4 combine without stores, 8 splat_block without the LDS source reads
+int g_scatter_store = 0;     // slice's row-scattered output stores: 0 plain, 1 non-temporal, 2 agent-scope (write-through)
+int g_block_threads = 256;   // threads per block workgroup (256, 512 or 1024); a block holds threads * kBlkE corners
 
 constexpr int kBlkE = 16;        // corners per thread of splat_block_kernel
-constexpr int kLongRow = 32;     // splat_combine_kernel: vertex rows longer than this are summed by the whole wave
+constexpr int kCombineRun = 256; // block rows per wave of splat_combine_kernel
 
 // exclusive scan of one int per thread over a kBlock-thread workgroup
 __device__ __forceinline__ int wg_exclusive_scan(int val, int *total)
@@ -169,93 +172,18 @@ __global__ __launch_bounds__(kBlock) void blk_rowptr_kernel(const uint32_t *__re
     s2_ptr[u] = lo;
 }
 
-// Block tables for the owned points of a built lattice (evid / ew / perm final).  Leaves L->use_blocks.
-int build_blocks(plx_lattice *L, hipStream_t stream)
-{
-    L->use_blocks = false;
-    const int d1 = L->d + 1;
-    const int n = (int)L->n, n_own = (int)(L->own_end - L->own_begin);
-    const int64_t nnz = L->nnz, m = L->m;
-    if (g_block_path == 0 || nnz == 0 || m == 0) return PLX_OK;
-    // the path pays when corners share vertices: with m > nnz / 2 most block rows hold a single corner and the
-    // two-stage splat only adds a pass (the sparse regime keeps the vertex-sorted CSR path)
-    if (g_block_path == 1 && 2 * m > nnz) return PLX_OK;
-    const int T = (g_block_threads == 512) ? 512 : 1024;
-    const int C = T * kBlkE;
-    int P = (C / d1) & ~7;                       // points per block: whole 16-byte vectors of every per-corner array
-    if (P < 8) return PLX_OK;
-    if (P > 32760) P = 32760;                    // 15-bit block-local point index
-    const int cpb = P * d1;                      // corners per (full) block
-    const int64_t nblocks = (n_own + P - 1) / P;
-    int vbits = 1, bbits = 0;
-    while ((1ll << vbits) < m) ++vbits;
-    while ((1ll << bbits) < nblocks) ++bbits;
-    if (vbits + bbits > 32) return PLX_OK;       // (block, vertex) does not fit a 32-bit sort key: CSR path
-    L->blk_P = P; L->blk_T = T; L->blk_cpb = cpb; L->nblocks = nblocks;
-    L->srow_stride = ((int64_t)n_own + 7) & ~7ll;
-
-    size_t temp_bytes = 0;
-    PLX_TRY(sort_pairs_temp_bytes(nnz, vbits + bbits, &temp_bytes));
-    PLX_TRY(ensure(L->sort_keys_in, (size_t)nnz * 4));
-    PLX_TRY(ensure(L->sort_keys_out, (size_t)nnz * 4 + 16));
-    PLX_TRY(ensure(L->sort_vals_in, (size_t)nnz * 4));
-    PLX_TRY(ensure(L->sort_vals_out, (size_t)nnz * 4));
-    PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
-    PLX_TRY(ensure(L->bc_pt, (size_t)nnz * 2 + 64));
-    PLX_TRY(ensure(L->bc_w, (size_t)nnz * 4 + 64));
-    PLX_TRY(ensure(L->srow, (size_t)d1 * L->srow_stride * 2 + 64));
-    PLX_TRY(ensure(L->brow_ptr, (size_t)(nblocks + 1) * 4));
-
-    blk_keys_kernel<<<dim3(ceil_div(n_own, kBlock), d1), kBlock, 0, stream>>>(
-        L->evid.as<int>(), n, (int)L->own_begin, n_own, P, vbits, L->sort_keys_in.as<uint32_t>(),
-        L->sort_vals_in.as<uint32_t>());
-    PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(), L->sort_keys_out.as<uint32_t>(),
-                       L->sort_vals_in.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), nnz, vbits + bbits, stream));
-    blk_count_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)nnz, cpb,
-                                                              L->brow_ptr.as<int>());
-    blk_scan_kernel<<<1, kBlock, 0, stream>>>(L->brow_ptr.as<int>(), (int)nblocks, L->counters.as<int>() + 40);
-    PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned + 40, L->counters.as<int>() + 40, 8, hipMemcpyDeviceToHost, stream));
-    PLX_HIP_TRY(hipStreamSynchronize(stream));          // R_b sizes the row tables
-    const int64_t nrows = L->h_pinned[40];
-    L->n_brows = nrows;
-    L->blk_max_rows = L->h_pinned[41];
-    if (g_block_path == 1 && 10 * nrows > 7 * nnz) return PLX_OK;   // too little sharing inside blocks: CSR path
-    PLX_TRY(ensure(L->brow_vid, (size_t)nrows * 4 + 16));
-    PLX_TRY(ensure(L->s2_idx, (size_t)nrows * 4 + 16));
-    PLX_TRY(ensure(L->s2_ptr, (size_t)(m + 2) * 4));
-    PLX_TRY(ensure(L->partial, (size_t)nrows * 4 + 16));
-    blk_fill_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(
-        L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n, (int)L->own_begin, n_own,
-        (int)nnz, cpb, P, (uint32_t)((1ull << vbits) - 1), L->brow_ptr.as<int>(), L->bc_pt.as<uint16_t>(),
-        L->bc_w.as<float>(), L->brow_vid.as<int>(), L->srow.as<uint16_t>(), L->srow_stride);
-    // vertex -> its block rows
-    size_t temp2 = 0;
-    PLX_TRY(sort_pairs_temp_bytes(nrows, vbits, &temp2));
-    PLX_TRY(ensure(L->sort_temp, temp2 + 16));
-    blk_iota_kernel<<<ceil_div(nrows, kBlock), kBlock, 0, stream>>>(L->brow_vid.as<int>(), (int)nrows,
-                                                                    L->sort_keys_in.as<uint32_t>(),
-                                                                    L->sort_vals_in.as<uint32_t>());
-    PLX_TRY(sort_pairs(L->sort_temp.p, temp2, L->sort_keys_in.as<uint32_t>(), L->sort_keys_out.as<uint32_t>(),
-                       L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, stream));
-    blk_rowptr_kernel<<<ceil_div(m + 1, kBlock), kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)nrows, (int)m,
-                                                                      L->s2_ptr.as<int>());
-    PLX_HIP_TRY(hipGetLastError());
-    L->use_blocks = true;
-    return PLX_OK;
-}
-
 // ----------------------------------------------------------------------------
 // splat, stage 1: one workgroup per block.
 
-template <int E>
-__global__ __launch_bounds__(1024) void splat_block_kernel(const uint16_t *__restrict__ bc_pt, const float *__restrict__ bc_w,
+template <int E, int T>
+__global__ __launch_bounds__(T) void splat_block_kernel(const uint16_t *__restrict__ bc_pt, const float *__restrict__ bc_w,
                                                            const int *__restrict__ brow_ptr, const float *__restrict__ src,
                                                            const uint32_t *__restrict__ perm, int own_begin, int n_own,
                                                            int nnz, int P, int cpb, float *__restrict__ partial)
 {
-    extern __shared__ float lds_src[];                  // [P] source values of the block's points
-    __shared__ int w_cnt[16];
-    __shared__ float w_tail[16];
+    extern __shared__ float lds_src[];                  // [P] source values of the block's points, then [rows] row sums
+    __shared__ int w_cnt[T / 64];
+    __shared__ float w_tail[T / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int p0 = b * P, np = min(P, n_own - p0);
@@ -287,7 +215,7 @@ __global__ __launch_bounds__(1024) void splat_block_kernel(const uint16_t *__res
         }
     }
     // source window; perm == nullptr: rows are already in lattice order
-    for (int i = tid; i < np; i += blockDim.x) {
+    for (int i = tid; i < np; i += T) {
         const int row = perm ? (int)perm[own_begin + p0 + i] - own_begin : p0 + i;
         lds_src[i] = src[row];
     }
@@ -331,63 +259,143 @@ __global__ __launch_bounds__(1024) void splat_block_kernel(const uint16_t *__res
         pcnt += c;
     }
     float run = xcnt > 0 ? xtail : ptail + xtail;       // what the open row holds when it reaches this thread
-    float *dst = partial + brow_ptr[b] + pcnt + xcnt;   // first row that ends in this thread
+    // Row sums go through LDS (behind the source window) and leave as coalesced stores: written straight from
+    // here they are one 4-byte request per row end (2.8e6 of them at N = 1e6: 6 us of the kernel).
+    float *rowsum = lds_src + P;
+    int r = pcnt + xcnt;                                // first row that ends in this thread
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const bool end = ((ptw[j / 2] >> (16 * (j & 1))) & 0x8000u) != 0;
         run += prod[j];
-        if (end) { *dst++ = run; run = 0.f; }
+        if (end) { rowsum[r++] = run; run = 0.f; }
+    }
+    __syncthreads();
+    const int base = brow_ptr[b], rows = brow_ptr[b + 1] - base;
+    for (int j = tid; j < rows; j += T) partial[base + j] = rowsum[j];
+}
+
+// splat, stage 2: values[v] = sum of v's block-row partials, in block order.  The block rows are sorted by vertex
+// (s2_idx, bit 31 = last row of its vertex; s2_vid = the vertex, read at row ends only).  One wave per ~kCombineRun
+// entries -- a balanced share whatever the row lengths (1 .. number of blocks): the wave's range starts at the first
+// vertex row that begins at or after entry w * kCombineRun (s2_wave: built with the tables), the lanes take
+// consecutive entries, gather their partials and reduce them by vertex with the same fixed-tree segmented scan as
+// stage 1; a row that crosses a 64-entry step is carried in a register.  (A first version with one thread per
+// vertex and a serial loop over its rows ran 35 us at N = 1e6: every wave waited for its longest row.)
+
+__global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__restrict__ s2_wave, const int *__restrict__ s2_idx,
+                                                               const int *__restrict__ s2_vid,
+                                                               const float *__restrict__ partial, int nwaves,
+                                                               float *__restrict__ values, int ntiles, int remap,
+                                                               int ablate)
+{
+    // XCD-aware tile order: every XCD sweeps one contiguous eighth of the vertex-sorted rows, whose partials lie in
+    // about one eighth of the partial array (blocks and vertices both follow the lattice order): L2-resident gathers
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int lane = threadIdx.x & 63;
+    const int w = tile * (kBlock / 64) + (threadIdx.x >> 6);
+    if (w >= nwaves) return;                            // whole waves leave; no workgroup barrier below
+    const int e0 = s2_wave[w], e1 = s2_wave[w + 1];
+    float carry = 0.f;                                  // what the row open at the start of a step already holds
+    // EPL consecutive entries per lane (16-byte loads, aligned: the step starts at e0 rounded down and the entries
+    // before e0 -- the tail of the previous wave's last row -- are masked), summed in the thread, then ONE wave scan
+    // per 64 * EPL entries (a scan per 64 entries made the kernel issue-bound: 12 us with every load switched off)
+    constexpr int EPL = 4;
+    for (int base = e0 & ~3; base < e1; base += EPL * 64) {
+        const int k0 = base + EPL * lane;
+        int idx[EPL], vid[EPL];
+#pragma unroll
+        for (int q = 0; q < EPL / 4; ++q) {
+            int4 ix = make_int4(0, 0, 0, 0), vx = make_int4(0, 0, 0, 0);
+            if (k0 + 4 * q < e1) {
+                const int kq = k0 + 4 * q;
+                ix = (ablate & 2) ? make_int4(kq, kq + 1, kq + 2, (int)(0x80000000u | (uint32_t)(kq + 3)))
+                                  : *reinterpret_cast<const int4 *>(s2_idx + kq);
+                vx = *reinterpret_cast<const int4 *>(s2_vid + kq);
+            }
+            idx[4 * q] = ix.x; idx[4 * q + 1] = ix.y; idx[4 * q + 2] = ix.z; idx[4 * q + 3] = ix.w;
+            vid[4 * q] = vx.x; vid[4 * q + 1] = vx.y; vid[4 * q + 2] = vx.z; vid[4 * q + 3] = vx.w;
+        }
+        float val[EPL];
+        bool end[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const bool live = k0 + j >= e0 && k0 + j < e1;
+            end[j] = live && idx[j] < 0;
+            val[j] = live ? ((ablate & 1) ? 1.0f : partial[idx[j] & 0x7FFFFFFF]) : 0.f;
+        }
+        // this thread's scan element (row ends seen, sum since the last row end): as in splat_block_kernel
+        int icnt = 0;
+        float itail = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            itail = end[j] ? 0.f : itail + val[j];
+            icnt += end[j] ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int ocnt = __shfl_up(icnt, off);
+            const float otail = __shfl_up(itail, off);
+            if (lane >= off) {
+                itail = icnt > 0 ? itail : otail + itail;
+                icnt += ocnt;
+            }
+        }
+        int xcnt = __shfl_up(icnt, 1);
+        float xtail = __shfl_up(itail, 1);
+        if (lane == 0) { xcnt = 0; xtail = 0.f; }
+        float run = xcnt > 0 ? xtail : carry + xtail;   // what the open row holds when it reaches this thread
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            run += val[j];
+            if (end[j]) {
+                if (!(ablate & 4)) values[vid[j]] = run;
+                run = 0.f;
+            }
+        }
+        const int tcnt = __shfl(icnt, 63);
+        const float ttail = __shfl(itail, 63);
+        carry = tcnt > 0 ? ttail : carry + ttail;
     }
 }
 
-// splat, stage 2: values[v] = sum of v's block-row partials, in block order
-__global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__restrict__ s2_ptr, const int *__restrict__ s2_idx,
-                                                               const float *__restrict__ partial, int m,
-                                                               float *__restrict__ values, int ntiles, int remap)
+// bit 31 of s2_idx = last block row of its vertex; s2_wave[w] = first entry >= w * kCombineRun that starts a vertex row
+__global__ __launch_bounds__(kBlock) void blk_s2_finish_kernel(int *__restrict__ s2_idx, const int *__restrict__ s2_vid,
+                                                               const int *__restrict__ s2_ptr, int nrows, int nwaves,
+                                                               int *__restrict__ s2_wave)
 {
-    const int tile = tile_index(ntiles, remap);
-    if (tile < 0) return;
-    const int v = tile * kBlock + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int lo = 0, hi = 0;
-    if (v < m) { lo = s2_ptr[v]; hi = s2_ptr[v + 1]; }
-    const int len = hi - lo;
-    float acc = 0.f;
-    if (len <= kLongRow) {
-        int k = lo;
-        for (; k + 4 <= hi; k += 4) {
-            const int i0 = s2_idx[k], i1 = s2_idx[k + 1], i2 = s2_idx[k + 2], i3 = s2_idx[k + 3];
-            const float g0 = partial[i0], g1 = partial[i1], g2 = partial[i2], g3 = partial[i3];
-            acc = (((acc + g0) + g1) + g2) + g3;
-        }
-        for (; k < hi; ++k) acc += partial[s2_idx[k]];
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < nrows) {
+        const bool end = (k + 1 == nrows) || s2_vid[k + 1] != s2_vid[k];
+        if (end) s2_idx[k] |= (int)0x80000000u;
     }
-    // long rows: the whole wave, lanes striding the row, then a fixed butterfly
-    unsigned long long todo = __ballot(len > kLongRow);
-    while (todo) {
-        const int who = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int l = __shfl(lo, who), h = __shfl(hi, who);
-        float part = 0.f;
-        for (int k = l + lane; k < h; k += 64) part += partial[s2_idx[k]];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-        if (lane == who) acc = part;
+    if (k <= nwaves) {
+        int e = k * kCombineRun;
+        if (e >= nrows) e = nrows;
+        else if (e > 0 && s2_vid[e - 1] == s2_vid[e]) e = s2_ptr[s2_vid[e] + 1];   // inside a row: it belongs to the wave before
+        s2_wave[k] = e;
     }
-    if (v < m) values[v] = acc;
 }
 
 int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream)
 {
     const int n_own = (int)(L->own_end - L->own_begin);
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
-    const size_t lds = (size_t)L->blk_P * 4;
-    splat_block_kernel<kBlkE><<<(unsigned)L->nblocks, L->blk_T, lds, stream>>>(
-        L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->brow_ptr.as<int>(), d_src, perm, (int)L->own_begin, n_own,
-        (int)L->nnz, L->blk_P, L->blk_cpb, L->partial.as<float>());
-    const int nt = ceil_div(L->m, kBlock);
+    const size_t lds = ((size_t)L->blk_P + (size_t)L->blk_max_rows) * 4;
+#define PLX_LAUNCH(T)                                                                                                  \
+    splat_block_kernel<kBlkE, T><<<(unsigned)L->nblocks, T, lds, stream>>>(                                            \
+        L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->brow_ptr.as<int>(), d_src, perm, (int)L->own_begin, n_own,    \
+        (int)L->nnz, L->blk_P, L->blk_cpb, L->partial.as<float>())
+    if (L->blk_T == 256) PLX_LAUNCH(256);
+    else if (L->blk_T == 512) PLX_LAUNCH(512);
+    else PLX_LAUNCH(1024);
+#undef PLX_LAUNCH
+    // vertices no owned point touches (a rank's share of a sharded lattice) have no block rows: zero them first
+    if (L->n_shards != 1 || L->partial_cover) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)L->m * 4, stream));
+    const int nt = ceil_div(L->n_s2waves, kBlock / 64);
     splat_combine_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
-        L->s2_ptr.as<int>(), L->s2_idx.as<int>(), L->partial.as<float>(), (int)L->m, d_values, nt, g_xcd_remap);
+        L->s2_wave.as<int>(), L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->partial.as<float>(), (int)L->n_s2waves, d_values,
+        nt, g_xcd_remap, g_block_ablate);
     L->kn_splat = "splat_block_kernel+splat_combine_kernel";
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());
@@ -405,16 +413,18 @@ __global__ __launch_bounds__(1024) void slice_block_kernel(const uint16_t *__res
                                                            const float *__restrict__ values, const uint32_t *__restrict__ perm,
                                                            int own_begin, int n_own, int P, float rden,
                                                            float *__restrict__ out, const float *__restrict__ affine,
-                                                           const float *__restrict__ src)
+                                                           const float *__restrict__ src, int store_mode)
 {
     extern __shared__ float lds_val[];                  // values of the block's rows
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int p0 = b * P, np = min(P, n_own - p0);
     const int base = brow_ptr[b], rows = brow_ptr[b + 1] - base;
-    // the first point's replay records: in flight while the rows are gathered
+    // the first point's replay records: in flight while the rows are gathered (two points per round and thread was
+    // measured 10 % slower)
     uint32_t v[D1];
     float w[D1];
+    const int T = blockDim.x;
     int i = tid;
     if (i < np) {
 #pragma unroll
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(1024) void slice_block_kernel(const uint16_t *__res
             w[r] = ew[(size_t)r * n + own_begin + p0 + i];
         }
     }
-    for (int j = tid; j < rows; j += blockDim.x) lds_val[j] = values[brow_vid[base + j]];
+    for (int j = tid; j < rows; j += T) lds_val[j] = values[brow_vid[base + j]];
     __syncthreads();
     while (i < np) {
         float acc = 0.f;
@@ -431,8 +441,10 @@ __global__ __launch_bounds__(1024) void slice_block_kernel(const uint16_t *__res
         for (int r = 0; r < D1; ++r) acc += w[r] * lds_val[v[r]] * rden;
         const int row = perm ? (int)perm[own_begin + p0 + i] - own_begin : p0 + i;
         if (affine) acc = affine[0] * acc + affine[1] * src[row];      // out = a K src + b src (plx_apply_affine)
-        out[row] = acc;
-        i += blockDim.x;
+        if (store_mode == 1) __builtin_nontemporal_store(acc, out + row);
+        else if (store_mode == 2) __hip_atomic_store(out + row, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[row] = acc;
+        i += T;
         if (i < np) {
 #pragma unroll
             for (int r = 0; r < D1; ++r) {
@@ -455,7 +467,8 @@ int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStr
     case D1:                                                                                                            \
         slice_block_kernel<D1><<<(unsigned)L->nblocks, L->blk_T, lds, stream>>>(                                        \
             L->srow.as<uint16_t>(), L->srow_stride, L->ew.as<float>(), (int)L->n, L->brow_ptr.as<int>(),                \
-            L->brow_vid.as<int>(), d_values, perm, (int)L->own_begin, n_own, L->blk_P, rden, d_out, d_affine, d_src);  \
+            L->brow_vid.as<int>(), d_values, perm, (int)L->own_begin, n_own, L->blk_P, rden, d_out, d_affine, d_src,   \
+            perm ? g_scatter_store : 0);                                                                                \
         break;
         PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9)
         PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17)
@@ -468,5 +481,87 @@ int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStr
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }
+
+// ----------------------------------------------------------------------------
+// Block tables for the owned points of a built lattice (evid / ew / perm final).  Leaves L->use_blocks.
+int build_blocks(plx_lattice *L, hipStream_t stream)
+{
+    L->use_blocks = false;
+    const int d1 = L->d + 1;
+    const int n = (int)L->n, n_own = (int)(L->own_end - L->own_begin);
+    const int64_t nnz = L->nnz, m = L->m;
+    if (g_block_path == 0 || nnz == 0 || m == 0) return PLX_OK;
+    // the path pays when corners share vertices: with m > nnz / 2 most block rows hold a single corner and the
+    // two-stage splat only adds a pass (the sparse regime keeps the vertex-sorted CSR path)
+    if (g_block_path == 1 && 2 * m > nnz) return PLX_OK;
+    const int T = (g_block_threads == 512) ? 512 : (g_block_threads == 1024 ? 1024 : 256);
+    const int C = T * kBlkE;
+    int P = (C / d1) & ~7;                       // points per block: whole 16-byte vectors of every per-corner array
+    if (P < 8) return PLX_OK;
+    if (P > 32760) P = 32760;                    // 15-bit block-local point index
+    const int cpb = P * d1;                      // corners per (full) block
+    const int64_t nblocks = (n_own + P - 1) / P;
+    int vbits = 1, bbits = 0;
+    while ((1ll << vbits) < m) ++vbits;
+    while ((1ll << bbits) < nblocks) ++bbits;
+    if (vbits + bbits > 32) return PLX_OK;       // (block, vertex) does not fit a 32-bit sort key: CSR path
+    L->blk_P = P; L->blk_T = T; L->blk_cpb = cpb; L->nblocks = nblocks;
+    L->srow_stride = ((int64_t)n_own + 7) & ~7ll;
+
+    size_t temp_bytes = 0;
+    PLX_TRY(sort_pairs_temp_bytes(nnz, vbits + bbits, &temp_bytes));
+    PLX_TRY(ensure(L->sort_keys_in, (size_t)nnz * 4));
+    PLX_TRY(ensure(L->sort_keys_out, (size_t)nnz * 4 + 16));
+    PLX_TRY(ensure(L->sort_vals_in, (size_t)nnz * 4));
+    PLX_TRY(ensure(L->sort_vals_out, (size_t)nnz * 4));
+    PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
+    PLX_TRY(ensure(L->bc_pt, (size_t)nnz * 2 + 64));
+    PLX_TRY(ensure(L->bc_w, (size_t)nnz * 4 + 64));
+    PLX_TRY(ensure(L->srow, (size_t)d1 * L->srow_stride * 2 + 64));
+    PLX_TRY(ensure(L->brow_ptr, (size_t)(nblocks + 1) * 4));
+
+    blk_keys_kernel<<<dim3(ceil_div(n_own, kBlock), d1), kBlock, 0, stream>>>(
+        L->evid.as<int>(), n, (int)L->own_begin, n_own, P, vbits, L->sort_keys_in.as<uint32_t>(),
+        L->sort_vals_in.as<uint32_t>());
+    PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(), L->sort_keys_out.as<uint32_t>(),
+                       L->sort_vals_in.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), nnz, vbits + bbits, stream));
+    blk_count_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)nnz, cpb,
+                                                              L->brow_ptr.as<int>());
+    blk_scan_kernel<<<1, kBlock, 0, stream>>>(L->brow_ptr.as<int>(), (int)nblocks, L->counters.as<int>() + 40);
+    PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned + 40, L->counters.as<int>() + 40, 8, hipMemcpyDeviceToHost, stream));
+    PLX_HIP_TRY(hipStreamSynchronize(stream));          // R_b sizes the row tables
+    const int64_t nrows = L->h_pinned[40];
+    L->n_brows = nrows;
+    L->blk_max_rows = L->h_pinned[41];
+    if (g_block_path == 1 && 10 * nrows > 7 * nnz) return PLX_OK;   // too little sharing inside blocks: CSR path
+    PLX_TRY(ensure(L->brow_vid, (size_t)nrows * 4 + 16));
+    PLX_TRY(ensure(L->s2_idx, (size_t)nrows * 4 + 64));
+    PLX_TRY(ensure(L->s2_ptr, (size_t)(m + 2) * 4));
+    PLX_TRY(ensure(L->s2_vid, (size_t)nrows * 4 + 64));
+    L->n_s2waves = (nrows + kCombineRun - 1) / kCombineRun;
+    PLX_TRY(ensure(L->s2_wave, (size_t)(L->n_s2waves + 2) * 4));
+    PLX_TRY(ensure(L->partial, (size_t)nrows * 4 + 16));
+    blk_fill_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(
+        L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n, (int)L->own_begin, n_own,
+        (int)nnz, cpb, P, (uint32_t)((1ull << vbits) - 1), L->brow_ptr.as<int>(), L->bc_pt.as<uint16_t>(),
+        L->bc_w.as<float>(), L->brow_vid.as<int>(), L->srow.as<uint16_t>(), L->srow_stride);
+    // vertex -> its block rows
+    size_t temp2 = 0;
+    PLX_TRY(sort_pairs_temp_bytes(nrows, vbits, &temp2));
+    PLX_TRY(ensure(L->sort_temp, temp2 + 16));
+    blk_iota_kernel<<<ceil_div(nrows, kBlock), kBlock, 0, stream>>>(L->brow_vid.as<int>(), (int)nrows,
+                                                                    L->sort_keys_in.as<uint32_t>(),
+                                                                    L->sort_vals_in.as<uint32_t>());
+    PLX_TRY(sort_pairs(L->sort_temp.p, temp2, L->sort_keys_in.as<uint32_t>(), L->s2_vid.as<uint32_t>(),
+                       L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, stream));
+    blk_rowptr_kernel<<<ceil_div(m + 1, kBlock), kBlock, 0, stream>>>(L->s2_vid.as<uint32_t>(), (int)nrows, (int)m,
+                                                                      L->s2_ptr.as<int>());
+    blk_s2_finish_kernel<<<ceil_div(std::max<int64_t>(nrows, L->n_s2waves + 1), kBlock), kBlock, 0, stream>>>(
+        L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->s2_ptr.as<int>(), (int)nrows, (int)L->n_s2waves, L->s2_wave.as<int>());
+    PLX_HIP_TRY(hipGetLastError());
+    L->use_blocks = true;
+    return PLX_OK;
+}
+
 
 }  // namespace plx

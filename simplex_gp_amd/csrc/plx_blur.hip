@@ -155,6 +155,127 @@ __global__ __launch_bounds__(kBlock) void blur_axis_compact_kernel(const float *
     }
 }
 
+// ----------------------------------------------------------------------------
+// vd == 1, order 1, cache-resident lattices: TWO axes per launch.
+//
+// On a coarse lattice (N = 1e6, d = 8, lengthscale 1: m = 4e5, 1.6 MB of values, 3.2 MB of neighbour ids per axis) a
+// blur pass moves 6.4 MB and takes 5.8 us however it is tiled: it is a dependent-launch boundary plus two memory
+// latencies (ids, then gathers) from a cold L2 -- the XCD L2s are written back and invalidated at every kernel
+// boundary.  d+1 = 9 of them were 52 us of a 110 us MVM.  Two consecutive passes (axis i, then axis j) are
+//     out[v] = sum_b c_b * tmp[nbr_j(v, b)],   tmp[u] = sum_a c_a * old[nbr_i(u, a)]            (h:539-549 twice)
+// i.e. a 3x3 stencil over the composite neighbours nbr_i(nbr_j(v, b), a), which depend on the lattice only: they are
+// tabulated once per build (pair_nbr, 8 ids per vertex and pair; an absent intermediate vertex nbr_j(v, b) makes its
+// three composites absent, exactly as the two-pass form never reads tmp there).  The inner sums are formed from zero
+// in tap order like a single pass, then the outer sum likewise: the same fp32 operations in the same order as two
+// launches, half the launches.  Costs 8 instead of 2 x 2 id loads and 8 instead of 2 x 2 gathers per vertex, which
+// only pays while the pass is latency-bound: lattices of up to kPairMaxVertices vertices.
+constexpr int kPairMaxVertices = 1200000;
+int g_blur_fuse = 1;     // 0: one axis per launch; 1: axis pairs when order = 1, vd = 1 and m <= kPairMaxVertices; 2: whenever order = 1
+
+// slot = 3 * (b + 1) + (a + 1) without the centre (b = a = 0): 0..3 -> (b,a) = (-1,-1) (-1,0) (-1,+1) (0,-1); 4..7 -> (0,+1) (+1,-1) (+1,0) (+1,+1)
+__global__ __launch_bounds__(kBlock) void pair_nbr_kernel(const int *__restrict__ nbr, int m, int64_t mstride, int axis_i,
+                                                          int axis_j, int *__restrict__ out)
+{
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= m) return;
+    const int *ni = nbr + (size_t)axis_i * 2 * mstride, *nj = nbr + (size_t)axis_j * 2 * mstride;
+    int slot = 0;
+#pragma unroll
+    for (int b = -1; b <= 1; ++b) {
+        const int u = b == 0 ? v : nj[(size_t)(b < 0 ? 0 : 1) * mstride + v];
+#pragma unroll
+        for (int a = -1; a <= 1; ++a) {
+            if (a == 0 && b == 0) continue;
+            int id = -1;
+            if (u >= 0) id = a == 0 ? u : ni[(size_t)(a < 0 ? 0 : 1) * mstride + u];
+            out[(size_t)slot * mstride + v] = id;
+            ++slot;
+        }
+    }
+}
+
+template <int VPT>
+__global__ __launch_bounds__(kBlock) void blur_pair_v1_kernel(const float *__restrict__ old, float *__restrict__ out,
+                                                              const int *__restrict__ pn, int m, int64_t mstride,
+                                                              TapArgs taps, int ntiles, int remap)
+{
+    using ivec = typename std::conditional<VPT == 4, int4, int2>::type;
+    using fvec = typename std::conditional<VPT == 4, float4, float2>::type;
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int i0 = (tile * kBlock + threadIdx.x) * VPT;
+    if (i0 >= m) return;
+    int id[8][VPT];
+    float c[VPT];
+    if (i0 + VPT <= m) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const ivec v = *reinterpret_cast<const ivec *>(pn + s * mstride + i0);
+            const int *pv = reinterpret_cast<const int *>(&v);
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) id[s][j] = pv[j];
+        }
+        const fvec cv = *reinterpret_cast<const fvec *>(old + i0);
+        const float *pc = reinterpret_cast<const float *>(&cv);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) c[j] = pc[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const bool in = i0 + j < m;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) id[s][j] = in ? pn[s * mstride + i0 + j] : -1;
+            c[j] = in ? old[i0 + j] : 0.f;
+        }
+    }
+    float g[8][VPT];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) g[s][j] = id[s][j] >= 0 ? old[id[s][j]] : 0.f;
+    float r[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        // tmp at nbr_j(v, -1), v, nbr_j(v, +1): each from zero in tap order (a = -1, 0, +1), as one pass computes it
+        float tm = 0.f, t0 = 0.f, tp = 0.f;
+        tm += taps.c[0] * g[0][j]; tm += taps.c[1] * g[1][j]; tm += taps.c[2] * g[2][j];
+        t0 += taps.c[0] * g[3][j]; t0 += taps.c[1] * c[j];    t0 += taps.c[2] * g[4][j];
+        tp += taps.c[0] * g[5][j]; tp += taps.c[1] * g[6][j]; tp += taps.c[2] * g[7][j];
+        // an absent intermediate vertex contributes 0 (its three composites are absent, so its tmp is an exact 0)
+        float acc = 0.f;
+        acc += taps.c[0] * tm; acc += taps.c[1] * t0; acc += taps.c[2] * tp;
+        r[j] = acc;
+    }
+    if (i0 + VPT <= m) {
+        fvec res;
+        float *pr = reinterpret_cast<float *>(&res);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) pr[j] = r[j];
+        *reinterpret_cast<fvec *>(out + i0) = res;
+    } else {
+#pragma unroll
+        for (int j = 0; j < VPT; ++j)
+            if (i0 + j < m) out[i0 + j] = r[j];
+    }
+}
+
+// composite neighbour tables for the axis pairs (0,1), (2,3), ...; called by the lattice build
+int build_blur_pairs(plx_lattice *L, hipStream_t stream)
+{
+    L->use_pairs = false;
+    const int d1 = L->d + 1, m = (int)L->m;
+    if (g_blur_fuse == 0 || L->order != 1 || d1 < 2 || m == 0) return PLX_OK;
+    if (g_blur_fuse == 1 && m > kPairMaxVertices) return PLX_OK;
+    const int npairs = d1 / 2;
+    PLX_TRY(ensure(L->pair_nbr, (size_t)npairs * 8 * L->mstride * 4 + 64));
+    for (int p = 0; p < npairs; ++p)
+        pair_nbr_kernel<<<ceil_div(m, kBlock), kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, 2 * p, 2 * p + 1,
+                                                                    L->pair_nbr.as<int>() + (size_t)p * 8 * L->mstride);
+    PLX_HIP_TRY(hipGetLastError());
+    L->use_pairs = true;
+    return PLX_OK;
+}
+
 // vd == 1 on a lattice so small that both ping-pong copies of the vertex values fit in LDS (m <= kSmallM): every
 // pass is launch-bound there (a few us of host + device launch cost for < 1 us of work), so ONE workgroup runs all
 // d+1 passes with a barrier between them.  Same tap order as the per-axis kernels: bit-identical results.
@@ -376,8 +497,24 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
         return PLX_ERR_TOO_LARGE;
     }
     float *cur = d_values, *nxt = d_scratch;
+    bool paired = false;
     for (int axis = 0; axis < d1; ++axis) {
         const int *nb = L->nbr.as<int>() + (size_t)axis * 2 * order * L->mstride;
+        if (v1 && order == 1 && L->use_pairs && !L->use_compact && g_blur_fuse != 0 && axis + 1 < d1) {
+            // axes (axis, axis + 1) in one launch
+            const int *pn = L->pair_nbr.as<int>() + (size_t)(axis / 2) * 8 * L->mstride;
+            if (g_blur_vpt == 4) {
+                const int nt = ceil_div(ceil_div(m, 4), kBlock);
+                blur_pair_v1_kernel<4><<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, pn, m, L->mstride, L->taps, nt, g_xcd_remap);
+            } else {
+                const int nt = ceil_div(ceil_div(m, 2), kBlock);
+                blur_pair_v1_kernel<2><<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, pn, m, L->mstride, L->taps, nt, g_xcd_remap);
+            }
+            paired = true;
+            ++axis;
+            float *t = cur; cur = nxt; nxt = t;
+            continue;
+        }
         if (v1 && L->use_compact) {
             const uint32_t *cm = L->cmask.as<uint32_t>() + (size_t)axis * L->nquads;
             const uint32_t *cb = L->cbase.as<uint32_t>() + (size_t)axis * (L->nqwaves + 1);
@@ -395,7 +532,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             case 2: launch_blur_v1<2>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             default: launch_blur_v1<3>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             }
-            L->kn_blur = "blur_axis_v1_kernel";
+            L->kn_blur = paired ? "blur_pair_v1_kernel+blur_axis_v1_kernel" : "blur_axis_v1_kernel";
         } else if (vd == 1) {
             launch_blur_general<float>(cur, nxt, nb, m, L->mstride, 1, order, L->taps, stream);
             L->kn_blur = "blur_axis_kernel";
@@ -431,6 +568,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
         }
         float *t = cur; cur = nxt; nxt = t;
     }
+    if (paired && (d1 & 1) == 0) L->kn_blur = "blur_pair_v1_kernel";
     tmark(L, stream);
     *result_in_scratch = (cur == d_scratch) ? 1 : 0;
     PLX_HIP_TRY(hipGetLastError());

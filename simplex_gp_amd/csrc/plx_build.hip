@@ -965,6 +965,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
                                                                      L->nbr.as<int>());
         }
     }
+    PLX_TRY(build_blur_pairs(L, stream));      // composite neighbours for the two-axes-per-launch blur (coarse lattices)
     // compacted copy for sparse lattices (used by the vd = 1 blur when under half the neighbours exist)
     // Neighbourhoods are only sparse when most corners created a vertex of their own (measured: m/E = 0.19 ->
     // 57 % of the slots exist, 0.8 -> ~30 %, 0.99 -> 12 %), so the count + host sync is skipped for denser lattices.

@@ -96,6 +96,8 @@ struct plx_lattice {
     plx::DevBuf cmask;      // uint32 [d+1][nquads]
     plx::DevBuf cbase;      // uint32 [d+1][nqwaves + 1]
     plx::DevBuf cids;       // int32  [total existing neighbours]
+    bool use_pairs = false;      // pair_nbr holds the composite neighbours of the axis pairs (0,1), (2,3), ... (plx_blur.hip)
+    plx::DevBuf pair_nbr;   // int32  [(d+1)/2][8][mstride]  nbr_i(nbr_j(v, b), a) without the centre; -1 absent
     plx::DevBuf csr_pt;     // int32  [nnz]          local (owned) point index, sorted by vertex
     plx::DevBuf csr_row;    // int32  [nnz]          the same points numbered as the caller's rows (vd = 1 splat
                             //                       gathers straight from d_src, no sorted copy)
@@ -117,8 +119,11 @@ struct plx_lattice {
     plx::DevBuf srow;       // uint16 [d+1][srow_stride]  block-local row of corner r of owned point p (slice)
     plx::DevBuf brow_ptr;   // int32  [nblocks+1]    first block row of every block
     plx::DevBuf brow_vid;   // int32  [n_brows]      vertex of every block row
-    plx::DevBuf s2_idx;     // int32  [n_brows]      block rows sorted by vertex
+    plx::DevBuf s2_idx;     // int32  [n_brows]      block rows sorted by vertex; bit 31: last row of its vertex
     plx::DevBuf s2_ptr;     // int32  [m+1]          block rows of vertex v: s2_idx[s2_ptr[v] .. s2_ptr[v+1])
+    plx::DevBuf s2_vid;     // int32  [n_brows]      vertex of every sorted block row (read at row ends)
+    plx::DevBuf s2_wave;    // int32  [n_s2waves+1]  first block row of every combine wave
+    int64_t n_s2waves = 0;
     plx::DevBuf partial;    // float  [n_brows]      per-MVM block-row sums
 
     // apply workspace
@@ -166,6 +171,7 @@ int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream);
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
+int build_blur_pairs(plx_lattice *L, hipStream_t stream);   // composite neighbour tables of the two-axes-per-launch blur
 int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream,
                const float *d_affine = nullptr, const float *d_src = nullptr, float *d_dot_partial = nullptr);
 // plx_linalg.hip: out[c] = sum over nblocks of partial[k * vd + c], fixed order

@@ -43,6 +43,9 @@ extern int g_insert_dedupe;
 extern int g_nbr_symmetric;
 extern int g_block_path;
 extern int g_block_threads;
+extern int g_block_ablate;
+extern int g_blur_fuse;
+extern int g_scatter_store;
 
 // Tile index for workgroup blockIdx.x.  With remap the launch has 8 * ceil(ntiles / 8) workgroups and
 // workgroup b takes tile (b % 8) * per + b / 8: workgroups are dealt to the 8 XCDs round-robin

@@ -447,7 +447,7 @@ def test_every_tap_order_at_every_row_width(plx, ntaps):
         oracle.set_exact_mode(True)
 
 
-@pytest.mark.parametrize("threads", [512, 1024])
+@pytest.mark.parametrize("threads", [256, 512, 1024])
 def test_block_tables_equal_csr_path(plx, threads):
     """vd = 1 through the block tables (plx_block.hip: block-local splat + per-vertex combine, LDS-staged slice) against
     the vertex-sorted CSR kernels and the oracle: caller row order, lattice row order, the affine epilogue, an owned
@@ -516,4 +516,38 @@ def test_block_tables_equal_csr_path(plx, threads):
             b.close()
     finally:
         nv.check(lib.plx_tune(b"block_path", 1), "plx_tune")
-        nv.check(lib.plx_tune(b"block_threads", 1024), "plx_tune")
+        nv.check(lib.plx_tune(b"block_threads", 256), "plx_tune")
+
+
+def test_blur_axis_pairs_equal_single_axis_passes(plx):
+    """Order-1, vd = 1 blur with two axes per launch (composite neighbour table) against one axis per launch: the
+    same fp32 operations in the same order, so the same bits; d + 1 even and odd, dense and sparse neighbourhoods."""
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    rng = np.random.default_rng(91)
+    try:
+        for n, d, scale in [(3000, 1, 1.0), (20000, 2, 1.0), (30000, 3, 0.5), (50000, 8, 1.0), (20000, 5, 0.2), (20011, 4, 1.0)]:
+            ref = (rng.standard_normal((n, d)) / scale).astype(np.float32)
+            src = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).cuda()
+            x = torch.from_numpy(ref).cuda()
+            outs, blurs = [], []
+            for mode in (0, 2):
+                nv.check(lib.plx_tune(b"blur_fuse", mode), "plx_tune")
+                nv.check(lib.plx_tune(b"blur_small", 0), "plx_tune")      # small lattices: per-axis kernels, not the LDS one
+                lat = plx.Lattice().build(x, taps)
+                vals = lat.splat(src)
+                blurs.append(lat.blur(vals.clone(), vd=1).clone())
+                outs.append(lat.apply(src).clone())
+                names = lat.stage_kernels()["blur_axis"]
+                assert ("blur_pair_v1_kernel" in names) == (mode == 2 and "blur_axis_compact_kernel" not in names), (mode, names)
+                lat.close()
+            assert torch.equal(blurs[0], blurs[1]), (n, d)
+            assert torch.equal(outs[0], outs[1]), (n, d)
+            oracle.set_exact_mode(False)
+            want = oracle.filter(src.cpu().numpy(), ref, taps)
+            oracle.set_exact_mode(True)
+            assert rel_l2(outs[1].cpu().numpy(), want) <= TOL_ORACLE
+    finally:
+        nv.check(lib.plx_tune(b"blur_fuse", 1), "plx_tune")
+        nv.check(lib.plx_tune(b"blur_small", 1), "plx_tune")
