@@ -32,6 +32,7 @@ int g_block_path = 1;        // 0 never, 1 when the lattice qualifies (see build
 int g_block_ablate = 0;      // diagnostics only: 1 combine without the partial gathers, 2 combine without idx loads too,
                              // 4 combine without stores, 8 splat_block without the LDS source reads
 int g_scatter_store = 0;     // slice's row-scattered output stores: 0 plain, 1 non-temporal, 2 agent-scope (write-through)
+int g_block_lds_sort = 1;    // 1: the corners of a block are sorted by one workgroup in LDS (256-thread blocks); 0: one global radix sort
 int g_block_threads = 256;   // threads per block workgroup (256, 512 or 1024); a block holds threads * kBlkE corners
 
 constexpr int kBlkE = 16;        // corners per thread of splat_block_kernel
@@ -496,8 +497,8 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     if (g_block_path == 1 && 2 * m > nnz) return PLX_OK;
     const int T = (g_block_threads == 512) ? 512 : (g_block_threads == 1024 ? 1024 : 256);
     const int C = T * kBlkE;
-    int P = (C / d1) & ~7;                       // points per block: whole 16-byte vectors of every per-corner array
-    if (P < 8) return PLX_OK;
+    int P = (C / d1) & ~15;                      // points per block: every thread's 16 corners are whole 16-byte vectors of the per-corner arrays
+    if (P < 16) return PLX_OK;
     if (P > 32760) P = 32760;                    // 15-bit block-local point index
     const int cpb = P * d1;                      // corners per (full) block
     const int64_t nblocks = (n_own + P - 1) / P;
@@ -520,13 +521,21 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     PLX_TRY(ensure(L->srow, (size_t)d1 * L->srow_stride * 2 + 64));
     PLX_TRY(ensure(L->brow_ptr, (size_t)(nblocks + 1) * 4));
 
-    blk_keys_kernel<<<dim3(ceil_div(n_own, kBlock), d1), kBlock, 0, stream>>>(
-        L->evid.as<int>(), n, (int)L->own_begin, n_own, P, vbits, L->sort_keys_in.as<uint32_t>(),
-        L->sort_vals_in.as<uint32_t>());
-    PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(), L->sort_keys_out.as<uint32_t>(),
-                       L->sort_vals_in.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), nnz, vbits + bbits, stream));
-    blk_count_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)nnz, cpb,
-                                                              L->brow_ptr.as<int>());
+    const bool lds_build = (T == 256 && vbits <= 30 && g_block_lds_sort != 0);
+    if (lds_build) {
+        // one workgroup per block: sort in LDS, per-corner records, row counts; the vertex lists go to sort_keys_in
+        PLX_TRY(sort_fill_blocks_lds(L->evid.as<int>(), L->ew.as<float>(), n, (int)L->own_begin, n_own, P, d1, cpb, vbits, nblocks,
+                                     L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->srow.as<uint16_t>(), L->srow_stride,
+                                     L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), stream));
+    } else {
+        blk_keys_kernel<<<dim3(ceil_div(n_own, kBlock), d1), kBlock, 0, stream>>>(
+            L->evid.as<int>(), n, (int)L->own_begin, n_own, P, vbits, L->sort_keys_in.as<uint32_t>(),
+            L->sort_vals_in.as<uint32_t>());
+        PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(), L->sort_keys_out.as<uint32_t>(),
+                           L->sort_vals_in.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), nnz, vbits + bbits, stream));
+        blk_count_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)nnz, cpb,
+                                                                  L->brow_ptr.as<int>());
+    }
     blk_scan_kernel<<<1, kBlock, 0, stream>>>(L->brow_ptr.as<int>(), (int)nblocks, L->counters.as<int>() + 40);
     PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned + 40, L->counters.as<int>() + 40, 8, hipMemcpyDeviceToHost, stream));
     PLX_HIP_TRY(hipStreamSynchronize(stream));          // R_b sizes the row tables
@@ -541,10 +550,14 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     L->n_s2waves = (nrows + kCombineRun - 1) / kCombineRun;
     PLX_TRY(ensure(L->s2_wave, (size_t)(L->n_s2waves + 2) * 4));
     PLX_TRY(ensure(L->partial, (size_t)nrows * 4 + 16));
-    blk_fill_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(
-        L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n, (int)L->own_begin, n_own,
-        (int)nnz, cpb, P, (uint32_t)((1ull << vbits) - 1), L->brow_ptr.as<int>(), L->bc_pt.as<uint16_t>(),
-        L->bc_w.as<float>(), L->brow_vid.as<int>(), L->srow.as<uint16_t>(), L->srow_stride);
+    if (lds_build) {
+        PLX_TRY(compact_block_rows(L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), cpb, nblocks, L->brow_vid.as<int>(), stream));
+    } else {
+        blk_fill_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(
+            L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n, (int)L->own_begin, n_own,
+            (int)nnz, cpb, P, (uint32_t)((1ull << vbits) - 1), L->brow_ptr.as<int>(), L->bc_pt.as<uint16_t>(),
+            L->bc_w.as<float>(), L->brow_vid.as<int>(), L->srow.as<uint16_t>(), L->srow_stride);
+    }
     // vertex -> its block rows
     size_t temp2 = 0;
     PLX_TRY(sort_pairs_temp_bytes(nrows, vbits, &temp2));

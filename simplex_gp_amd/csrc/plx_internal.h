@@ -70,6 +70,7 @@ struct plx_lattice {
     // lexicographic in the rounded lattice coordinates); every per-point array below is in that order
     plx::DevBuf perm;         // uint32 [n]
     plx::DevBuf sortkey_in, sortkey_out, iota;   // uint64 [n], uint64 [n], uint32 [n]
+    plx::DevBuf order_range;  // int32 [256]  per shard: extent of the rounded lattice coordinates (scales the 32-bit order key)
 
     // build scratch
     plx::DevBuf ekeys;      // uint32 [d+1][n][DW]   packed int16 keys of every simplex corner
@@ -167,6 +168,12 @@ int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t 
 int sort_pairs64_temp_bytes(int64_t n, int end_bit, size_t *bytes);
 int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                  const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit, hipStream_t stream);
+// block tables built in LDS, one workgroup per block (256-thread blocks): sort by vertex + every per-corner record;
+// the block's vertex list lands in rows_tmp[b * cpb + row] and is compacted once the row offsets are scanned
+int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin, int n_own, int P, int d1, int cpb, int vbits,
+                         int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
+                         int *rows, hipStream_t stream);
+int compact_block_rows(const int *rows_tmp, const int *brow_ptr, int cpb, int64_t nblocks, int *brow_vid, hipStream_t stream);
 // plx_splat.hip / plx_blur.hip / plx_slice.hip
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream);
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,

@@ -38,6 +38,7 @@ extern int g_splat_ablate;
 extern int g_blur_ablate;
 extern int g_sort_points;
 extern int g_order_zcurve;
+extern int g_order_key32;
 extern int g_compact_nbr;
 extern int g_insert_dedupe;
 extern int g_nbr_symmetric;
@@ -46,6 +47,7 @@ extern int g_block_threads;
 extern int g_block_ablate;
 extern int g_blur_fuse;
 extern int g_scatter_store;
+extern int g_block_lds_sort;
 
 // Tile index for workgroup blockIdx.x.  With remap the launch has 8 * ceil(ntiles / 8) workgroups and
 // workgroup b takes tile (b % 8) * per + b / 8: workgroups are dealt to the 8 XCDs round-robin

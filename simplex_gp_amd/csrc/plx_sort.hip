@@ -45,4 +45,139 @@ int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_
     return PLX_OK;
 }
 
+
+// ----------------------------------------------------------------------------
+// Block tables (plx_block.hip), built by ONE workgroup per point block, in LDS: the block's <= 4096 corners are
+// loaded in (corner, point) order and sorted by vertex id with rocPRIM's block radix sort (stable, so equal vertices
+// keep that order -- the order a global stable sort of (block, vertex) keys gives, which is what the other block
+// sizes use); row heads / ends, block-local row numbers and every per-corner record follow from the sorted registers.
+// Replaces a global radix sort of all nnz keys + a count pass + a fill pass (0.37 + 0.02 + 0.11 ms at N = 1e6, d = 8).
+// The block's vertex list goes to a block-strided scratch (rows_tmp[b * cpb + row]); blk_compact_kernel moves it
+// behind the row offsets once those are scanned.
+template <int IPT>
+__global__ __launch_bounds__(256) void blk_sort_fill_kernel(const int *__restrict__ evid, const float *__restrict__ ew, int n,
+                                                            int own_begin, int n_own, int P, int d1, int cpb, int vbits,
+                                                            uint16_t *__restrict__ bc_pt, float *__restrict__ bc_w,
+                                                            uint16_t *__restrict__ srow, int64_t sstride,
+                                                            int *__restrict__ rows_tmp, int *__restrict__ rows)
+{
+    using Sort = rocprim::block_radix_sort<uint32_t, 256, IPT, uint32_t>;
+    __shared__ typename Sort::storage_type storage;
+    __shared__ uint32_t edge_key[256 + 1];             // first key of every thread (+ a sentinel)
+    __shared__ uint32_t last_key[256];                 // last key of every thread
+    __shared__ int wave_sum[4];
+    extern __shared__ uint16_t srow_tile[];            // [d1][np] block-local row of every corner, point major per corner
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int p0 = b * P, np = min(P, n_own - p0), nc = np * d1;
+    uint32_t keys[IPT], vals[IPT];                      // vals: local corner c = r * np + i
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int c = tid * IPT + j;
+        if (c < nc) {
+            const int r = c / np, i = c - r * np;
+            keys[j] = (uint32_t)evid[(size_t)r * n + own_begin + p0 + i];
+            vals[j] = (uint32_t)c;
+        } else {
+            keys[j] = 0xFFFFFFFFu;                      // padding sorts behind every vertex (vbits <= 30)
+            vals[j] = 0u;
+        }
+    }
+    Sort().sort(keys, vals, storage, 0, (unsigned)vbits + 1);   // + 1: the padding key's top bit must take part
+    // neighbours across threads: the last key of the thread before, the first key of the thread after
+    edge_key[tid] = keys[0];
+    last_key[tid] = keys[IPT - 1];
+    if (tid == 0) edge_key[256] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t next_first = edge_key[tid + 1];
+    const uint32_t prev_last = tid == 0 ? 0u : last_key[tid - 1];
+    // heads: first corner of a vertex row; the block's first corner is one by construction
+    int heads = 0;
+    bool head[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int pos = tid * IPT + j;
+        const uint32_t prev = j == 0 ? prev_last : keys[j - 1];
+        head[j] = pos < nc && (pos == 0 || keys[j] != prev);
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) heads += head[j] ? 1 : 0;
+    // exclusive scan of the head counts over the workgroup
+    int incl = heads;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int before = incl - heads, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wv < wave) before += wave_sum[wv];
+        total += wave_sum[wv];
+    }
+    if (tid == 0) rows[b] = total;
+    // per-corner records
+    const size_t k0 = (size_t)b * cpb;
+    int lrow = before - 1;
+    uint32_t ptw[IPT / 2];
+    float wq[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int pos = tid * IPT + j;
+        lrow += head[j] ? 1 : 0;
+        const uint32_t nxt = j + 1 < IPT ? keys[j + 1] : next_first;
+        const bool live = pos < nc;
+        const bool end = live && (pos + 1 == nc || nxt != keys[j]);
+        const uint32_t c = vals[j];
+        const uint32_t r = live ? c / (uint32_t)np : 0u, i = live ? c - r * (uint32_t)np : 0u;
+        const uint32_t rec = live ? (i | (end ? 0x8000u : 0u)) : 0u;
+        if (j & 1) ptw[j / 2] |= rec << 16; else ptw[j / 2] = rec;
+        wq[j] = live ? ew[(size_t)r * n + own_begin + p0 + i] : 0.f;
+        if (live) srow_tile[c] = (uint16_t)lrow;
+        if (head[j]) rows_tmp[k0 + lrow] = (int)keys[j];
+    }
+    // blocked stores: 16 consecutive corners per thread = 32 bytes of bc_pt, 64 bytes of bc_w (the arrays have slack)
+    if (tid * IPT < nc) {
+#pragma unroll
+        for (int q = 0; q < IPT / 8; ++q)
+            *reinterpret_cast<uint4 *>(bc_pt + k0 + tid * IPT + 8 * q) = make_uint4(ptw[4 * q], ptw[4 * q + 1], ptw[4 * q + 2], ptw[4 * q + 3]);
+#pragma unroll
+        for (int q = 0; q < IPT / 4; ++q)
+            *reinterpret_cast<float4 *>(bc_w + k0 + tid * IPT + 4 * q) = make_float4(wq[4 * q], wq[4 * q + 1], wq[4 * q + 2], wq[4 * q + 3]);
+    }
+    __syncthreads();
+    for (int c = tid; c < nc; c += 256) {
+        const int r = c / np, i = c - r * np;
+        srow[(size_t)r * sstride + p0 + i] = srow_tile[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void blk_compact_kernel(const int *__restrict__ rows_tmp, const int *__restrict__ brow_ptr,
+                                                          int cpb, int *__restrict__ brow_vid)
+{
+    const int b = blockIdx.x;
+    const int base = brow_ptr[b], rows = brow_ptr[b + 1] - base;
+    for (int j = threadIdx.x; j < rows; j += 256) brow_vid[base + j] = rows_tmp[(size_t)b * cpb + j];
+}
+
+int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin, int n_own, int P, int d1, int cpb, int vbits,
+                         int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
+                         int *rows, hipStream_t stream)
+{
+    if (cpb > 256 * 16 || vbits > 30) return PLX_ERR_INVALID;
+    blk_sort_fill_kernel<16><<<(unsigned)nblocks, 256, (size_t)cpb * 2, stream>>>(evid, ew, n, own_begin, n_own, P, d1, cpb, vbits,
+                                                                                  bc_pt, bc_w, srow, sstride, rows_tmp, rows);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+int compact_block_rows(const int *rows_tmp, const int *brow_ptr, int cpb, int64_t nblocks, int *brow_vid, hipStream_t stream)
+{
+    blk_compact_kernel<<<(unsigned)nblocks, 256, 0, stream>>>(rows_tmp, brow_ptr, cpb, brow_vid);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
 }  // namespace plx

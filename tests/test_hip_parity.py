@@ -486,6 +486,13 @@ def test_block_tables_equal_csr_path(plx, threads):
             blurred = a.blur(va.clone(), vd=1)
             assert torch.equal(b.slice(blurred, vd=1), a.slice(blurred, vd=1))        # same arithmetic, same order
             assert torch.equal(b.apply(s), out_b)                                       # reproducible bits
+            if threads == 256:
+                # the per-block LDS sort and the global radix sort of (block, vertex) keys order the corners identically
+                nv.check(lib.plx_tune(b"block_lds_sort", 0), "plx_tune")
+                c = plx.Lattice().build(x, taps)
+                nv.check(lib.plx_tune(b"block_lds_sort", 1), "plx_tune")
+                assert c.block_rows == b.block_rows and torch.equal(c.apply(s), out_b), (n, d)
+                c.close()
             # affine epilogue and lattice row order
             ss = torch.tensor([0.7, 0.3], device="cuda")
             assert rel_l2(b.apply_affine(s, ss).cpu().numpy(), (0.7 * out_b + 0.3 * s).cpu().numpy()) <= 1e-6
@@ -517,6 +524,7 @@ def test_block_tables_equal_csr_path(plx, threads):
     finally:
         nv.check(lib.plx_tune(b"block_path", 1), "plx_tune")
         nv.check(lib.plx_tune(b"block_threads", 256), "plx_tune")
+        nv.check(lib.plx_tune(b"block_lds_sort", 1), "plx_tune")
 
 
 def test_blur_axis_pairs_equal_single_axis_passes(plx):
