@@ -39,7 +39,6 @@
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
-int g_order_key32 = 1;   // 1: 32-bit Z-curve key of the top varying bit planes (4 radix passes); 0: the 63-bit key (8 passes)
 int g_order_zcurve = 1;  // 1: points ordered along the Z-curve of their rounded lattice coordinates; 0: lexicographically
 int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only and mirrors the hits
                               // (fine regime 7.2 -> 4.9 ms; an occupancy bitmap on top did not pay)
@@ -204,86 +203,6 @@ __global__ __launch_bounds__(kBlock) void sortkey_kernel(const float *__restrict
             if (i < oa.ncoord) key = (key << oa.bits) | (unsigned long long)q[i];
     }
     keys[p] = key;
-    iota[p] = (uint32_t)p;
-}
-
-// 32-bit variant of the order key (the shipped one): the Z-curve key of the TOP bit planes that actually vary.
-// A first pass finds the largest rounded lattice coordinate of the cloud (one atomicMax per wave); the key kernel reads
-// it from device memory (no host round trip) and interleaves the planes from the top varying one downwards until
-// 32 bits are full.  1e6 points are resolved by ~20 key bits, and a block of the splat / slice tables spans far more
-// than one cell of a 32-bit key, so the planes that do not fit buy no locality -- but the 63-bit key cost 8 radix
-// passes over (8-byte key, 4-byte value) pairs, 165 us per build at N = 1e6; 32 bits are 4 cheaper passes.
-__device__ __forceinline__ uint32_t shard_of(int p, const OrderArgs &oa)
-{
-    const long long split = (oa.base + 1) * oa.extra;
-    return (oa.n_shards <= 1) ? 0u
-           : (uint32_t)((p < split) ? p / (oa.base + 1) : oa.extra + (p - split) / (oa.base > 0 ? oa.base : 1));
-}
-
-// range[s] = extent of shard s (every shard keys its points by its own extent, so that a rank which sees only its
-// shard -- plx_build_local -- orders it exactly as a rank that sees all shards does)
-template <int D>
-__global__ __launch_bounds__(kBlock) void order_range_kernel(const float *__restrict__ x, int n, ScaleArgs sf, OrderArgs oa,
-                                                             int *__restrict__ range)
-{
-    constexpr int D1 = D + 1;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    int big = 0;
-    if (p < n) {
-        float pos[D], el[D1];
-#pragma unroll
-        for (int i = 0; i < D; ++i) pos[i] = x[(size_t)p * D + i];
-        elevate<D>(pos, sf, el);
-#pragma unroll
-        for (int i = 0; i < D1; ++i) {
-            float c = rintf(el[i] * (1.0f / (float)D1));
-            c = fminf(fmaxf(c, -1.0e6f), 1.0e6f);
-            const int q = (int)c;
-            big = max(big, q < 0 ? -q : q + 1);            // planes needed: q in [-2^k, 2^k)
-        }
-    }
-    if (oa.n_shards <= 1) {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) big = max(big, __shfl_xor(big, off));
-        if ((threadIdx.x & 63) == 0 && big > 0) atomicMax(range, big);
-    } else if (p < n && big > 0) {
-        atomicMax(range + shard_of(p, oa), big);           // shards are contiguous row blocks: few distinct targets per wave
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(kBlock) void sortkey32_kernel(const float *__restrict__ x, int n, ScaleArgs sf, OrderArgs oa,
-                                                           const int *__restrict__ range, int shard_bits,
-                                                           uint32_t *__restrict__ keys, uint32_t *__restrict__ iota)
-{
-    constexpr int D1 = D + 1;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= n) return;
-    float pos[D], el[D1];
-#pragma unroll
-    for (int i = 0; i < D; ++i) pos[i] = x[(size_t)p * D + i];
-    elevate<D>(pos, sf, el);
-    // planes: smallest k with every coordinate of the point's shard in [-2^(k-1), 2^(k-1)); at most 20
-    const uint32_t shard = shard_of(p, oa);
-    const int big = range[shard];
-    int planes = 1;
-    while (planes < 20 && (1 << (planes - 1)) < big) ++planes;
-    const int half = 1 << (planes - 1), top = (1 << planes) - 1;
-    int q[D1];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        float c = rintf(el[i] * (1.0f / (float)D1));
-        c = fminf(fmaxf(c, -1.0e6f), 1.0e6f);                // NaN -> -1e6 (fmaxf), rejected later by embed
-        const int v = (int)c + half;
-        q[i] = v < 0 ? 0 : (v > top ? top : v);
-    }
-    uint32_t key = shard;
-    int room = 32 - shard_bits;
-    for (int b = planes - 1; b >= 0 && room > 0; --b)
-#pragma unroll
-        for (int i = 0; i < D1; ++i)
-            if (i < oa.ncoord && room > 0) { key = (key << 1) | (uint32_t)((q[i] >> b) & 1); --room; }
-    keys[p] = room > 0 ? key << room : key;
     iota[p] = (uint32_t)p;
 }
 
@@ -817,18 +736,6 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     PLX_HIP_TRY(hipMemsetAsync(L->table.p, 0xFF, (size_t)cap * 4, stream));
 
     mark();
-    if (g_sort_points && g_order_zcurve && g_order_key32) {
-        size_t temp32 = 0;
-        PLX_TRY(sort_pairs_temp_bytes(n, 32, &temp32));
-        PLX_TRY(ensure(L->sort_temp, temp32 + 16));
-        uint32_t *k_in = L->sortkey_in.as<uint32_t>(), *k_out = L->sortkey_out.as<uint32_t>();
-        PLX_TRY(ensure(L->order_range, 256 * 4));
-        PLX_HIP_TRY(hipMemsetAsync(L->order_range.p, 0, 256 * 4, stream));
-        order_range_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, n, sf, oa, L->order_range.as<int>());
-        sortkey32_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, n, sf, oa, L->order_range.as<int>(), shard_bits, k_in,
-                                                            L->iota.as<uint32_t>());
-        PLX_TRY(sort_pairs(L->sort_temp.p, temp32, k_in, k_out, L->iota.as<uint32_t>(), L->perm.as<uint32_t>(), n, 32, stream));
-    } else {
     sortkey_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, n, sf, oa, L->sortkey_in.as<unsigned long long>(),
                                                       L->iota.as<uint32_t>());
     if (g_sort_points) {
@@ -836,7 +743,6 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
                              L->iota.as<uint32_t>(), L->perm.as<uint32_t>(), n, key_bits, stream));
     } else {
         PLX_HIP_TRY(hipMemcpyAsync(L->perm.p, L->iota.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
-    }
     }
     embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, L->perm.as<uint32_t>(), n, sf, L->ekeys.as<uint32_t>(),
                                                     L->ew.as<float>(), L->counters.as<int>());

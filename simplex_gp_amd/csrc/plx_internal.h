@@ -70,7 +70,6 @@ struct plx_lattice {
     // lexicographic in the rounded lattice coordinates); every per-point array below is in that order
     plx::DevBuf perm;         // uint32 [n]
     plx::DevBuf sortkey_in, sortkey_out, iota;   // uint64 [n], uint64 [n], uint32 [n]
-    plx::DevBuf order_range;  // int32 [256]  per shard: extent of the rounded lattice coordinates (scales the 32-bit order key)
 
     // build scratch
     plx::DevBuf ekeys;      // uint32 [d+1][n][DW]   packed int16 keys of every simplex corner

@@ -38,7 +38,6 @@ extern int g_splat_ablate;
 extern int g_blur_ablate;
 extern int g_sort_points;
 extern int g_order_zcurve;
-extern int g_order_key32;
 extern int g_compact_nbr;
 extern int g_insert_dedupe;
 extern int g_nbr_symmetric;

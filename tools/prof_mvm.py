@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--ell", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--lattice-rows", action="store_true")
+    ap.add_argument("--builds", type=int, default=1, help="build the lattice this many times (timelines of a warm build)")
     ap.add_argument("--tune", nargs="*", default=[], help="key=value pairs for plx_tune")
     args = ap.parse_args()
     if args.stats:
@@ -47,7 +48,10 @@ def main():
     x = torch.randn(args.n, args.d, generator=g)
     v = torch.randn(args.n, args.vd, generator=g).cuda()
     ref = (x / args.ell).contiguous().cuda()
-    lat = plx.Lattice().build(ref, np.array([0.34608543, 1.0, 0.34608543], np.float32))
+    lat = plx.Lattice()
+    for _ in range(args.builds):
+        lat.build(ref, np.array([0.34608543, 1.0, 0.34608543], np.float32))
+        torch.cuda.synchronize()
     if args.lattice_rows:
         lat.set_lattice_row_order(True)
     out = torch.empty_like(v)
