@@ -16,7 +16,7 @@ from .lattice_kernel import (  # noqa: F401
     lattice_cache,
 )
 from .stencil import DiscretizedKernelFN, Matern, get_coeffs, matern, rbf  # noqa: F401
-from . import distributed, solvers, training  # noqa: F401
+from . import distributed, solvers, torch_ext, training  # noqa: F401
 
 __all__ = [
     "RBFLattice", "MaternLattice", "BilateralKernel", "LatticeAccelerated", "LatticeFilterGeneral",

@@ -29,7 +29,10 @@ class _LatticeCache:
 
     An entry holds a reference to its position tensor, so the allocator cannot
     hand the same address to different data while the entry lives; together
-    with tensor._version that makes (data_ptr, _version, shape, taps) a sound key.
+    with tensor._version that makes (data_ptr, _version, shape, taps) a sound key
+    for every write torch knows about.  Writes that bypass the version counter
+    (`x.data.copy_()`, a custom kernel or a DLPack alias writing into the same
+    storage) are NOT seen: call lattice_cache().clear() after such a write.
     """
 
     def __init__(self, capacity=4):
@@ -80,6 +83,9 @@ def cached_filter(src, ref, coeffs):
         raise ValueError("simplex_gp_amd has no CPU path: tensors must live on an MI355X (cuda) device")
     if src.dtype != torch.float32 or ref.dtype != torch.float32:
         raise TypeError(f"float32 only (got src {src.dtype}, ref {ref.dtype}); the reference CPU path is fp32 (h:277-278)")
+    if not ref.is_cuda or ref.device != src.device:
+        # checked before the cache is touched: a bad call must not evict a good lattice
+        raise ValueError(f"src ({src.device}) and ref ({ref.device}) must live on the same MI355X (cuda) device")
     lat = _cache.get(ref.contiguous() if not ref.is_contiguous() else ref, coeffs)
     return lat.apply(src)
 

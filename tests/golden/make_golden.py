@@ -261,6 +261,46 @@ def main():
     np.savez_compressed(os.path.join(HERE, "host_side.npz"), **host)
     print("host_side.npz:", len(host), "arrays")
 
+    dataset_fixture()
+
+
+def dataset_fixture():
+    # -------------------------------------------------------------- dataset conventions (experiments/utils.py)
+    # The reference's own prepare_dataset / UCIDataset / EarlyStopper, imported with `wandb` stubbed (it is only
+    # imported, never called on this path), run on a synthetic .mat: the three standardised splits and an
+    # early-stopping trace become the fixture that simplex_gp_amd.data / training.EarlyStopper are compared with.
+    import tempfile
+    from scipy.io import savemat
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    sys.path.insert(0, "/root/reference/experiments")
+    import utils as ref_utils
+    rng = np.random.default_rng(20211)
+    raw = rng.standard_normal((1237, 7)) * np.array([1, 5, 0.1, 3, 2, 1e-3, 10]) + np.array([0, 1, -2, 3, 0, 7, 5])
+    raw[:, 2] = np.round(raw[:, 2], 1)                     # a nearly constant, quantised feature (std ~ 0.1)
+    ds = {"raw": raw}
+    with tempfile.TemporaryDirectory() as tmp:
+        savemat(os.path.join(tmp, "toyset.mat"), {"data": raw})
+        for mode, x, y in ref_utils.prepare_dataset("toyset", uci_data_dir=tmp, device="cpu"):
+            ds[f"{mode}/x"], ds[f"{mode}/y"] = x.numpy(), y.numpy()
+        for mode, x, y in ref_utils.prepare_dataset("toyset", uci_data_dir=tmp, device="cpu", train_val_split=0.6):
+            ds[f"split0.6/{mode}/x"], ds[f"split0.6/{mode}/y"] = x.numpy(), y.numpy()
+    scores = np.array([-1.0, -0.8, -0.80005, -0.7, -0.75, -0.71, -0.6999, -0.9, -0.5, -0.6, -0.55, -0.51, -0.52], np.float64)
+    st = ref_utils.EarlyStopper(patience=3, delta=1e-4)
+    best, done = [], []
+    for i, sc in enumerate(scores):
+        if st.is_done():
+            break
+        st(float(sc), i)
+        best.append(st.info())
+        done.append(st.is_done())
+    ds["stopper/scores"], ds["stopper/best"], ds["stopper/done"] = scores, np.array(best), np.array(done)
+    np.savez_compressed(os.path.join(HERE, "dataset_split.npz"), **ds)
+    print("dataset_split.npz:", sorted(ds))
+
 
 if __name__ == "__main__":
-    main()
+    # `python tests/golden/make_golden.py dataset` regenerates dataset_split.npz only
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        dataset_fixture()
+    else:
+        main()

@@ -465,3 +465,54 @@ def test_fused_entry_points_reject_bad_use(plx):
     gr, gs = lat.apply_backward(v, v, x, want_grad_src=False)
     assert gs is None and gr.shape == (n, d) and torch.isfinite(gr).all()
     lat.close()
+
+
+@pytest.mark.parametrize("cname", sorted(CASES))
+def test_torch_extension_as_reference_method(plx, golden_dir, cname):
+    """The swap a reference maintainer makes: LatticeFilterGeneral.method = <compiled extension>.filter
+    (bilateral_kernel.py:60, py:94-95), then the reference-generated autograd goldens through it."""
+    ext = plx.torch_ext.load()
+    host = np.load(os.path.join(golden_dir, "host_side.npz"))
+    profiles = {"rbf": plx.rbf, "matern15": lambda d2: plx.Matern.apply(d2, 1.5)}
+    pname, order = CASES[cname]
+    dk = plx.DiscretizedKernelFN(profiles[pname], order)
+    x = torch.from_numpy(host[f"autograd/{cname}/x"]).cuda().requires_grad_(True)
+    s = torch.from_numpy(host[f"autograd/{cname}/src"]).cuda().requires_grad_(True)
+    gout = torch.from_numpy(host[f"autograd/{cname}/grad_out"]).cuda()
+    plx.LatticeFilterGeneral.method = staticmethod(ext.filter)
+    try:
+        out = plx.LatticeFilterGeneral.apply(s, x, dk)
+        out.backward(gout)
+    finally:
+        plx.LatticeFilterGeneral.method = None
+    for got, name in [(out, "out"), (s.grad, "grad_src"), (x.grad, "grad_x")]:
+        assert rel_l2(got.detach().cpu().numpy(), host[f"autograd/{cname}/{name}"]) <= 2e-5, name
+
+
+def test_torch_extension_matches_ctypes_path(plx):
+    """filter() and the staged LatticeHandle of the extension against the ctypes path: same library, same bits; work is
+    enqueued on torch's current stream; non-contiguous sources and bad inputs behave like the reference's checks."""
+    ext = plx.torch_ext.load()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(30000, 4, generator=g).cuda()
+    v = torch.randn(30000, 3, generator=g).cuda()
+    taps = torch.tensor([0.34608543, 1.0, 0.34608543])
+    want = plx.filter(v, x, taps)
+    assert torch.equal(ext.filter(v, x, taps), want)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        got = ext.filter(v, x, taps)
+    side.synchronize()
+    assert torch.equal(got, want)
+    vt = v.t().contiguous().t()                               # non-contiguous source: accepted (py:95 passes it as is)
+    assert not vt.is_contiguous() and torch.equal(ext.filter(vt, x, taps), want)
+    h = ext.LatticeHandle(0)
+    h.build(x, taps)
+    assert h.num_vertices == plx.Lattice().build(x, taps.numpy()).m
+    assert torch.equal(h.apply(v), want) and torch.equal(h.apply(v[:, :1].contiguous()), plx.filter(v[:, :1].contiguous(), x, taps))
+    with pytest.raises(RuntimeError, match="Incompatible shapes"):
+        ext.filter(v[:5], x, taps)
+    with pytest.raises(RuntimeError, match="float32"):
+        ext.filter(v.double(), x, taps)
+    with pytest.raises(RuntimeError, match="odd number of taps"):
+        ext.filter(v, x, torch.tensor([0.5, 0.5]))

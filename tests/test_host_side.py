@@ -187,3 +187,14 @@ def test_gp_compat_fallback_is_explicit():
     assert gp_compat.HAVE_GPYTORCH in (True, False)
     if not gp_compat.HAVE_GPYTORCH:
         assert plx.LatticeAccelerated.__mro__[1] is gp_compat._Kernel
+
+
+def test_torch_extension_boundary_on_cpu():
+    """The compiled PyTorch-ROCm extension (csrc/plx_torch.cpp) loads, exports the reference's one symbol and keeps the
+    reference's input checks (cuda/permutohedral_cuda.cpp:3-5) as Python exceptions; compute needs a GPU (-m gpu)."""
+    ext = plx.torch_ext.load()
+    assert ext.version() == _native.lib().plx_version().decode()
+    assert "filter(src" in ext.filter.__doc__ and hasattr(ext, "LatticeHandle")
+    taps = torch.tensor([0.5, 1.0, 0.5])
+    with pytest.raises(RuntimeError, match="must be a CUDA"):
+        ext.filter(torch.randn(4, 1), torch.randn(4, 2), taps)
