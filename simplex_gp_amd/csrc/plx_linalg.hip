@@ -34,16 +34,26 @@ __global__ __launch_bounds__(kBlock) void coldot_partial_kernel(const float *__r
     }
 }
 
-__global__ __launch_bounds__(kBlock) void coldot_final_kernel(const float *__restrict__ partial, int nblocks, int vd,
-                                                              float *__restrict__ out)
+// One workgroup per column; 1024 threads with four independent loads in flight each (the partials of the fused
+// slice + dot are one row per 256-thread tile: 11,719 rows at N = 1e6, vd = 12 -- 256 threads with one load in flight
+// took 11 us, twice per CG iteration).  Fixed summation order: thread-strided partial sums, then a tree.
+constexpr int kFinalBlock = 1024;
+__global__ __launch_bounds__(kFinalBlock) void coldot_final_kernel(const float *__restrict__ partial, int nblocks, int vd,
+                                                                   float *__restrict__ out)
 {
-    __shared__ float red[kBlock];
+    __shared__ float red[kFinalBlock];
     const int c = blockIdx.x;
-    float acc = 0.f;
-    for (int k = threadIdx.x; k < nblocks; k += kBlock) acc += partial[(size_t)k * vd + c];
-    red[threadIdx.x] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int k = threadIdx.x;
+    for (; k + 3 * kFinalBlock < nblocks; k += 4 * kFinalBlock) {
+        const float p0 = partial[(size_t)k * vd + c], p1 = partial[(size_t)(k + kFinalBlock) * vd + c];
+        const float p2 = partial[(size_t)(k + 2 * kFinalBlock) * vd + c], p3 = partial[(size_t)(k + 3 * kFinalBlock) * vd + c];
+        a0 += p0; a1 += p1; a2 += p2; a3 += p3;
+    }
+    for (; k < nblocks; k += kFinalBlock) a0 += partial[(size_t)k * vd + c];
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
+    for (int s = kFinalBlock / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void backward_contract_kernel(const float *
 namespace plx {
 int coldot_final(const float *d_partial, int nblocks, int vd, float *d_out, hipStream_t stream)
 {
-    coldot_final_kernel<<<vd, kBlock, 0, stream>>>(d_partial, nblocks, vd, d_out);
+    coldot_final_kernel<<<vd, kFinalBlock, 0, stream>>>(d_partial, nblocks, vd, d_out);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }
@@ -257,7 +267,7 @@ extern "C" int plx_cg_update(float *d_x, float *d_r, const float *d_p, const flo
     while ((1 << logcw) < vd) ++logcw;
     hipStream_t s = (hipStream_t)stream;
     cg_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_alpha, n, vd, logcw, d_work);
-    coldot_final_kernel<<<vd, kBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
+    coldot_final_kernel<<<vd, kFinalBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }
@@ -275,7 +285,7 @@ extern "C" int plx_cg_step_update(float *d_x, float *d_r, const float *d_p, cons
     while ((1 << logcw) < vd) ++logcw;
     hipStream_t s = (hipStream_t)stream;
     cg_step_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_rs, d_pap, d_active, n, vd, logcw, d_work, d_alpha);
-    coldot_final_kernel<<<vd, kBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
+    coldot_final_kernel<<<vd, kFinalBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }
@@ -318,7 +328,7 @@ extern "C" int plx_coldot(const float *d_a, const float *d_b, int64_t n, int vd,
     while ((1 << logcw) < vd) ++logcw;
     hipStream_t s = (hipStream_t)stream;
     coldot_partial_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_a, d_b, n, vd, logcw, d_work);
-    coldot_final_kernel<<<vd, kBlock, 0, s>>>(d_work, kDotBlocks, vd, d_out);
+    coldot_final_kernel<<<vd, kFinalBlock, 0, s>>>(d_work, kDotBlocks, vd, d_out);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }

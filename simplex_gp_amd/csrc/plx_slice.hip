@@ -43,7 +43,11 @@ __global__ __launch_bounds__(kBlock) void slice_v1_kernel(const int *__restrict_
     out[row] = acc;
 }
 
-// vd > 1: one thread per (point, 16-byte chunk)
+// vd > 1: one thread per (point, 16-byte chunk).  D1 > 0: d + 1 compiled in -- all (vertex, weight) pairs are loaded
+// first, then all row gathers are issued, then the ordered sum (with a runtime trip count every corner waited for its
+// own pair and then for its own gather: vd = 12 slice 100 us at N = 1e6); D1 = 0: runtime d + 1 (d + 1 > kSliceMaxD1).
+constexpr int kSliceMaxD1 = 20;
+template <int D1>
 __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict__ evid,
                                                            const float *__restrict__ ew,
                                                            const uint32_t *__restrict__ perm, int n, int own_begin,
@@ -62,11 +66,29 @@ __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict
         const int pl = (int)(item / nch), ch = (int)(item - (int64_t)pl * nch);
         const int p = own_begin + pl;
         float4 acc = f4_zero();
-        for (int r = 0; r < d1; ++r) {
-            const int v = evid[(size_t)r * n + p];
-            const float w = ew[(size_t)r * n + p];
-            const float4 g = values[(size_t)v * nch + ch];
-            acc.x += w * g.x * rden; acc.y += w * g.y * rden; acc.z += w * g.z * rden; acc.w += w * g.w * rden;
+        if constexpr (D1 > 0) {
+            int v[D1];
+            float w[D1];
+            float4 g[D1];
+#pragma unroll
+            for (int r = 0; r < D1; ++r) {
+                v[r] = evid[(size_t)r * n + p];
+                w[r] = ew[(size_t)r * n + p];
+            }
+#pragma unroll
+            for (int r = 0; r < D1; ++r) g[r] = values[(size_t)v[r] * nch + ch];
+#pragma unroll
+            for (int r = 0; r < D1; ++r) {
+                acc.x += w[r] * g[r].x * rden; acc.y += w[r] * g[r].y * rden;
+                acc.z += w[r] * g[r].z * rden; acc.w += w[r] * g[r].w * rden;
+            }
+        } else {
+            for (int r = 0; r < d1; ++r) {
+                const int v = evid[(size_t)r * n + p];
+                const float w = ew[(size_t)r * n + p];
+                const float4 g = values[(size_t)v * nch + ch];
+                acc.x += w * g.x * rden; acc.y += w * g.y * rden; acc.z += w * g.z * rden; acc.w += w * g.w * rden;
+            }
         }
         const size_t row = perm ? (size_t)((int)perm[p] - own_begin) : (size_t)pl;
         float *o = out + row * vd + 4 * ch;
@@ -137,9 +159,18 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
         L->kn_slice = "slice_vec_kernel";
         const int nch = values_stride(vd) / 4;
         const int nt = ceil_div((int64_t)n_own * nch, kBlock);
-        slice_vec_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
-            evid, ew, perm, n, ob, n_own, L->d + 1, reinterpret_cast<const float4 *>(d_values), nch, vd,
-            1.0f / L->slice_denom, d_out, nt, g_xcd_remap, d_affine, d_src, d_dot_partial);
+        const float4 *v4 = reinterpret_cast<const float4 *>(d_values);
+        const float rden = 1.0f / L->slice_denom;
+        const int grid = tile_grid(nt, g_xcd_remap);
+        switch (L->d + 1 <= kSliceMaxD1 ? L->d + 1 : 0) {
+#define PLX_CASE(D1) \
+    case D1: slice_vec_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, L->d + 1, v4, nch, vd, rden, d_out, nt, g_xcd_remap, d_affine, d_src, d_dot_partial); break;
+            PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9) PLX_CASE(10)
+            PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17) PLX_CASE(18)
+            PLX_CASE(19) PLX_CASE(20)
+#undef PLX_CASE
+        default: slice_vec_kernel<0><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, L->d + 1, v4, nch, vd, rden, d_out, nt, g_xcd_remap, d_affine, d_src, d_dot_partial); break;
+        }
     }
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());
