@@ -10,7 +10,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 2 --skip-cpu-baseline"
+ARGS="--steps 20 --warmup 2 --skip-cpu-baseline --skip-configs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.json 2> $OUT/trace.err
 for ELL in 1.0 0.25; do
   for C in FETCH_SIZE WRITE_SIZE; do
