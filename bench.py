@@ -497,6 +497,22 @@ def main():
         result["lattice_device_MB"] = round(lat.device_bytes / 1e6, 1)
         log("stage times (ms):", kt)
         log("build (ms):", build_ms)
+        # the same MVM with rows in lattice order, as a CG solve runs it (solvers.khat_solve permutes the right-hand side
+        # once per solve, every iteration's MVM skips the two row permutations): reported, never `value`
+        lat.set_lattice_row_order(True)
+        v_l = lat.to_lattice_order(v)
+        for _ in range(3):
+            lat.apply(v_l, out)
+        wall_l = time_region(lambda i: lat.apply(v_l, out), args.steps, ctx.sync, ctx.barrier)
+        kt_l = kernel_times(lat, v_l, out, reps=max(10, args.steps))
+        _, stages_l = roofline_for(lat, kt_l, n_local, d, m, vd, r, args.ell)
+        lat.set_lattice_row_order(False)
+        result["lattice_row_order"] = {"warm_mvms_per_s": round(args.steps / wall_l, 1),
+                                       "stages": {k: {kk: vv for kk, vv in st.items() if kk != "traffic_MB_per_launch"}
+                                                  for k, st in stages_l.items()},
+                                       "note": "rows of src / out in lattice order (plx_set_row_order): the mode of every "
+                                               "CG iteration in solvers.khat_solve; the caller-order figures above "
+                                               "include the two row permutations"}
         x_cpu, v_cpu = job.x_cpu, job.v_cpu
         job.close()
 

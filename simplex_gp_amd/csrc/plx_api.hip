@@ -42,7 +42,7 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->row_ptr,
             &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
             &L->sortkey_in, &L->sortkey_out,
-            &L->bc_pt, &L->bc_w, &L->srow, &L->brow_ptr, &L->brow_vid, &L->s2_idx, &L->s2_ptr, &L->s2_vid, &L->s2_wave, &L->partial, &L->pair_nbr};
+            &L->bc_pt, &L->bc_w, &L->srow, &L->brow_ptr, &L->brow_vid, &L->s2_idx, &L->s2_ptr, &L->s2_vid, &L->s2_wave, &L->partial, &L->pair_nbr, &L->inv_perm};
 }
 
 struct DeviceGuard {

@@ -33,6 +33,7 @@ int g_block_ablate = 0;      // diagnostics only: 1 combine without the partial 
                              // 4 combine without stores, 8 splat_block without the LDS source reads
 int g_scatter_store = 0;     // slice's row-scattered output stores: 0 plain, 1 non-temporal, 2 agent-scope (write-through)
 int g_block_lds_sort = 1;    // 1: the corners of a block are sorted by one workgroup in LDS (256-thread blocks); 0: one global radix sort
+int g_unpermute_gather = 1;  // caller row order out of the block slice: 1 = lattice-ordered scratch + a gather pass, 0 = scatter from the slice kernel
 int g_block_threads = 256;   // threads per block workgroup (256, 512 or 1024); a block holds threads * kBlkE corners
 
 constexpr int kBlkE = 16;        // corners per thread of splat_block_kernel
@@ -456,6 +457,49 @@ __global__ __launch_bounds__(1024) void slice_block_kernel(const uint16_t *__res
     }
 }
 
+// Caller row order on the way out, as a GATHER: out[j] = tmp[inv_perm[j]] (+ the affine epilogue), 4 rows per thread.
+// Scattering the results from the slice kernel costs one partial-line write per point that the XCD L2s cannot merge
+// (36 MB of write traffic for a 4 MB output, +10 us at N = 1e6); reading 4 bytes from a random place is cheaper than
+// writing 4 bytes to one, and the stores here are whole 16-byte vectors.
+__global__ __launch_bounds__(kBlock) void unpermute_kernel(const float *__restrict__ tmp, const uint32_t *__restrict__ inv,
+                                                           int n_own, float *__restrict__ out,
+                                                           const float *__restrict__ affine, const float *__restrict__ src)
+{
+    const int j0 = (blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (j0 >= n_own) return;
+    const bool full = j0 + 4 <= n_own;
+    uint32_t q[4] = {0, 0, 0, 0};
+    if (full) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(inv + j0);
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+    } else {
+        for (int k = 0; k < 4; ++k) q[k] = j0 + k < n_own ? inv[j0 + k] : 0u;
+    }
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = tmp[q[k]];
+    if (affine) {
+        const float a = affine[0], b = affine[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (j0 + k < n_own) r[k] = a * r[k] + b * src[j0 + k];
+    }
+    if (full && (reinterpret_cast<uintptr_t>(out + j0) & 15) == 0) {
+        *reinterpret_cast<float4 *>(out + j0) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+        for (int k = 0; k < 4; ++k)
+            if (j0 + k < n_own) out[j0 + k] = r[k];
+    }
+}
+
+// inv_perm[caller row within the shard] = position of that row in lattice order (within the shard)
+__global__ __launch_bounds__(kBlock) void inv_perm_kernel(const uint32_t *__restrict__ perm, int own_begin, int n_own,
+                                                          uint32_t *__restrict__ inv)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n_own) inv[perm[own_begin + i] - (uint32_t)own_begin] = (uint32_t)i;
+}
+
 int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStream_t stream, const float *d_affine,
                      const float *d_src)
 {
@@ -463,6 +507,16 @@ int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStr
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
     const size_t lds = (size_t)L->blk_max_rows * 4;
     const float rden = 1.0f / L->slice_denom;
+    // caller row order: slice into a lattice-ordered scratch (coalesced), then gather the rows out
+    const bool two_step = perm != nullptr && g_unpermute_gather != 0;
+    float *final_out = d_out;
+    const float *final_affine = d_affine;
+    if (two_step) {
+        PLX_TRY(ensure(L->ssrc, (size_t)n_own * 4 + 16));
+        d_out = L->ssrc.as<float>();
+        perm = nullptr;
+        d_affine = nullptr;
+    }
     switch (L->d + 1) {
 #define PLX_CASE(D1)                                                                                                    \
     case D1:                                                                                                            \
@@ -478,6 +532,11 @@ int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStr
 #undef PLX_CASE
     }
     L->kn_slice = "slice_block_kernel";
+    if (two_step) {
+        unpermute_kernel<<<ceil_div(ceil_div(n_own, 4), kBlock), kBlock, 0, stream>>>(d_out, L->inv_perm.as<uint32_t>(), n_own,
+                                                                                    final_out, final_affine, d_src);
+        L->kn_slice = "slice_block_kernel+unpermute_kernel";
+    }
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -571,6 +630,9 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
                                                                       L->s2_ptr.as<int>());
     blk_s2_finish_kernel<<<ceil_div(std::max<int64_t>(nrows, L->n_s2waves + 1), kBlock), kBlock, 0, stream>>>(
         L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->s2_ptr.as<int>(), (int)nrows, (int)L->n_s2waves, L->s2_wave.as<int>());
+    PLX_TRY(ensure(L->inv_perm, (size_t)n_own * 4 + 16));
+    inv_perm_kernel<<<ceil_div(n_own, kBlock), kBlock, 0, stream>>>(L->perm.as<uint32_t>(), (int)L->own_begin, n_own,
+                                                                    L->inv_perm.as<uint32_t>());
     PLX_HIP_TRY(hipGetLastError());
     L->use_blocks = true;
     return PLX_OK;

@@ -125,6 +125,7 @@ struct plx_lattice {
     plx::DevBuf s2_wave;    // int32  [n_s2waves+1]  first block row of every combine wave
     int64_t n_s2waves = 0;
     plx::DevBuf partial;    // float  [n_brows]      per-MVM block-row sums
+    plx::DevBuf inv_perm;   // uint32 [n_own]        lattice-order position of every caller row of the shard
 
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
