@@ -564,12 +564,13 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     int vbits = 1, bbits = 0;
     while ((1ll << vbits) < m) ++vbits;
     while ((1ll << bbits) < nblocks) ++bbits;
-    if (vbits + bbits > 32) return PLX_OK;       // (block, vertex) does not fit a 32-bit sort key: CSR path
+    const bool lds_build = (T == 256 && vbits <= 30 && g_block_lds_sort != 0);
+    if (!lds_build && vbits + bbits > 32) return PLX_OK;   // (block, vertex) does not fit the global sort's 32-bit key: CSR path
     L->blk_P = P; L->blk_T = T; L->blk_cpb = cpb; L->nblocks = nblocks;
     L->srow_stride = ((int64_t)n_own + 7) & ~7ll;
 
     size_t temp_bytes = 0;
-    PLX_TRY(sort_pairs_temp_bytes(nnz, vbits + bbits, &temp_bytes));
+    if (!lds_build) PLX_TRY(sort_pairs_temp_bytes(nnz, vbits + bbits, &temp_bytes));
     PLX_TRY(ensure(L->sort_keys_in, (size_t)nnz * 4));
     PLX_TRY(ensure(L->sort_keys_out, (size_t)nnz * 4 + 16));
     PLX_TRY(ensure(L->sort_vals_in, (size_t)nnz * 4));
@@ -580,7 +581,6 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     PLX_TRY(ensure(L->srow, (size_t)d1 * L->srow_stride * 2 + 64));
     PLX_TRY(ensure(L->brow_ptr, (size_t)(nblocks + 1) * 4));
 
-    const bool lds_build = (T == 256 && vbits <= 30 && g_block_lds_sort != 0);
     if (lds_build) {
         // one workgroup per block: sort in LDS, per-corner records, row counts; the vertex lists go to sort_keys_in
         PLX_TRY(sort_fill_blocks_lds(L->evid.as<int>(), L->ew.as<float>(), n, (int)L->own_begin, n_own, P, d1, cpb, vbits, nblocks,
