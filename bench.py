@@ -106,12 +106,27 @@ def alg_bytes(n, d, m, vd, r):
     }
 
 
-def synth(n, d, vd, seed=1234):
+SYNTH_BLOCK = 1_000_000
+
+
+def synth(n, d, vd, seed=1234, lo=0, hi=None):
+    """Rows [lo, hi) of the synthetic data set of n rows: x ~ N(0, I_d), v ~ N(0, 1), generated in blocks of 1e6 rows,
+    block b from torch.Generator().manual_seed(seed + b) (x drawn first, then v: block 0 is SURVEY 8d's recipe).  Every
+    rank of a sharded job generates only the blocks its rows live in, whatever the total size."""
     import torch
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(n, d, generator=g)
-    v = torch.randn(n, vd, generator=g)
-    return x, v
+    hi = n if hi is None else hi
+    xs, vs = [], []
+    for b in range(lo // SYNTH_BLOCK, max(lo // SYNTH_BLOCK + 1, -(-hi // SYNTH_BLOCK))):
+        b0, b1 = b * SYNTH_BLOCK, min((b + 1) * SYNTH_BLOCK, n)
+        if b1 <= b0:
+            break
+        g = torch.Generator().manual_seed(seed + b)
+        x = torch.randn(b1 - b0, d, generator=g)
+        v = torch.randn(b1 - b0, vd, generator=g)
+        a, z = max(lo, b0) - b0, min(hi, b1) - b0
+        xs.append(x[a:z])
+        vs.append(v[a:z])
+    return torch.cat(xs, 0), torch.cat(vs, 0)
 
 
 def time_region(fn, steps, sync, barrier):
@@ -232,13 +247,13 @@ class Job:
         import torch
         from simplex_gp_amd.distributed import ShardedLatticeMVM, shard_bounds
         self.ctx, self.n_total, self.d, self.vd, self.ell, self.taps = ctx, n_total, d, vd, ell, taps
-        x, v_all = synth(n_total, d, vd)
         self.lo, self.hi = shard_bounds(n_total, ctx.world, ctx.rank)
-        # a rank keeps only its own rows on the device (the sharded build never needs the others)
-        self.ref = (x[self.lo:self.hi] / ell).contiguous().to(ctx.dev)
-        self.v = v_all[self.lo:self.hi].contiguous().to(ctx.dev)
+        # a rank generates and keeps only its own rows (the sharded build never needs the others)
+        x, v = synth(n_total, d, vd, lo=self.lo, hi=self.hi)
+        self.ref = (x / ell).contiguous().to(ctx.dev)
+        self.v = v.contiguous().to(ctx.dev)
         self.out = torch.empty_like(self.v)
-        self.x_cpu, self.v_cpu = x, v_all
+        self.x_cpu, self.v_cpu = x, v
         self.op = ShardedLatticeMVM.from_local_rows(self.ref, taps, n_total=n_total)
         self.lat = self.op.lattice
 
@@ -477,6 +492,11 @@ def main():
                 result["strong"] = sharded_leg(ctx, args.n, d, args.ell, [1], short)
             if args.scaling != "config4":
                 result["config4"] = sharded_leg(ctx, 4_000_000, d, 1.0, [1, 11], short)
+            # weak scaling with 4e6 points per GPU: where the sharded splat / slice outweigh the replicated blur and the
+            # all-reduce; value of this leg = (n_total / 4e6) x MVMs/s
+            big = sharded_leg(ctx, 4_000_000 * world, d, 1.0, [1], short)
+            big["blocks_4e6_per_s"] = round(big["mvms_per_s_vd1"] * world, 1)
+            result["weak_4e6_per_gpu"] = big
     else:
         # ---- warm / cold rates and per-stage times on the same lattice
         ref, v, out = job.ref, job.v, job.out
@@ -552,6 +572,7 @@ def main():
         if not args.no_configs and args.scaling == "weak" and args.n == 1_000_000 and d == 8:
             result.update(config3_leg(ctx))
             result["config4"] = sharded_leg(ctx, 4_000_000, d, 1.0, [1, 11], 20)
+            result["weak_4e6_per_gpu"] = dict(result["config4"], blocks_4e6_per_s=result["config4"]["mvms_per_s_vd1"])
             result.update(config5_leg(ctx))
 
         if not args.no_cpu_baseline:
