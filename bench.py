@@ -166,20 +166,37 @@ def roofline_for(lat, kt, n, d, m, vd, r, ell=1.0):
     launch_ms = {"splat": kt["splat"], "blur_axis": kt["blur"], "slice": kt["slice"]}[dom]
     achieved = ab[dom] / (launch_ms * 1e-3) / 1e9
     names = lat.stage_kernels(vd)
-    pmc = pmc_traffic(names[dom], ell)
+
+    def stage_traffic(stage):
+        """HBM bytes per launch-equivalent of a stage from the committed PMC table.  splat / slice: the sum over the
+        stage's kernels (one launch each per MVM).  blur: per AXIS -- a two-axes-per-launch kernel counts for two."""
+        ks = names[stage]
+        if stage == "blur_axis" and "blur_pair_v1_kernel" in ks:
+            pair, single = pmc_traffic(["blur_pair_v1_kernel"], ell), pmc_traffic(["blur_axis_v1_kernel"], ell)
+            npair, nsingle = (d + 1) // 2, (d + 1) % 2
+            if pair is None or (nsingle and single is None):
+                return None
+            total = npair * pair["bytes"] + (nsingle * single["bytes"] if nsingle else 0)
+            return {"bytes": int(total / (d + 1)), "source": pair["source"]}
+        return pmc_traffic(ks, ell)
+
+    pmc = stage_traffic(dom)
+    cache_resident = m * (d + 1) * 8 * r < 128e6
     roof = {
         "bound": "hbm", "stage": dom, "kernel": " + ".join(names[dom]), "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
         "traffic": pmc["bytes"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,
         "bytes_per_launch": int(ab[dom]), "launch_us": round(launch_ms * 1e3, 2),
         "launches_per_mvm": (d + 1) if dom == "blur_axis" else 1,
-        "note": ("cache-resident lattice: bound by the L2 request rate of 4-byte gathers, not HBM (DESIGN.md 4); "
-                 "the HBM-bound regime is reported under 'fine'") if m * (d + 1) * 8 * r < 128e6 else "",
+        "note": ("cache-resident lattice (values + neighbour ids of an axis fit the L2s): a blur launch is a dependent-"
+                 "launch boundary plus two memory latencies from 8 cold XCD L2s, not an HBM stream (DESIGN.md 4); bytes and "
+                 "time are per axis (two-axes-per-launch kernels count twice); the HBM-bound regime is reported under 'fine'")
+                if cache_resident else "",
     }
     stages = {}
     for k in per_mvm_ms:
         mult = (d + 1) if k == "blur_axis" else 1
-        p = pmc_traffic(names[k], ell)
+        p = stage_traffic(k)
         stages[k] = {"us_per_mvm": round(per_mvm_ms[k] * 1e3, 2), "alg_MB_per_mvm": round(ab[k] * mult / 1e6, 2),
                      "GBps": round(ab[k] * mult / (per_mvm_ms[k] * 1e-3) / 1e9, 1),
                      "frac": round(ab[k] * mult / (per_mvm_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
