@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomised comparison of the block-table path (vd = 1: block splat + combine, pair blur, block slice + gather-out)
+against the CPU oracle and against the CSR kernels: shapes up to n = 40000, d = 1..32, every tap order, degenerate
+clouds (duplicates, grids, lines, one simplex), caller and lattice row order, owned row ranges.  Exits 1 above 5e-5."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import simplex_gp_amd as plx
+from simplex_gp_amd import _native as nv
+from oracle import oracle
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+lib = nv.lib()
+worst = (0.0, None)
+oracle.set_exact_mode(False)
+for c in range(cases):
+    n = int(rng.choice([1, 2, 15, 16, 17, 447, 448, 449, 1000, 4097, 12345, 40000]))
+    d = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 18, 25, 32]))
+    if n * (d + 1) > 400000:
+        n = 400000 // (d + 1)
+    order = int(rng.integers(0, 4))
+    scale = float(rng.choice([0.02, 0.3, 1.0, 4.0, 30.0]))
+    kind = str(rng.choice(["normal", "grid", "dup", "line", "same"]))
+    if kind == "normal":
+        ref = rng.standard_normal((n, d))
+    elif kind == "grid":
+        ref = rng.integers(-3, 4, (n, d)).astype(np.float64) * 0.5
+    elif kind == "dup":
+        k = max(1, n // 20)
+        ref = rng.standard_normal((k, d))[rng.integers(0, k, n)]
+    elif kind == "line":
+        ref = np.outer(rng.standard_normal(n), rng.standard_normal(d))
+    else:
+        ref = np.tile(rng.standard_normal((1, d)), (n, 1))
+    ref = (ref * scale).astype(np.float32)
+    src = rng.standard_normal((n, 1)).astype(np.float32)
+    taps = np.array([0.1, 0.3, 0.6, 1.0, 0.6, 0.3, 0.1][3 - order: 4 + order], np.float32)
+    want = oracle.filter(src, ref, taps)
+    x, s = torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda()
+    nv.check(lib.plx_tune(b"block_path", 2), "plx_tune")
+    nv.check(lib.plx_tune(b"blur_fuse", 2 if c % 2 else 1), "plx_tune")
+    nv.check(lib.plx_tune(b"unpermute_gather", c % 3 != 0), "plx_tune")
+    lat = plx.Lattice().build(x, taps)
+    used = lat.block_rows > 0
+    out = lat.apply(s)
+    errs = [float(np.linalg.norm(out.cpu().numpy().astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20))]
+    lat.set_lattice_row_order(True)
+    out_l = lat.from_lattice_order(lat.apply(lat.to_lattice_order(s)))
+    lat.set_lattice_row_order(False)
+    errs.append(float((out_l - out).abs().max()))                      # same bits in either row order
+    if n >= 16:
+        shards = int(rng.integers(2, 5))
+        from simplex_gp_amd.distributed import shard_bounds
+        total, parts = None, []
+        for r in range(shards):
+            lo, hi = shard_bounds(n, shards, r)
+            sl = plx.Lattice().build(x, taps, shard=(r, shards))
+            part = sl.splat(s[lo:hi])
+            total = part.clone() if total is None else total + part
+            parts.append((sl, lo, hi))
+        got = torch.empty_like(out)
+        for sl, lo, hi in parts:
+            got[lo:hi] = sl.slice(sl.blur(total.clone(), vd=1), vd=1)
+            sl.close()
+        errs.append(float(np.linalg.norm(got.cpu().numpy().astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20)))
+    lat.close()
+    err = max(errs)
+    if err > worst[0]:
+        worst = (err, (c, n, d, order, scale, kind, used, errs))
+    if err > 5e-5 or not np.isfinite(err):
+        print("FAIL", c, n, d, order, scale, kind, used, errs)
+        sys.exit(1)
+    if c % 25 == 0:
+        print(f"case {c}: n={n} d={d} order={order} scale={scale} {kind} blocks={used} worst so far {worst[0]:.2e}", flush=True)
+nv.check(lib.plx_tune(b"block_path", 1), "plx_tune")
+print("OK", cases, "cases; worst", worst)
