@@ -173,55 +173,60 @@ class LatticeFilterGeneral(Function):
         return grad_source, grad_reference, None
 
 
+def _lattice_matvec(rhs, positions, dkernel):
+    """K(positions) @ rhs through the autograd op; the one place the operator classes reach the native filter."""
+    return LatticeFilterGeneral.apply(rhs, positions, dkernel)
+
+
 class SquareLazyLattice(LazyTensor):
-    """K(x, x) known through matmul only (py:127-140)."""
+    """K(x, x), known through its action only (py:127-140): symmetric by declaration (its transpose is itself,
+    py:137-138) and with a unit diagonal by declaration (py:139-140), whatever the lattice actually computes."""
 
     def __init__(self, x, dkernel=None):
         super().__init__(x, dkernel=dkernel)
-        self.x = x
-        self.dkernel = dkernel
-
-    def _matmul(self, V):
-        return LatticeFilterGeneral.apply(V, self.x, self.dkernel)
+        self.x, self.dkernel = x, dkernel
 
     def _size(self):
-        return torch.Size((self.x.shape[-2], self.x.shape[-2]))
+        n = self.x.shape[-2]
+        return torch.Size((n, n))
+
+    def _matmul(self, V):
+        return _lattice_matvec(V, self.x, self.dkernel)
 
     def _transpose_nonbatch(self):
         return self
 
     def diag(self):
-        return torch.ones_like(self.x[..., 0])
+        return self.x.new_ones(self.x.shape[:-1])
 
 
 class RectangularLazyLattice(LazyTensor):
-    """K(xin, xout): one square filter over the union of the two point sets
-    with the right-hand side zero-padded (py:142-160)."""
+    """K(xin, xout) for two different point sets (prediction), py:142-160: the right-hand side lives on `xout`; it is
+    extended by zeros over `xin`, ONE square filter runs over the stacked points [xout; xin], and the rows that belong to
+    `xin` are returned."""
 
     def __init__(self, xin, xout, dkernel=None):
         super().__init__(xin, xout, dkernel=dkernel)
-        self.xin = xin
-        self.xout = xout
-        self.dkernel = dkernel
-
-    def _matmul(self, V):
-        n = V.shape[-2]
-        assert n == self.xout.shape[-2], f"mismatched shapes? {V.shape, self.xout.shape}"
-        x_large = torch.cat([self.xout, self.xin], dim=-2)
-        V_large = torch.zeros(*V.shape[:-2], x_large.shape[-2], V.shape[-1], device=V.device, dtype=V.dtype)
-        V_large[..., :n, :] += V
-        return LatticeFilterGeneral.apply(V_large, x_large, self.dkernel)[..., n:, :]
+        self.xin, self.xout, self.dkernel = xin, xout, dkernel
 
     def _size(self):
         return torch.Size((*self.xin.shape[:-1], self.xout.shape[-2]))
 
+    def _matmul(self, V):
+        n_out, n_in = self.xout.shape[-2], self.xin.shape[-2]
+        assert V.shape[-2] == n_out, f"mismatched shapes? {V.shape, self.xout.shape}"
+        stacked_points = torch.cat((self.xout, self.xin), dim=-2)
+        stacked_rhs = torch.nn.functional.pad(V, (0, 0, 0, n_in))          # zero rows for the points of xin
+        return _lattice_matvec(stacked_rhs, stacked_points, self.dkernel)[..., n_out:, :]
+
     def _transpose_nonbatch(self):
-        return RectangularLazyLattice(self.xout, self.xin, self.dkernel)
+        return type(self)(self.xout, self.xin, self.dkernel)
 
 
 class LatticeAccelerated(Kernel):
-    """A stationary kernel, given as a differentiable profile in squared
-    distance, evaluated through the permutohedral lattice (py:183-200)."""
+    """A stationary kernel, given as a differentiable profile in the squared distance, evaluated through the
+    permutohedral lattice (py:183-200).  ARD lengthscales divide the inputs before they reach the lattice (py:198-200);
+    the diagonal is reported as ones (py:193-195)."""
 
     has_lengthscale = True
 
@@ -229,22 +234,35 @@ class LatticeAccelerated(Kernel):
         super().__init__(*args, **kwargs)
         self.dkernel_fn = DiscretizedKernelFN(kernel_fn, order)
 
+    @staticmethod
+    def _same_points(a, b):
+        """The reference decides square vs rectangular by comparing the two tensors element by element on every call
+        (py:197, one device synchronisation); identical objects / storage are recognised without that."""
+        if a is b:
+            return True
+        if a.shape != b.shape:
+            return False
+        return a.data_ptr() == b.data_ptr() or bool(torch.equal(a, b))
+
     def forward(self, x1, x2, diag=False, **params):
         if diag:
-            return torch.ones_like(x1[..., 0])
-        same = x1 is x2 or (x1.shape == x2.shape and (x1.data_ptr() == x2.data_ptr() or bool(x1.eq(x2).all())))
-        if same:
-            return SquareLazyLattice(x1.div(self.lengthscale), self.dkernel_fn)
-        return RectangularLazyLattice(x1.div(self.lengthscale), x2.div(self.lengthscale), self.dkernel_fn)
+            return x1.new_ones(x1.shape[:-1])
+        scaled1 = x1.div(self.lengthscale)
+        if self._same_points(x1, x2):
+            return SquareLazyLattice(scaled1, self.dkernel_fn)
+        return RectangularLazyLattice(scaled1, x2.div(self.lengthscale), self.dkernel_fn)
 
 
-def RBFLattice(*args, order=2, **kwargs):
-    return LatticeAccelerated(rbf, *args, order=order, **kwargs)
+def _lattice_kernel_factory(profile, default_order):
+    def make(*args, order=default_order, **kwargs):
+        return LatticeAccelerated(profile, *args, order=order, **kwargs)
+    return make
 
 
-def BilateralKernel(*args, **kwargs):
-    return RBFLattice(*args, **kwargs)
+RBFLattice = _lattice_kernel_factory(rbf, 2)                    # py:247-248
+RBFLattice.__name__ = "RBFLattice"
+BilateralKernel = RBFLattice                                    # py:250-251
 
 
-def MaternLattice(*args, nu=1.5, order=3, **kwargs):
+def MaternLattice(*args, nu=1.5, order=3, **kwargs):            # py:253-254
     return LatticeAccelerated(lambda d2: Matern.apply(d2, nu), *args, order=order, **kwargs)

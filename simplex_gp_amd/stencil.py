@@ -95,26 +95,43 @@ class DiscretizedKernelFN(nn.Module):
 
 
 # ----------------------------------------------------------------- profiles
+#
+# All profiles are functions of the SQUARED distance d2 (py:202-245).  Matern-nu, with t = sqrt(2 nu) * sqrt(d2):
+#     nu = 1/2:  e^-t          nu = 3/2:  (1 + t) e^-t          nu = 5/2:  (1 + t + t^2 / 3) e^-t
+# and d/d(d2) in closed form (finite at d2 = 0, which plain autograd through sqrt is not):
+#     nu = 3/2:  -(3/2) e^-t                 nu = 5/2:  -(5/6) (1 + t) e^-t
 
 def rbf(d2):
     """exp(-d^2) (py:202-203)."""
-    return torch.exp(-d2)
+    return (-d2).exp()
+
+
+def _matern_terms(d2, nu):
+    """(distance, decay e^-t, polynomial factor) of the Matern-nu profile; written like the reference so that the
+    fp32 results agree to the last bit (py:209-217, py:235-244)."""
+    dist = d2.abs().sqrt()
+    decay = torch.exp(-math.sqrt(2 * nu) * dist)
+    if nu == 0.5:
+        poly = 1
+    elif nu == 1.5:
+        poly = (math.sqrt(3) * dist).add(1)
+    elif nu == 2.5:
+        poly = (math.sqrt(5) * dist).add(1).add(5.0 / 3.0 * dist ** 2)
+    else:
+        raise NotImplementedError(f"Matern nu={nu}")
+    return dist, decay, poly
 
 
 class Matern(torch.autograd.Function):
-    """Matern-nu profile in d^2 with a closed-form derivative that stays finite
-    at d = 0 (py:207-232).  nu in {1.5, 2.5}."""
+    """Matern-nu profile in d^2, nu in {1.5, 2.5}, with the closed-form derivative above (py:207-232)."""
+
+    _SLOPE = {1.5: lambda dist: -(3 / 2), 2.5: lambda dist: -(5 / 6) * (1 + dist * math.sqrt(5))}
 
     @staticmethod
     def forward(ctx, d2, nu):
-        dist = d2.abs().sqrt()
-        decay = torch.exp(-math.sqrt(nu * 2) * dist)
-        if nu == 1.5:
-            poly = (math.sqrt(3) * dist).add(1)
-        elif nu == 2.5:
-            poly = (math.sqrt(5) * dist).add(1).add(5.0 / 3.0 * dist ** 2)
-        else:
+        if nu not in Matern._SLOPE:
             raise NotImplementedError(f"Matern nu={nu}")
+        dist, decay, poly = _matern_terms(d2, nu)
         if any(ctx.needs_input_grad):
             ctx.nu = nu
             ctx.save_for_backward(dist, decay)
@@ -125,25 +142,10 @@ class Matern(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             raise NotImplementedError("gradient with respect to nu")
         dist, decay = ctx.saved_tensors
-        if ctx.nu == 1.5:
-            factor = -(3 / 2)
-        elif ctx.nu == 2.5:
-            factor = -(5 / 6) * (1 + dist * math.sqrt(5))
-        else:
-            raise NotImplementedError
-        return grad_output * factor * decay, None
+        return grad_output * Matern._SLOPE[ctx.nu](dist) * decay, None
 
 
 def matern(d2, nu=.5):
     """Plain-autograd Matern profile, nu in {0.5, 1.5, 2.5} (py:234-245)."""
-    dist = d2.abs().sqrt()
-    decay = torch.exp(-math.sqrt(nu * 2) * dist)
-    if nu == 0.5:
-        poly = 1
-    elif nu == 1.5:
-        poly = (math.sqrt(3) * dist).add(1)
-    elif nu == 2.5:
-        poly = (math.sqrt(5) * dist).add(1).add(5.0 / 3.0 * dist ** 2)
-    else:
-        raise NotImplementedError(f"Matern nu={nu}")
+    _, decay, poly = _matern_terms(d2, nu)
     return poly * decay
