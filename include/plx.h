@@ -110,7 +110,8 @@ int plx_build(plx_lattice *lat, const float *d_ref, int64_t n, int d,
  *      keys = [m_r][plx_key_words(d)] uint32 (plx_copy_local_keys), all-gathered in
  *      rank order (RCCL all_gather through torch.distributed in this repo);
  *   3. plx_build_merge     numbers the union (first occurrence in rank order, then
- *      local order: the same ids plx_build's shard-major numbering produces),
+ *      local order -- or along the Morton curve of the vertices, see "vertex_order": either way
+ *      the same ids plx_build's shard-major numbering produces),
  *      relabels the local corners, builds the neighbour table over the union and the
  *      splat CSR / slice tables over the rank's rows.
  * Afterwards the lattice behaves like one built by plx_build for that shard:
@@ -122,7 +123,10 @@ int plx_key_words(int d);                               /* uint32 words per pack
 int64_t plx_local_vertices(const plx_lattice *lat);     /* m_r after plx_build_local                     */
 int plx_copy_local_keys(plx_lattice *lat, void *d_dst, void *stream);   /* d_dst: [m_r][key_words] uint32 */
 int plx_build_merge(plx_lattice *lat, const void *d_all_keys, const int64_t *h_counts, int n_ranks,
-                    int my_rank, void *stream);
+                    int my_rank, int64_t total_points, void *stream);
+/* total_points: points of ALL ranks together (the row counts ride along with the key counts), the same value on every
+ * rank; it only feeds the choice of vertex numbering ("vertex_order" under plx_tune), which must fall the same way on
+ * every rank.  <= 0: unknown, the choice is made from the key counts alone. */
 
 int64_t plx_num_points(const plx_lattice *lat);    /* n                              */
 int64_t plx_num_owned(const plx_lattice *lat);     /* rows of this shard             */
@@ -240,7 +244,9 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
 
 /* Select a kernel variant by name (process-wide, not synchronised with running builds / MVMs: for A/B measurements
  * in one process -- the defaults are the shipped configuration).  Keys (default): "sort_points" (1; 0 keeps the
- * caller's point order), "order_zcurve" (1; 0 = lexicographic point order), "insert_dedupe" (1), "nbr_symmetric" (1),
+ * caller's point order), "order_zcurve" (1; 0 = lexicographic point order), "vertex_order" (1: vertices numbered along
+ * the Morton curve of their blur-axis coordinates where that pays, 65536 <= m <= 0.9 n (d+1); 0: always by first touch;
+ * 2: always Morton -- vertex ids are internal, the PLX_ARRAY_* exports are in whichever numbering the build used), "insert_dedupe" (1), "nbr_symmetric" (1),
  * "compact_nbr" (1 = when under half of the neighbour slots exist; 0 never, 2 always), "blur_vpt" (4; vertices per
  * thread at vd = 1: 2 or 4, anything else selects the general kernel), "blur_small" (1), "blur_narrow" (1),
  * "blur_multi" (1), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1), "block_path" (1 = block
@@ -249,8 +255,8 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
 int plx_tune(const char *key, int value);
 
 /* Names of the kernels the last plx_splat / plx_blur / plx_slice (or plx_apply) on this lattice launched, as
- * "splat=a+b;blur_axis=c;slice=d" -- the names rocprofv3 --kernel-trace shows (without template arguments), so that a
- * bench line can name what actually ran. */
+ * "splat=a+b;blur_axis=c;slice=d;vertex_order=morton|first_touch" -- the names rocprofv3 --kernel-trace shows (without
+ * template arguments) and the vertex numbering of the last build, so that a bench line can name what actually ran. */
 int plx_last_kernels(const plx_lattice *lat, char *buf, int cap);
 /* Block rows of the lattice's block tables (the single-column splat / slice path of coarse lattices: owned points
  * are cut into blocks, a block row = one distinct vertex of one block), or 0 when the lattice uses the

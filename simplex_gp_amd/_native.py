@@ -37,7 +37,7 @@ _SIGNATURES = {
     "plx_key_words": (_i32, [_i32]),
     "plx_local_vertices": (_i64, [_vp]),
     "plx_copy_local_keys": (_i32, [_vp, _vp, _vp]),
-    "plx_build_merge": (_i32, [_vp, _vp, ctypes.POINTER(_i64), _i32, _i32, _vp]),
+    "plx_build_merge": (_i32, [_vp, _vp, ctypes.POINTER(_i64), _i32, _i32, _i64, _vp]),
     "plx_num_points": (_i64, [_vp]),
     "plx_num_owned": (_i64, [_vp]),
     "plx_num_vertices": (_i64, [_vp]),

@@ -42,7 +42,7 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->row_ptr,
             &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
             &L->sortkey_in, &L->sortkey_out,
-            &L->bc_pt, &L->bc_w, &L->srow, &L->brow_ptr, &L->brow_vid, &L->s2_idx, &L->s2_ptr, &L->s2_vid, &L->s2_wave, &L->partial, &L->pair_nbr, &L->inv_perm};
+            &L->bc_pt, &L->bc_w, &L->srow, &L->brow_ptr, &L->brow_vid, &L->s2_idx, &L->s2_ptr, &L->s2_vid, &L->s2_wave, &L->partial, &L->pair_nbr, &L->inv_perm, &L->vslot, &L->vkeys_alt, &L->vslot_alt, &L->vorder};
 }
 
 struct DeviceGuard {
@@ -165,7 +165,9 @@ int plx_build_local(plx_lattice *L, const float *d_ref_local, int64_t n_local, i
     L->own_begin = 0; L->own_end = n_local;
     memset(&L->taps, 0, sizeof(L->taps));
     for (int i = 0; i < ntaps; ++i) L->taps.c[i] = h_taps[i];
+    L->for_merge = true;
     int rc = build_local_impl(L, d_ref_local, (hipStream_t)stream);
+    L->for_merge = false;
     if (rc == PLX_OK) L->local_ready = true;
     return rc;
 }
@@ -184,7 +186,7 @@ int plx_copy_local_keys(plx_lattice *L, void *d_dst, void *stream)
     return PLX_OK;
 }
 
-int plx_build_merge(plx_lattice *L, const void *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
+int plx_build_merge(plx_lattice *L, const void *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank, int64_t total_points,
                     void *stream)
 {
     if (!L || !d_all_keys || !h_counts) { set_error("plx_build_merge: NULL argument"); return PLX_ERR_INVALID; }
@@ -195,6 +197,7 @@ int plx_build_merge(plx_lattice *L, const void *d_all_keys, const int64_t *h_cou
     }
     DeviceGuard g(L->device);
     if (!g.ok) { set_error("plx_build_merge: cannot select device %d", L->device); return PLX_ERR_HIP; }
+    L->merge_total_points = total_points;
     int rc = build_merge_impl(L, (const uint32_t *)d_all_keys, h_counts, n_ranks, my_rank, (hipStream_t)stream);
     L->local_ready = false;
     if (rc == PLX_OK) L->built = true;
@@ -478,7 +481,8 @@ int plx_apply_times(plx_lattice *L, float *h_ms, int cap, int *count)
 int plx_last_kernels(const plx_lattice *L, char *buf, int cap)
 {
     if (!L || !buf || cap < 1) return PLX_ERR_INVALID;
-    snprintf(buf, (size_t)cap, "splat=%s;blur_axis=%s;slice=%s", L->kn_splat, L->kn_blur, L->kn_slice);
+    snprintf(buf, (size_t)cap, "splat=%s;blur_axis=%s;slice=%s;vertex_order=%s", L->kn_splat, L->kn_blur, L->kn_slice,
+             L->vertex_order ? "morton" : "first_touch");
     return PLX_OK;
 }
 

@@ -36,6 +36,9 @@
 
 #include <math.h>
 
+#include <algorithm>
+#include <utility>
+
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ eslot,
                                                         const uint32_t *__restrict__ ekeys, int n,
                                                         uint32_t *__restrict__ table,
-                                                        uint32_t *__restrict__ vkeys)
+                                                        uint32_t *__restrict__ vkeys, uint32_t *__restrict__ vslot)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
@@ -446,7 +449,9 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
         bool first = (r < 32) ? ((bits >> r) & 1u) : ((bits_hi >> (r - 32)) & 1u);
         if (first) {
             const size_t idx = (size_t)r * n + p;
-            table[eslot[idx]] = (uint32_t)id;
+            const uint32_t slot = eslot[idx];
+            table[slot] = (uint32_t)id;
+            vslot[id] = slot;
             uint32_t k[DW];
             load_key<DW>(ekeys, idx, k);
             store_key<DW>(vkeys, (size_t)id, k);
@@ -676,6 +681,110 @@ static float taps_variance(const float *c, int R)
     return mom2 / mom0 - mean * mean;
 }
 
+// ----------------------------------------------------------------------------
+// Vertex order.  First-touch numbering follows the points, so the vertices of one point block are consecutive -- good for
+// splat / slice -- but along a blur axis the neighbour of vertex v is ~15,000 ids away (every axis step changes all d+1
+// key coordinates).  In the basis of the blur directions, a_i = (k_d - k_i) / (d+1) for i < d (k_d = -sum k_i), a step along
+// axis i < d changes a_i ALONE by +-1 (axis d changes all of them).  Numbering the vertices along the Morton curve of
+// (a_0 .. a_{d-1}) puts the axis-i neighbour a median 2^(d-1-i) ids away for i < d and roughly halves the share of
+// neighbours beyond any cache-sized window (N = 1e6, d = 8, l = 0.69: farther than 87k ids 32 % -> 16 %, than 262k ids
+// 20 % -> 8.5 %; tools/vertex_order_study.py).  The numbering depends on the vertex set only, so every rank of a sharded
+// job derives the same one.  Measured (N = 1e6, d = 8, vd = 1, us per MVM, first touch -> Morton): l = 1.0 114 -> 94
+// (two-axis blur pass 10.8 -> 6.4), l = 0.69 211 -> 170, l = 0.5 415 -> 305, l = 0.4 438 -> 357, l = 0.35 373 -> 363,
+// l = 0.3 307 -> 357, l = 0.25 280 -> 346: where nearly every corner has a vertex of its own (m > 0.9 nnz) the blur has
+// few neighbours to find and splat / slice lose the point-order locality of first touch, so those keep first touch.
+// Cost: one 64-bit sort of m codes + two passes over the keys, +0.1 ms of 1.25 (l = 1.0), +0.24 of 1.9 (l = 0.69).
+int g_vertex_order = 1;      // 0: first touch; 1: Morton order where it pays (kMortonMinVertices <= m <= 0.9 corners); 2: always
+constexpr int kMortonMinVertices = 65536;
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void vertex_code_kernel(const uint32_t *__restrict__ vkeys, int m, int bits,
+                                                             unsigned long long *__restrict__ code, uint32_t *__restrict__ ids)
+{
+    constexpr int DW = (D + 1) / 2;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= m) return;
+    uint32_t kw[DW];
+    load_key<DW>(vkeys, (size_t)v, kw);
+    int key[D], kd = 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        key[c] = (int)(int16_t)((kw[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu);
+        kd -= key[c];
+    }
+    const int half = 1 << (bits - 1), top = (1 << bits) - 1;
+    int a[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const int q = (kd - key[c]) / (D + 1) + half;       // exact: all coordinates of a lattice point agree mod d+1
+        a[c] = q < 0 ? 0 : (q > top ? top : q);              // a clamp costs locality for far outliers only
+    }
+    unsigned long long z = 0;
+    for (int b = bits - 1; b >= 0; --b)
+#pragma unroll
+        for (int c = 0; c < D; ++c) z = (z << 1) | (unsigned long long)((a[c] >> b) & 1);
+    code[v] = z;
+    ids[v] = (uint32_t)v;
+}
+
+// order[new] = old  ->  keys into the new order, and the key -> id table follows
+template <int D>
+__global__ __launch_bounds__(kBlock) void vertex_permute_kernel(const uint32_t *__restrict__ order, int m,
+                                                                const uint32_t *__restrict__ vkeys_old,
+                                                                const uint32_t *__restrict__ vslot_old,
+                                                                uint32_t *__restrict__ vkeys_new, uint32_t *__restrict__ vslot_new,
+                                                                uint32_t *__restrict__ table)
+{
+    constexpr int DW = (D + 1) / 2;
+    const int nw = blockIdx.x * kBlock + threadIdx.x;
+    if (nw >= m) return;
+    const uint32_t old = order[nw];
+    uint32_t k[DW];
+    load_key<DW>(vkeys_old, (size_t)old, k);
+    store_key<DW>(vkeys_new, (size_t)nw, k);
+    const uint32_t slot = vslot_old[old];
+    vslot_new[nw] = slot;
+    table[slot] = (uint32_t)nw;
+}
+
+template <int D>
+static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream)
+{
+    // corners: how many (point, vertex) incidences stand behind the m vertices -- n (d+1) of the whole job, or the sum of
+    // the per-rank vertex counts when only those are known (plx_build_merge); the same number on every rank
+    constexpr int DW = (D + 1) / 2;
+    const int m = (int)L->m;
+    L->vertex_order = 0;
+    if (g_vertex_order == 0 || m < 2) return PLX_OK;
+    if (g_vertex_order == 1 && (m < kMortonMinVertices || 10 * (int64_t)m > 9 * corners)) return PLX_OK;
+    L->vertex_order = 1;
+    int bits = 64 / D;
+    if (bits > 8) bits = 8;
+    if (bits < 1) return PLX_OK;                              // d > 64 does not occur (PLX_MAX_DIM = 32)
+    const int key_bits = bits * D;
+    size_t temp = 0;
+    PLX_TRY(sort_pairs64_temp_bytes(m, key_bits, &temp));
+    PLX_TRY(ensure(L->sort_temp, temp + 16));
+    PLX_TRY(ensure(L->sortkey_in, (size_t)m * 8));
+    PLX_TRY(ensure(L->sortkey_out, (size_t)m * 8));
+    PLX_TRY(ensure(L->iota, (size_t)m * 4));
+    PLX_TRY(ensure(L->vorder, (size_t)m * 4 + 16));
+    PLX_TRY(ensure(L->vkeys_alt, (size_t)m * DW * 4 + 16));
+    PLX_TRY(ensure(L->vslot_alt, (size_t)m * 4 + 16));
+    const int nb = ceil_div(m, kBlock);
+    vertex_code_kernel<D><<<nb, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, bits, L->sortkey_in.as<unsigned long long>(),
+                                                     L->iota.as<uint32_t>());
+    PLX_TRY(sort_pairs64(L->sort_temp.p, temp, L->sortkey_in.as<uint64_t>(), L->sortkey_out.as<uint64_t>(),
+                         L->iota.as<uint32_t>(), L->vorder.as<uint32_t>(), m, key_bits, stream));
+    vertex_permute_kernel<D><<<nb, kBlock, 0, stream>>>(L->vorder.as<uint32_t>(), m, L->vkeys.as<uint32_t>(),
+                                                        L->vslot.as<uint32_t>(), L->vkeys_alt.as<uint32_t>(),
+                                                        L->vslot_alt.as<uint32_t>(), L->table.as<uint32_t>());
+    std::swap(L->vkeys, L->vkeys_alt);
+    std::swap(L->vslot, L->vslot_alt);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
 // ---- stage 1: everything that depends only on this lattice's own points --------------------
 // order, embed, hashed insert, first-touch numbering, per-corner vertex ids.  Leaves L->m (the
 // number of vertices THESE points touch), vkeys, evid, ew, perm and the key -> id table.
@@ -763,9 +872,11 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     const int m = L->h_pinned[0];
     L->m = m;
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));
+    PLX_TRY(ensure(L->vslot, (size_t)m * 4 + 16));
     assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->blockcnt.as<int>(),
                                                      L->eslot.as<uint32_t>(), L->ekeys.as<uint32_t>(), n,
-                                                     L->table.as<uint32_t>(), L->vkeys.as<uint32_t>());
+                                                     L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>());
+    if (!L->for_merge) PLX_TRY(renumber_vertices<D>(L, E, stream));   // (a job built from local rows renumbers the union, after the merge)
     mark();
     ids_kernel<<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
                                                          L->evid.as<int>());
@@ -829,7 +940,7 @@ __global__ __launch_bounds__(kBlock) void merge_assign_kernel(const uint32_t *__
                                                               const uint32_t *__restrict__ slot,
                                                               const uint32_t *__restrict__ keys, int M,
                                                               uint32_t *__restrict__ table,
-                                                              uint32_t *__restrict__ gkeys)
+                                                              uint32_t *__restrict__ gkeys, uint32_t *__restrict__ vslot)
 {
     constexpr int DW = (D + 1) / 2;
     const int idx = blockIdx.x * kBlock + threadIdx.x;
@@ -838,6 +949,7 @@ __global__ __launch_bounds__(kBlock) void merge_assign_kernel(const uint32_t *__
     const int gid = blockoff[blockIdx.x] + block_exclusive_scan(first, &total);
     if (idx < M && first) {
         table[slot[idx]] = (uint32_t)gid;
+        vslot[gid] = slot[idx];
         uint32_t k[DW];
         load_key<DW>(keys, (size_t)idx, k);
         store_key<DW>(gkeys, (size_t)gid, k);
@@ -888,9 +1000,12 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
     PLX_HIP_TRY(hipStreamSynchronize(stream));
     const int m = L->h_pinned[0];
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));   // local keys are no longer needed: all_keys holds them
+    PLX_TRY(ensure(L->vslot, (size_t)m * 4 + 16));
     merge_assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>(),
                                                            L->merge_slot.as<uint32_t>(), d_all_keys, (int)M,
-                                                           L->table.as<uint32_t>(), L->vkeys.as<uint32_t>());
+                                                           L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>());
+    L->m = m;
+    PLX_TRY(renumber_vertices<D>(L, L->merge_total_points > 0 ? L->merge_total_points * D1 : M, stream));
     const int64_t E = L->n * D1;
     merge_remap_kernel<<<ceil_div(E, kBlock), kBlock, 0, stream>>>(L->evid.as<int>(), E, L->merge_slot.as<uint32_t>(),
                                                                    L->table.as<uint32_t>(), (int)my_off);

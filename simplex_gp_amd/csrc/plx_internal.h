@@ -50,6 +50,9 @@ struct plx_lattice {
     bool timing = false;
     bool partial_cover = false;  // built by plx_build_merge: this rank's points do not touch every vertex
     bool local_ready = false;    // plx_build_local done, waiting for plx_build_merge
+    int vertex_order = 0;        // 0 first touch, 1 Morton order of the blur-axis coordinates (this build)
+    int64_t merge_total_points = 0;   // plx_build_merge: points of all ranks (<= 0: unknown)
+    bool for_merge = false;      // the local stage of a sharded build is running (vertex renumbering waits for the merge)
     bool lattice_rows = false;   // d_src / d_out rows are in lattice order (plx_set_row_order)
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
 
@@ -83,7 +86,9 @@ struct plx_lattice {
     plx::DevBuf sort_keys_out;   // int32 [nnz] sorted vertex id of every owned corner (kept: splat reads it at row ends)
 
     // structure
-    plx::DevBuf vkeys;      // uint32 [m][DW]        packed vertex keys, first-touch order
+    plx::DevBuf vkeys;      // uint32 [m][DW]        packed vertex keys, in vertex id order
+    plx::DevBuf vslot;      // uint32 [m]            hash-table slot of every vertex (renumbering)
+    plx::DevBuf vkeys_alt, vslot_alt, vorder;   // the other halves of the renumbering pass: keys / slots in the new order, order[new] = old
     plx::DevBuf ew;         // float  [d+1][n]       barycentric weights
     plx::DevBuf evid;       // int32  [d+1][n]       vertex ids
     plx::DevBuf nbr;        // int32  [d+1][2r][mstride]

@@ -107,8 +107,8 @@ class ShardedLatticeMVM:
         keys = self.lattice.build_local(ref_local, coeffs)
         # the one exchange of the build: vertex keys, with the key and row counts riding in its size message
         all_keys, counts, rows = all_gather_rows(keys, self.group, extra=[ref_local.shape[0]])
-        self.lattice.build_merge(all_keys, counts, self.rank)
         every = [r[0] for r in rows]
+        self.lattice.build_merge(all_keys, counts, self.rank, total_points=sum(every))
         self.n = sum(every) if self._n_total is None else self._n_total
         self.lo = sum(every[: self.rank])
         self.hi = self.lo + every[self.rank]

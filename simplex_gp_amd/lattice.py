@@ -115,14 +115,15 @@ class Lattice:
         nv.check(rc, "plx_copy_local_keys")
         return keys
 
-    def build_merge(self, all_keys, counts, rank):
-        """Stage 2: all ranks' keys concatenated in rank order ([sum(counts), key_words] int32)."""
+    def build_merge(self, all_keys, counts, rank, total_points=0):
+        """Stage 2: all ranks' keys concatenated in rank order ([sum(counts), key_words] int32); total_points = rows of
+        all ranks together (feeds the vertex-numbering choice only; 0 = unknown)."""
         all_keys = all_keys.contiguous()
         assert all_keys.is_cuda and all_keys.dtype == torch.int32 and all_keys.shape[0] == sum(counts)
         arr = (ctypes.c_int64 * len(counts))(*[int(c) for c in counts])
         with torch.cuda.device(self.device):
             rc = nv.lib().plx_build_merge(self._h, ctypes.c_void_p(all_keys.data_ptr()), arr, len(counts), rank,
-                                          _stream_ptr(self.device))
+                                          int(total_points), _stream_ptr(self.device))
         nv.check(rc, "plx_build_merge")
         return self
 

@@ -42,7 +42,7 @@ class OracleLattice:
         self._ref_local, self._coeffs = ref_local, np.asarray(coeffs, np.float32)
         return torch.from_numpy(self._pack(self._local.keys).copy())
 
-    def build_merge(self, all_keys, counts, rank):
+    def build_merge(self, all_keys, counts, rank, total_points=0):
         keys = all_keys.numpy()
         assert keys.shape[0] == sum(counts) and counts[rank] == self._local.m
         first = {}

@@ -218,9 +218,20 @@ def test_coldot_matches_torch(plx):
 
 
 @pytest.mark.parametrize("shards", [2, 3])
-def test_sharded_build_equals_replicated_build(plx, shards):
+@pytest.mark.parametrize("vertex_order", [0, 2])
+def test_sharded_build_equals_replicated_build(plx, shards, vertex_order):
     """plx_build_local + key exchange + plx_build_merge (each rank sees only its rows) gives the SAME
-    vertex numbering and the same per-shard tables as plx_build(shard_index, n_shards) on all rows."""
+    vertex numbering and the same per-shard tables as plx_build(shard_index, n_shards) on all rows -- by first touch
+    (shard-major) and along the Morton curve of the vertices' blur-axis coordinates (a function of the vertex set)."""
+    from simplex_gp_amd import _native as nv
+    nv.check(nv.lib().plx_tune(b"vertex_order", vertex_order), "plx_tune")
+    try:
+        _sharded_equals_replicated(plx, shards, "morton" if vertex_order else "first_touch")
+    finally:
+        nv.check(nv.lib().plx_tune(b"vertex_order", 1), "plx_tune")
+
+
+def _sharded_equals_replicated(plx, shards, numbering):
     from simplex_gp_amd import _native as nv
     from simplex_gp_amd.distributed import shard_bounds
     g = torch.Generator().manual_seed(21)
@@ -235,9 +246,10 @@ def test_sharded_build_equals_replicated_build(plx, shards):
     all_keys = torch.cat(keys, 0)
     total = None
     for r, (lat, (lo, hi)) in enumerate(zip(locals_, bounds)):
-        lat.build_merge(all_keys, counts, r)
+        lat.build_merge(all_keys, counts, r, total_points=n)
         rep = plx.Lattice().build(x, taps, shard=(r, shards))
         assert lat.m == rep.m and lat.n == hi - lo and lat.n_owned == hi - lo
+        assert lat.stage_kernels()["vertex_order"] == [numbering] == rep.stage_kernels()["vertex_order"]
         assert np.array_equal(lat.export(nv.ARRAY_KEYS), rep.export(nv.ARRAY_KEYS))            # same numbering
         assert np.array_equal(lat.export(nv.ARRAY_NEIGHBORS), rep.export(nv.ARRAY_NEIGHBORS))
         assert np.array_equal(lat.export(nv.ARRAY_ENTRY_VERTEX), rep.export(nv.ARRAY_ENTRY_VERTEX)[:, lo:hi])

@@ -559,3 +559,36 @@ def test_blur_axis_pairs_equal_single_axis_passes(plx):
     finally:
         nv.check(lib.plx_tune(b"blur_fuse", 1), "plx_tune")
         nv.check(lib.plx_tune(b"blur_small", 1), "plx_tune")
+
+
+def test_vertex_order_morton_is_a_relabelling(plx):
+    """vertex_order = 2 numbers the vertices along the Morton curve of the blur-axis coordinates instead of by first
+    touch: the same vertex set under other ids, so the filter output agrees to fp32 rounding (the per-vertex sums see
+    their block rows in another order), the keys agree as sets, and the oracle still bounds the result."""
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    rng = np.random.default_rng(97)
+    try:
+        for n, d, scale, vd in [(3000, 1, 1.0, 1), (20000, 2, 1.0, 3), (50000, 8, 1.0, 1), (20000, 5, 0.2, 1),
+                                (20011, 4, 1.0, 12), (30000, 12, 1.0, 1), (10000, 20, 1.0, 2)]:
+            ref = (rng.standard_normal((n, d)) / scale).astype(np.float32)
+            src = torch.from_numpy(rng.standard_normal((n, vd)).astype(np.float32)).cuda()
+            x = torch.from_numpy(ref).cuda()
+            outs, keys = [], []
+            for mode in (0, 2):
+                nv.check(lib.plx_tune(b"vertex_order", mode), "plx_tune")
+                lat = plx.Lattice().build(x, taps)
+                outs.append(lat.apply(src).clone())
+                assert lat.stage_kernels()["vertex_order"] == [["first_touch", None, "morton"][mode]]
+                k = lat.export(nv.ARRAY_KEYS)
+                keys.append(k[np.lexsort(k.T[::-1])])
+                lat.close()
+            assert np.array_equal(keys[0], keys[1]), (n, d)
+            assert rel_l2(outs[1].cpu().numpy(), outs[0].cpu().numpy()) <= 1e-6, (n, d)
+            oracle.set_exact_mode(False)
+            want = oracle.filter(src.cpu().numpy(), ref, taps)
+            oracle.set_exact_mode(True)
+            assert rel_l2(outs[1].cpu().numpy(), want) <= TOL_ORACLE
+    finally:
+        nv.check(lib.plx_tune(b"vertex_order", 1), "plx_tune")

@@ -49,9 +49,12 @@ def main():
     v = torch.randn(args.n, args.vd, generator=g).cuda()
     ref = (x / args.ell).contiguous().cuda()
     lat = plx.Lattice()
+    import time
     for _ in range(args.builds):
+        t0 = time.perf_counter()
         lat.build(ref, np.array([0.34608543, 1.0, 0.34608543], np.float32))
         torch.cuda.synchronize()
+        build_ms = (time.perf_counter() - t0) * 1e3
     if args.lattice_rows:
         lat.set_lattice_row_order(True)
     out = torch.empty_like(v)
@@ -64,7 +67,7 @@ def main():
         lat.apply(v, out)
     b.record()
     torch.cuda.synchronize()
-    print(f"m={lat.m} block_rows={lat.block_rows} apply {a.elapsed_time(b) / args.reps * 1e3:.1f} us  kernels {lat.stage_kernels()}")
+    print(f"m={lat.m} build {build_ms:.3f} ms block_rows={lat.block_rows} apply {a.elapsed_time(b) / args.reps * 1e3:.1f} us  kernels {lat.stage_kernels()}")
 
 
 if __name__ == "__main__":

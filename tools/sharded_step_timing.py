@@ -9,6 +9,10 @@ import simplex_gp_amd as plx
 from tools.ab_apply import timeit, RBF1
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n_local, d, ell = (int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000), 8, 1.0
+from simplex_gp_amd import _native as nv
+for kv in sys.argv[3:]:                      # plx_tune pairs: vertex_order=0 ...
+    k, val = kv.split("=")
+    nv.check(nv.lib().plx_tune(k.encode(), int(val)), "plx_tune")
 g = torch.Generator().manual_seed(1234)
 x = torch.randn(n_local * W, d, generator=g) / ell
 v = torch.randn(n_local, 1, generator=g).cuda()
@@ -22,11 +26,11 @@ x0 = x[:n_local].contiguous().cuda()
 def sync(): torch.cuda.synchronize(); return time.perf_counter()
 best = {}
 for rep in range(4):
-    t0 = sync(); lat.build_local(x0, RBF1); t1 = sync(); lat.build_merge(all_keys, counts, 0); t2 = sync()
+    t0 = sync(); lat.build_local(x0, RBF1); t1 = sync(); lat.build_merge(all_keys, counts, 0, total_points=n_local * W); t2 = sync()
     best["build_local_ms"] = min(best.get("build_local_ms", 9e9), (t1 - t0) * 1e3)
     best["build_merge_ms"] = min(best.get("build_merge_ms", 9e9), (t2 - t1) * 1e3)
 lat.set_timing(True)
-lat.build_local(x0, RBF1); lat.build_merge(all_keys, counts, 0); torch.cuda.synchronize()
+lat.build_local(x0, RBF1); lat.build_merge(all_keys, counts, 0, total_points=n_local * W); torch.cuda.synchronize()
 best["merge_stage_ms"] = {k: round(v, 3) for k, v in lat.build_times_ms().items()}
 lat.set_timing(False)
 vals, scr = lat.new_values(1), lat.new_values(1)

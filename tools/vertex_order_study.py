@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Would another vertex numbering shorten the blur's neighbour distances?  Exports keys + neighbour table of a lattice and
+compares the current numbering (first touch along the point order) with a Morton order of the vertices' own coordinates
+in the blur-axis basis a_i = (k_d - k_i) / (d+1) (an axis step i < d changes a_i alone by +-1).
+Prints, per numbering, the share of existing neighbours farther than a few thresholds (in vertex ids)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import simplex_gp_amd as plx
+from simplex_gp_amd import _native as nv
+
+n, d = 1_000_000, 8
+ell = float(sys.argv[1]) if len(sys.argv) > 1 else 0.6931
+g = torch.Generator().manual_seed(1234)
+x = torch.randn(n, d, generator=g)
+lat = plx.Lattice().build((x / ell).contiguous().cuda(), np.array([0.34608543, 1.0, 0.34608543], np.float32))
+keys = lat.export(nv.ARRAY_KEYS).astype(np.int64)            # [m, d]
+nbr = lat.export(nv.ARRAY_NEIGHBORS)                         # [d+1, 2, m]
+m = lat.m
+kd = -keys.sum(1)
+a = (kd[:, None] - keys) // (d + 1)
+assert np.array_equal(a * (d + 1), kd[:, None] - keys)
+a -= a.min(0)
+bits = int(np.ceil(np.log2(a.max() + 1)))
+code = np.zeros(m, np.uint64)
+for b in range(bits - 1, -1, -1):
+    for i in range(d):
+        code = (code << np.uint64(1)) | ((a[:, i] >> b) & 1).astype(np.uint64)
+order = np.argsort(code, kind="stable")
+rank_morton = np.empty(m, np.int64); rank_morton[order] = np.arange(m)
+# plain lexicographic order of a for comparison
+lex = np.lexsort(tuple(a[:, i] for i in range(d - 1, -1, -1)))
+rank_lex = np.empty(m, np.int64); rank_lex[lex] = np.arange(m)
+print(f"ell={ell} m={m} bits/coord={bits}")
+for name, rank in (("current (first touch)", np.arange(m)), ("morton(axis basis)", rank_morton), ("lexicographic(axis basis)", rank_lex)):
+    rows = []
+    for axis in range(d + 1):
+        nb = nbr[axis].reshape(-1)
+        src = np.tile(np.arange(m), 2)
+        ok = nb >= 0
+        dist = np.abs(rank[nb[ok]] - rank[src[ok]])
+        rows.append([float((dist > t).mean()) for t in (1024, 32768, 87000, 262144, 1000000)] + [float(np.median(dist))])
+    rows = np.array(rows)
+    print(f"{name:28s} share of neighbours farther than 1k/32k/87k/262k/1M ids (mean over axes): "
+          + " ".join(f"{v:.3f}" for v in rows[:, :5].mean(0)) + f"   median distance per axis: {rows[:, 5].astype(int).tolist()}")
