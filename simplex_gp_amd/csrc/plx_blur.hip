@@ -260,22 +260,97 @@ __global__ __launch_bounds__(kBlock) void blur_pair_v1_kernel(const float *__res
     }
 }
 
-// composite neighbour tables for the axis pairs (0,1), (2,3), ...; called by the lattice build
-int build_blur_pairs(plx_lattice *L, hipStream_t stream)
+// The same two axes per launch for rows of 2..4 chunks (vd 2..16: every CG iteration).  There the id loads are shared by
+// the row: a pair launch moves 32 B of ids + one row read + one row written per vertex where two single passes move
+// 2 x (8 B + row + row), 128 against 208 bytes at vd = 12, and the 8 gathered rows come from the L2 / MALL like the
+// 2 x 2 of the single passes (they are near in id since the vertices are numbered along the Morton curve of the axis
+// coordinates).  Same operations in the same order as two blur_axis_narrow_kernel launches.
+int g_blur_fuse_vec = 1;   // 0: one axis per launch for vd > 1; 1: axis pairs when order = 1 and the row has 2..4 chunks
+
+template <int ROWLEN>
+__global__ __launch_bounds__(kBlock) void blur_pair_narrow_kernel(const float4 *__restrict__ old, float4 *__restrict__ out,
+                                                                  const int *__restrict__ pn, uint32_t total,
+                                                                  uint32_t mstride, TapArgs taps, int ntiles, int remap,
+                                                                  int ablate)
 {
-    L->use_pairs = false;
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const uint32_t item = (uint32_t)tile * kBlock + threadIdx.x;
+    if (item >= total) return;
+    const uint32_t i = item / ROWLEN, ch = item - i * ROWLEN;
+    int id[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) id[s] = pn[(uint32_t)s * mstride + i];
+    const float4 c = old[item];
+    float4 g[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) g[s] = old[(id[s] >= 0 && !(ablate & 1)) ? (uint32_t)id[s] * ROWLEN + ch : item];
+    // tmp at nbr_j(v, -1), v, nbr_j(v, +1), each from zero in tap order as blur_axis_narrow_kernel forms it; an absent
+    // intermediate vertex (slots 1 / 6) is skipped by the outer sum exactly as the second single pass skips it
+    float4 tm = f4_zero(), t0 = f4_zero(), tp = f4_zero();
+    tm = f4_sel(id[0] >= 0, f4_add(tm, f4_scale(taps.c[0], g[0])), tm);
+    tm = f4_add(tm, f4_scale(taps.c[1], g[1]));
+    tm = f4_sel(id[2] >= 0, f4_add(tm, f4_scale(taps.c[2], g[2])), tm);
+    t0 = f4_sel(id[3] >= 0, f4_add(t0, f4_scale(taps.c[0], g[3])), t0);
+    t0 = f4_add(t0, f4_scale(taps.c[1], c));
+    t0 = f4_sel(id[4] >= 0, f4_add(t0, f4_scale(taps.c[2], g[4])), t0);
+    tp = f4_sel(id[5] >= 0, f4_add(tp, f4_scale(taps.c[0], g[5])), tp);
+    tp = f4_add(tp, f4_scale(taps.c[1], g[6]));
+    tp = f4_sel(id[7] >= 0, f4_add(tp, f4_scale(taps.c[2], g[7])), tp);
+    float4 acc = f4_zero();
+    acc = f4_sel(id[1] >= 0, f4_add(acc, f4_scale(taps.c[0], tm)), acc);
+    acc = f4_add(acc, f4_scale(taps.c[1], t0));
+    acc = f4_sel(id[6] >= 0, f4_add(acc, f4_scale(taps.c[2], tp)), acc);
+    out[item] = acc;
+}
+
+static void launch_blur_pair_narrow(const float4 *cur, float4 *nxt, const int *pn, int m, int64_t mstride, int rowlen,
+                                    const TapArgs &taps, hipStream_t stream, int remap)
+{
+    const uint32_t total = (uint32_t)m * (uint32_t)rowlen;
+    const int nt = ceil_div((int64_t)total, kBlock);
+    const int grid = tile_grid(nt, remap);
+    switch (rowlen) {
+    case 2: blur_pair_narrow_kernel<2><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, g_blur_ablate); break;
+    case 3: blur_pair_narrow_kernel<3><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, g_blur_ablate); break;
+    default: blur_pair_narrow_kernel<4><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, g_blur_ablate); break;
+    }
+}
+
+// Which axes share a launch: (0,1) (2,3) ...; when d + 1 is odd the last axis runs alone.  (Measured with the Morton
+// numbering, where the last axis is the one with far neighbours: pairing it -- (0,1) .. (d-4,d-3), d-2 alone, (d-1,d) --
+// made the CG blur 6 % slower, the pair's three far gathers cost more than the single pass's two.  Staging a
+// workgroup's 768 rows in LDS and reading in-tile neighbours from there: 111 us against 57 us per pair launch.)
+static inline int pair_at_axis(int d1, int axis) { return (axis + 1 < d1 && !(axis & 1)) ? axis / 2 : -1; }
+
+// composite neighbour tables for the axis pairs: built with the lattice when its single-column blur
+// uses them, otherwise by the first multi-column blur that does
+int ensure_blur_pairs(plx_lattice *L, hipStream_t stream)
+{
+    if (L->pairs_ready) return PLX_OK;
     const int d1 = L->d + 1, m = (int)L->m;
-    if (g_blur_fuse == 0 || L->order != 1 || d1 < 2 || m == 0) return PLX_OK;
-    if (g_blur_fuse == 1 && m > kPairMaxVertices) return PLX_OK;
     const int npairs = d1 / 2;
     PLX_TRY(ensure(L->pair_nbr, (size_t)npairs * 8 * L->mstride * 4 + 64));
     for (int p = 0; p < npairs; ++p)
         pair_nbr_kernel<<<ceil_div(m, kBlock), kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, 2 * p, 2 * p + 1,
                                                                     L->pair_nbr.as<int>() + (size_t)p * 8 * L->mstride);
     PLX_HIP_TRY(hipGetLastError());
+    L->pairs_ready = true;
+    return PLX_OK;
+}
+
+int build_blur_pairs(plx_lattice *L, hipStream_t stream)
+{
+    L->use_pairs = false;
+    L->pairs_ready = false;
+    const int d1 = L->d + 1, m = (int)L->m;
+    if (g_blur_fuse == 0 || L->order != 1 || d1 < 2 || m == 0) return PLX_OK;
+    if (g_blur_fuse == 1 && m > kPairMaxVertices) return PLX_OK;
+    PLX_TRY(ensure_blur_pairs(L, stream));
     L->use_pairs = true;
     return PLX_OK;
 }
+
 
 // vd == 1 on a lattice so small that both ping-pong copies of the vertex values fit in LDS (m <= kSmallM): every
 // pass is launch-bound there (a few us of host + device launch cost for < 1 us of work), so ONE workgroup runs all
@@ -499,11 +574,24 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
     }
     float *cur = d_values, *nxt = d_scratch;
     bool paired = false;
+    const bool pair_vec = vd > 1 && order == 1 && g_blur_fuse_vec != 0 && g_blur_narrow && vdp / 4 >= 2 && vdp / 4 <= 4 &&
+                          d1 >= 2 && m > 0 && (int64_t)8 * L->mstride < (1ll << 32);
+    if (pair_vec) PLX_TRY(ensure_blur_pairs(L, stream));
     for (int axis = 0; axis < d1; ++axis) {
         const int *nb = L->nbr.as<int>() + (size_t)axis * 2 * order * L->mstride;
-        if (v1 && order == 1 && L->use_pairs && !L->use_compact && g_blur_fuse != 0 && axis + 1 < d1) {
+        const int pair = pair_at_axis(d1, axis);
+        if (pair_vec && pair >= 0) {
+            const int *pn = L->pair_nbr.as<int>() + (size_t)pair * 8 * L->mstride;
+            launch_blur_pair_narrow(reinterpret_cast<const float4 *>(cur), reinterpret_cast<float4 *>(nxt), pn, m, L->mstride,
+                                    vdp / 4, L->taps, stream, g_xcd_remap);
+            paired = true;
+            ++axis;
+            float *t = cur; cur = nxt; nxt = t;
+            continue;
+        }
+        if (v1 && order == 1 && L->use_pairs && !L->use_compact && g_blur_fuse != 0 && pair >= 0) {
             // axes (axis, axis + 1) in one launch
-            const int *pn = L->pair_nbr.as<int>() + (size_t)(axis / 2) * 8 * L->mstride;
+            const int *pn = L->pair_nbr.as<int>() + (size_t)pair * 8 * L->mstride;
             if (g_blur_vpt == 4) {
                 const int nt = ceil_div(ceil_div(m, 4), kBlock);
                 blur_pair_v1_kernel<4><<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, pn, m, L->mstride, L->taps, nt, g_xcd_remap);
@@ -533,7 +621,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             case 2: launch_blur_v1<2>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             default: launch_blur_v1<3>(cur, nxt, nb, m, L->mstride, L->taps, stream); break;
             }
-            L->kn_blur = paired ? "blur_pair_v1_kernel+blur_axis_v1_kernel" : "blur_axis_v1_kernel";
+            L->kn_blur = "blur_axis_v1_kernel";
         } else if (vd == 1) {
             launch_blur_general<float>(cur, nxt, nb, m, L->mstride, 1, order, L->taps, stream);
             L->kn_blur = "blur_axis_kernel";
@@ -569,7 +657,10 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
         }
         float *t = cur; cur = nxt; nxt = t;
     }
-    if (paired && (d1 & 1) == 0) L->kn_blur = "blur_pair_v1_kernel";
+    if (paired) {   // pairs, plus one axis on its own when d + 1 is odd
+        if (pair_vec) L->kn_blur = (d1 & 1) ? "blur_pair_narrow_kernel+blur_axis_narrow_kernel" : "blur_pair_narrow_kernel";
+        else L->kn_blur = (d1 & 1) ? "blur_pair_v1_kernel+blur_axis_v1_kernel" : "blur_pair_v1_kernel";
+    }
     tmark(L, stream);
     *result_in_scratch = (cur == d_scratch) ? 1 : 0;
     PLX_HIP_TRY(hipGetLastError());

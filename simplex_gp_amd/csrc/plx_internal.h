@@ -101,7 +101,7 @@ struct plx_lattice {
     plx::DevBuf cmask;      // uint32 [d+1][nquads]
     plx::DevBuf cbase;      // uint32 [d+1][nqwaves + 1]
     plx::DevBuf cids;       // int32  [total existing neighbours]
-    bool use_pairs = false;      // pair_nbr holds the composite neighbours of the axis pairs (0,1), (2,3), ... (plx_blur.hip)
+    bool pairs_ready = false, use_pairs = false;      // pair_nbr holds the composite neighbours of the axis pairs (0,1), (2,3), ... (plx_blur.hip)
     plx::DevBuf pair_nbr;   // int32  [(d+1)/2][8][mstride]  nbr_i(nbr_j(v, b), a) without the centre; -1 absent
     plx::DevBuf csr_pt;     // int32  [nnz]          local (owned) point index, sorted by vertex
     plx::DevBuf csr_row;    // int32  [nnz]          the same points numbered as the caller's rows (vd = 1 splat

@@ -46,6 +46,7 @@ extern int g_block_path;
 extern int g_block_threads;
 extern int g_block_ablate;
 extern int g_blur_fuse;
+extern int g_blur_fuse_vec;
 extern int g_scatter_store;
 extern int g_unpermute_gather;
 extern int g_block_lds_sort;

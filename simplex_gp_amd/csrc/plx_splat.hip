@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void splat_group_kernel(const int *__restri
     constexpr int G = 64 / NCHP;                       // groups per wave
     constexpr int WC = G * RUN;                  // corners per wave = one chunk of the partial protocol
     constexpr int RS = RUN + 1;                  // LDS words per group region
-    constexpr int U = 8;                               // source rows in flight per lane
+    constexpr int U = 8;                               // source rows in flight per lane (16: no faster)
     __shared__ int lds_pt[kBlock / 64][G * RS];
     __shared__ float lds_w[kBlock / 64][G * RS];
     __shared__ int lds_vid[kBlock / 64][G * RS];
@@ -408,21 +408,35 @@ __global__ __launch_bounds__(kBlock) void splat_group_kernel(const int *__restri
     if (k0 >= nnz) return;
     // stage: corner k0 + r -> slot (r / run) * RS + r % run; the first corner of a run also closes the
     // region of the run before it (its sign bit says whether that run's last corner closes a row)
-    for (int r = lane; r <= WC; r += 64) {
-        const int e = k0 + r;
+    // (all loads of the wave issued before the first LDS store: with a load -> store loop a wave had three
+    // 256-byte requests in flight at a time and the staging alone took a third of the kernel)
+    constexpr int NST = WC / 64 + 1;                   // r = lane + 64 it covers 0 .. WC
+    int st_pt[NST], st_vid[NST];
+    float st_w[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int r = lane + 64 * it, e = k0 + r;
         const bool in = e < nnz && r < WC;
-        const int pt = e < nnz ? csr_pt[e] : (int)0x80000000;          // past the data: reads as a row head
-        const float w = in ? csr_w[e] : 0.f;
-        const int vid = in ? csr_vid[e] : 0;
+        st_pt[it] = (e < nnz && r <= WC) ? csr_pt[e] : (int)0x80000000;   // past the data: reads as a row head
+        st_w[it] = in ? csr_w[e] : 0.f;
+        st_vid[it] = in ? csr_vid[e] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int r = lane + 64 * it;
         const int rg = r / RUN, rj = r - rg * RUN;
-        if (r < WC) { lds_pt[wave][rg * RS + rj] = pt; lds_w[wave][rg * RS + rj] = w; lds_vid[wave][rg * RS + rj] = vid; }
-        if (rj == 0 && rg > 0) lds_pt[wave][(rg - 1) * RS + RUN] = pt;
+        if (r < WC) { lds_pt[wave][rg * RS + rj] = st_pt[it]; lds_w[wave][rg * RS + rj] = st_w[it]; lds_vid[wave][rg * RS + rj] = st_vid[it]; }
+        if (r <= WC && rj == 0 && rg > 0) lds_pt[wave][(rg - 1) * RS + RUN] = st_pt[it];
     }
     __builtin_amdgcn_wave_barrier();                   // LDS traffic of one wave is in order; keep the compiler from moving it
 
-    const int g = lane / NCHP, cl = lane - g * NCHP;
-    const bool col = cl < nch;
-    const int len = min(RUN, nnz - (k0 + g * RUN));   // <= 0: this group has no corners
+    // NCHP need not divide 64 (3 chunks: 21 groups, lane 63 idles): lanes past the last group walk group 0's
+    // region with no corners of their own and never store
+    const int graw = lane / NCHP;
+    const bool lane_on = graw < G;
+    const int g = lane_on ? graw : 0, cl = lane - graw * NCHP;
+    const bool col = cl < nch && lane_on;
+    const int len = lane_on ? min(RUN, nnz - (k0 + g * RUN)) : 0;   // <= 0: this group has no corners
     const int *gp = lds_pt[wave] + g * RS;
     const float *gw = lds_w[wave] + g * RS;
     const int *gv = lds_vid[wave] + g * RS;
@@ -591,7 +605,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         }
         // one chunk (vd 2..4): the scan kernel is 25 % faster; two and more: the group kernel by 5 % .. 4x
         if (nch_total >= 2 && nch_total <= 16 && g_splat_group && (int64_t)n_own * nch_total < (1ll << 32) && (int64_t)m * nch_total < (1ll << 32)) {
-            const int nchp = nch_total <= 2 ? 2 : (nch_total <= 4 ? 4 : (nch_total <= 8 ? 8 : 16));
+            const int nchp = nch_total <= 2 ? 2 : (nch_total == 3 ? 3 : (nch_total <= 4 ? 4 : (nch_total <= 8 ? 8 : 16)));
             const int wc = (64 / nchp) * kGroupRun;
             const int nwchunks = ceil_div(nnz, wc), nt = ceil_div(nwchunks, kBlock / 64);
             PLX_TRY(ensure(L->head_partial, (size_t)nwchunks * vdp * 4));
@@ -601,6 +615,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
             const int grid = tile_grid(nt, g_xcd_remap);
             switch (nchp) {
             case 2: splat_group_kernel<float4, 2, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
+            case 3: splat_group_kernel<float4, 3, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
             case 4: splat_group_kernel<float4, 4, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
             case 8: splat_group_kernel<float4, 8, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
             default: splat_group_kernel<float4, 16, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;

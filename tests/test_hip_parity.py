@@ -592,3 +592,39 @@ def test_vertex_order_morton_is_a_relabelling(plx):
             assert rel_l2(outs[1].cpu().numpy(), want) <= TOL_ORACLE
     finally:
         nv.check(lib.plx_tune(b"vertex_order", 1), "plx_tune")
+
+
+def test_blur_axis_pairs_for_rows_equal_single_axis_passes(plx):
+    """Order-1 blur of 2..16 columns with two axes per launch (blur_pair_narrow_kernel over the composite neighbour table)
+    against one axis per launch: the same fp32 operations in the same order, so the same bits; rows of 2, 3 and 4
+    chunks, d + 1 even and odd, dense and sparse neighbourhoods, both vertex numberings."""
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    rng = np.random.default_rng(93)
+    try:
+        for n, d, scale, vd, vo in [(3000, 1, 1.0, 5, 1), (20000, 2, 1.0, 8, 1), (30000, 3, 0.5, 12, 2), (50000, 8, 1.0, 11, 2),
+                                    (20000, 5, 0.2, 16, 1), (20011, 4, 1.0, 7, 2)]:
+            nv.check(lib.plx_tune(b"vertex_order", vo), "plx_tune")
+            ref = (rng.standard_normal((n, d)) / scale).astype(np.float32)
+            src = torch.from_numpy(rng.standard_normal((n, vd)).astype(np.float32)).cuda()
+            x = torch.from_numpy(ref).cuda()
+            outs, blurs = [], []
+            for mode in (0, 1):
+                nv.check(lib.plx_tune(b"blur_fuse_vec", mode), "plx_tune")
+                lat = plx.Lattice().build(x, taps)
+                vals = lat.splat(src)
+                blurs.append(lat.blur(vals.clone(), vd=vd).clone())
+                outs.append(lat.apply(src).clone())
+                names = lat.stage_kernels()["blur_axis"]
+                assert ("blur_pair_narrow_kernel" in names) == (mode == 1), (mode, names)
+                lat.close()
+            assert torch.equal(blurs[0], blurs[1]), (n, d, vd)
+            assert torch.equal(outs[0], outs[1]), (n, d, vd)
+            oracle.set_exact_mode(False)
+            want = oracle.filter(src.cpu().numpy(), ref, taps)
+            oracle.set_exact_mode(True)
+            assert rel_l2(outs[1].cpu().numpy(), want) <= TOL_ORACLE
+    finally:
+        nv.check(lib.plx_tune(b"blur_fuse_vec", 1), "plx_tune")
+        nv.check(lib.plx_tune(b"vertex_order", 1), "plx_tune")
