@@ -244,7 +244,8 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
 
 /* Select a kernel variant by name (process-wide, not synchronised with running builds / MVMs: for A/B measurements
  * in one process -- the defaults are the shipped configuration).  Keys (default): "sort_points" (1; 0 keeps the
- * caller's point order), "order_zcurve" (1; 0 = lexicographic point order), "vertex_order" (1: vertices numbered along
+ * caller's point order), "order_zcurve" (1; 0 = lexicographic point order, 2 = Z-curve of the
+ * blur-axis coordinates), "blur_fuse_vec" (1 = two blur axes per launch for rows of 2..4 chunks; 0 = one), "vertex_order" (1: vertices numbered along
  * the Morton curve of their blur-axis coordinates where that pays, 65536 <= m <= 0.9 n (d+1); 0: always by first touch;
  * 2: always Morton -- vertex ids are internal, the PLX_ARRAY_* exports are in whichever numbering the build used), "insert_dedupe" (1), "nbr_symmetric" (1),
  * "compact_nbr" (1 = when under half of the neighbour slots exist; 0 never, 2 always), "blur_vpt" (4; vertices per

@@ -42,7 +42,7 @@
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
-int g_order_zcurve = 1;  // 1: points ordered along the Z-curve of their rounded lattice coordinates; 0: lexicographically
+int g_order_zcurve = 1;  // 1: points ordered along the Z-curve of their rounded lattice coordinates; 0: lexicographically; 2: Z-curve of the blur-axis coordinates
 int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only and mirrors the hits
                               // (fine regime 7.2 -> 4.9 ms; an occupancy bitmap on top did not pay)
 int g_insert_dedupe = 1;      // wave-level skip of repeated keys in the hashed insert (0.38 -> 0.32 ms at m = 4e5)
@@ -184,6 +184,14 @@ __global__ __launch_bounds__(kBlock) void sortkey_kernel(const float *__restrict
         float c = rintf(el[i] * (1.0f / (float)D1));
         c = fminf(fmaxf(c, -1.0e6f), 1.0e6f);                // NaN -> -1e6 (fmaxf), rejected later by embed
         q[i] = (int)c;
+    }
+    if (oa.zcurve == 2) {
+        // the vertices' own curve (renumber_vertices): blur-axis coordinates a_i = q_d - q_i, i < d.  A point and the
+        // vertices of its simplex differ by at most one step in every a_i, so points and vertices that meet in splat and
+        // slice are close on the same curve.  Measured against mode 1 (N = 1e6, d = 8): +-3 % per MVM (l = 1.0 93.7 vs
+        // 91.4 us, l = 0.5 299 vs 309, CG iteration 34.8 vs 35.0 ms): not the default.
+#pragma unroll
+        for (int i = 0; i < D; ++i) q[i] = q[D] - q[i];
     }
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
@@ -817,6 +825,7 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     oa.n_shards = L->n_shards;
     oa.zcurve = g_order_zcurve;
     oa.ncoord = D1 < 16 ? D1 : 16;
+    if (oa.zcurve == 2) oa.ncoord = D < 16 ? D : 16;
     int shard_bits = 0;
     while ((1 << shard_bits) < L->n_shards) ++shard_bits;
     oa.bits = (64 - shard_bits) / oa.ncoord;
