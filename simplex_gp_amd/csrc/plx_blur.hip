@@ -168,9 +168,10 @@ __global__ __launch_bounds__(kBlock) void blur_axis_compact_kernel(const float *
 // three composites absent, exactly as the two-pass form never reads tmp there).  The inner sums are formed from zero
 // in tap order like a single pass, then the outer sum likewise: the same fp32 operations in the same order as two
 // launches, half the launches.  Costs 8 instead of 2 x 2 id loads and 8 instead of 2 x 2 gathers per vertex, which
-// only pays while the pass is latency-bound: lattices of up to kPairMaxVertices vertices (measured at d = 8: 49 vs 52 us per
-// MVM at m = 4.0e5, 78 vs 74 us at m = 6.6e5).
-constexpr int kPairMaxVertices = 500000;
+// only pays while the pass is latency-bound: lattices of up to kPairMaxVertices vertices (measured at d = 8 under the Morton
+// vertex numbering, us per MVM with / without pairs: 94 / 99 at m = 4.0e5, 162 / 168 at m = 5.2e5 (N = 2e6), 286 / 286 at
+// m = 6.6e5 (N = 4e6), 124 / 116 at m = 7.9e5, 188 / 172 at m = 1.7e6).
+constexpr int kPairMaxVertices = 600000;
 int g_blur_fuse = 1;     // 0: one axis per launch; 1: axis pairs when order = 1, vd = 1 and m <= kPairMaxVertices; 2: whenever order = 1
 
 // slot = 3 * (b + 1) + (a + 1) without the centre (b = a = 0): 0..3 -> (b,a) = (-1,-1) (-1,0) (-1,+1) (0,-1); 4..7 -> (0,+1) (+1,-1) (+1,0) (+1,+1)
