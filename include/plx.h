@@ -176,7 +176,11 @@ int plx_apply(plx_lattice *lat, const float *d_src, int vd, float *d_out, void *
 /*
  * The reference's one-shot call (cpp:6-10 -> h:259-340): build a lattice for
  * d_ref, apply it to d_src, leave nothing behind.  `scratch` may be NULL or a
- * lattice object whose buffers are reused (avoids hipMalloc in steady state).
+ * lattice object whose buffers are reused (avoids hipMalloc in steady state; it
+ * is left built and usable).  The build knows it serves ONE MVM and leaves out
+ * the stages that only pay back over several (vertex renumbering, axis-pair
+ * tables of the blur): callers with more than a few MVMs per lattice use
+ * plx_build + plx_apply.
  */
 int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref,
                int64_t n, int d, int vd, const float *h_taps, int ntaps,

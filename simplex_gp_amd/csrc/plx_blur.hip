@@ -346,7 +346,7 @@ int build_blur_pairs(plx_lattice *L, hipStream_t stream)
     L->pairs_ready = false;
     const int d1 = L->d + 1, m = (int)L->m;
     if (g_blur_fuse == 0 || L->order != 1 || d1 < 2 || m == 0) return PLX_OK;
-    if (g_blur_fuse == 1 && m > kPairMaxVertices) return PLX_OK;
+    if (g_blur_fuse == 1 && (m > kPairMaxVertices || L->single_use)) return PLX_OK;
     PLX_TRY(ensure_blur_pairs(L, stream));
     L->use_pairs = true;
     return PLX_OK;
@@ -575,7 +575,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
     }
     float *cur = d_values, *nxt = d_scratch;
     bool paired = false;
-    const bool pair_vec = vd > 1 && order == 1 && g_blur_fuse_vec != 0 && g_blur_narrow && vdp / 4 >= 2 && vdp / 4 <= 4 &&
+    const bool pair_vec = vd > 1 && order == 1 && g_blur_fuse_vec != 0 && !(L->single_use && !L->pairs_ready) && g_blur_narrow && vdp / 4 >= 2 && vdp / 4 <= 4 &&
                           d1 >= 2 && m > 0 && (int64_t)8 * L->mstride < (1ll << 32);
     if (pair_vec) PLX_TRY(ensure_blur_pairs(L, stream));
     for (int axis = 0; axis < d1; ++axis) {

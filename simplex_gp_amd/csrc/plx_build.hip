@@ -764,7 +764,7 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
     const int m = (int)L->m;
     L->vertex_order = 0;
     if (g_vertex_order == 0 || m < 2) return PLX_OK;
-    if (g_vertex_order == 1 && (m < kMortonMinVertices || 10 * (int64_t)m > 9 * corners)) return PLX_OK;
+    if (g_vertex_order == 1 && (L->single_use || m < kMortonMinVertices || 10 * (int64_t)m > 9 * corners)) return PLX_OK;
     L->vertex_order = 1;
     int bits = 64 / D;
     if (bits > 8) bits = 8;

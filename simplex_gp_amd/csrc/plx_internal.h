@@ -52,6 +52,7 @@ struct plx_lattice {
     bool local_ready = false;    // plx_build_local done, waiting for plx_build_merge
     int vertex_order = 0;        // 0 first touch, 1 Morton order of the blur-axis coordinates (this build)
     int64_t merge_total_points = 0;   // plx_build_merge: points of all ranks (<= 0: unknown)
+    bool single_use = false;     // built by plx_filter for one MVM: no vertex renumbering, no axis-pair tables
     bool for_merge = false;      // the local stage of a sharded build is running (vertex renumbering waits for the merge)
     bool lattice_rows = false;   // d_src / d_out rows are in lattice order (plx_set_row_order)
     float build_ms[6] = {0, 0, 0, 0, 0, 0};

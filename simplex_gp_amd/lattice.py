@@ -93,6 +93,26 @@ class Lattice:
         self._own_begin = index * base + min(index, extra)
         return self
 
+    def filter_once(self, src, ref, coeffs, out=None):
+        """plx_filter on this lattice's buffers: build for `ref`, one MVM of `src`, in one native call.  The build knows
+        the lattice serves a single MVM and leaves out what only pays back over several (vertex renumbering, axis-pair
+        tables); the lattice stays usable afterwards like one built by build()."""
+        _check_f32_cuda(ref, "ref")
+        ref = ref.contiguous()
+        taps = _taps_array(coeffs)
+        n, d = ref.shape
+        src = self._src(src, n)
+        vd = src.shape[1]
+        if out is None:
+            out = torch.empty((n, vd), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_filter(self._h, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(ref.data_ptr()), n, d, vd,
+                                     taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), taps.size,
+                                     ctypes.c_void_p(out.data_ptr()), _stream_ptr(self.device))
+        nv.check(rc, "plx_filter")
+        self._ref, self.taps, self._perm_cache, self._own_begin = ref, taps, None, 0
+        return out
+
     # -- sharded build: local stage / key exchange / merge ---------------------
     def build_local(self, ref_local, coeffs):
         """Stage 1 of a sharded build: structure of this rank's own rows only.
@@ -381,6 +401,4 @@ def filter(src, ref, coeffs):
         raise ValueError("Incompatible shapes {}, and {}".format(tuple(src.shape), tuple(ref.shape)))
     if src.device != ref.device:
         raise ValueError("src and ref must be on the same device")
-    lat = _scratch_lattice(src.device)
-    lat.build(ref, coeffs)
-    return lat.apply(src)
+    return _scratch_lattice(src.device).filter_once(src, ref, coeffs)

@@ -628,3 +628,28 @@ def test_blur_axis_pairs_for_rows_equal_single_axis_passes(plx):
     finally:
         nv.check(lib.plx_tune(b"blur_fuse_vec", 1), "plx_tune")
         nv.check(lib.plx_tune(b"vertex_order", 1), "plx_tune")
+
+
+def test_one_shot_filter_skips_what_only_pays_over_many_mvms(plx):
+    """plx_filter (the reference's build-per-call contract) builds for a single MVM: no vertex renumbering, no axis-pair
+    tables; same output as build() + apply() to fp32 rounding, and the lattice it leaves behind is a normal one."""
+    rng = np.random.default_rng(5)
+    n, d = 300000, 8
+    ref = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    for vd in (1, 6):
+        src = torch.from_numpy(rng.standard_normal((n, vd)).astype(np.float32)).cuda()
+        many = plx.Lattice().build(ref, taps)
+        want = many.apply(src)
+        assert many.m >= 65536 and many.stage_kernels()["vertex_order"] == ["morton"]
+        once = plx.Lattice()
+        got = once.filter_once(src, ref, taps)
+        names = once.stage_kernels()
+        assert names["vertex_order"] == ["first_touch"]
+        assert not any("pair" in k for k in names["blur_axis"]), names
+        assert rel_l2(got.cpu().numpy(), want.cpu().numpy()) <= 1e-6
+        assert rel_l2(once.apply(src).cpu().numpy(), want.cpu().numpy()) <= 1e-6     # still a usable lattice
+        assert rel_l2(plx.filter(src, ref, torch.from_numpy(taps)).cpu().numpy(), want.cpu().numpy()) <= 1e-6
+        once.build(ref, taps)                                                          # and build() resets the mode
+        assert once.stage_kernels()["vertex_order"] == ["morton"]
+        many.close(); once.close()
