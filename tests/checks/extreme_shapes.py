@@ -13,6 +13,15 @@ for (n, d, vd, order) in [(500, 32, 1, 1), (500, 32, 5, 2), (2000, 25, 3, 3), (3
     taps = np.concatenate([half, [1.0], half[::-1]]).astype(np.float32)
     try:
         got = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), torch.from_numpy(taps)).cpu().numpy()
+        # the many-MVM build with the Morton vertex numbering forced (2 code bits per coordinate at d = 32)
+        from simplex_gp_amd import _native as nv
+        nv.check(nv.lib().plx_tune(b"vertex_order", 2), "plx_tune")
+        lat = plx.Lattice().build(torch.from_numpy(ref).cuda(), taps)
+        got2 = lat.apply(torch.from_numpy(src).cuda()).cpu().numpy()
+        assert lat.stage_kernels()["vertex_order"] == ["morton"] or lat.m < 2
+        lat.close()
+        nv.check(nv.lib().plx_tune(b"vertex_order", 1), "plx_tune")
+        assert np.linalg.norm(got2.astype(np.float64) - got) <= 2e-6 * np.linalg.norm(got), "Morton numbering changed the result"
     except Exception as e:
         print((n, d, vd, order), "HIP raised:", type(e).__name__, str(e)[:120]); continue
     try:

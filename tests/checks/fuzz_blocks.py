@@ -40,6 +40,7 @@ for c in range(cases):
     nv.check(lib.plx_tune(b"block_path", 2), "plx_tune")
     nv.check(lib.plx_tune(b"blur_fuse", 2 if c % 2 else 1), "plx_tune")
     nv.check(lib.plx_tune(b"unpermute_gather", c % 3 != 0), "plx_tune")
+    nv.check(lib.plx_tune(b"vertex_order", 2 if c % 4 < 2 else 0), "plx_tune")
     lat = plx.Lattice().build(x, taps)
     used = lat.block_rows > 0
     out = lat.apply(s)
@@ -73,4 +74,5 @@ for c in range(cases):
     if c % 25 == 0:
         print(f"case {c}: n={n} d={d} order={order} scale={scale} {kind} blocks={used} worst so far {worst[0]:.2e}", flush=True)
 nv.check(lib.plx_tune(b"block_path", 1), "plx_tune")
+nv.check(lib.plx_tune(b"vertex_order", 1), "plx_tune")
 print("OK", cases, "cases; worst", worst)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Wide randomised comparison of the HIP filter against the CPU oracle (duplicate-free mode): shapes up to n = 6000,
 d = 12, column counts that hit every splat / blur / slice kernel, all tap orders, degenerate clouds, with the compacted
-neighbour table forced on a third of the cases.  Prints the worst relative L2 error; exits 1 above 5e-5."""
+neighbour table forced on a third of the cases; odd cases go through build() + apply() with the Morton vertex numbering
+and both two-axes-per-launch blurs forced on, even ones through the one-shot plx_filter (first-touch numbering).  Prints the worst relative L2 error; exits 1 above 5e-5."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -35,7 +36,16 @@ for c in range(cases):
     src = rng.standard_normal((n, vd)).astype(np.float32)
     taps = np.array([0.1, 0.3, 0.6, 1.0, 0.6, 0.3, 0.1][3 - order: 4 + order], np.float32)
     nv.check(nv.lib().plx_tune(b"compact_nbr", 2 if c % 3 == 0 else 1), "plx_tune")
-    out = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), taps).cpu().numpy()
+    if c % 2:
+        nv.check(nv.lib().plx_tune(b"vertex_order", 2), "plx_tune")
+        nv.check(nv.lib().plx_tune(b"blur_fuse", 2), "plx_tune")
+        lat = plx.Lattice().build(torch.from_numpy(ref).cuda(), taps)
+        out = lat.apply(torch.from_numpy(src).cuda()).cpu().numpy()
+        lat.close()
+        nv.check(nv.lib().plx_tune(b"vertex_order", 1), "plx_tune")
+        nv.check(nv.lib().plx_tune(b"blur_fuse", 1), "plx_tune")
+    else:
+        out = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), taps).cpu().numpy()
     want = oracle.filter(src, ref, taps)
     err = float(np.linalg.norm(out.astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20))
     if err > worst[0]:
