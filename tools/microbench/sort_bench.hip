@@ -38,10 +38,28 @@ static int run(const char *name, size_t n, int end_bit, hipStream_t s)
     return 0;
 }
 
+template <unsigned B, unsigned I, unsigned R>
+using OS = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                      rocprim::radix_sort_onesweep_config<rocprim::kernel_config<B, I>, rocprim::kernel_config<B, I>, R,
+                                                                          rocprim::block_radix_rank_algorithm::match>, 0>;
+
 int main()
 {
     hipStream_t s; CK(hipStreamCreate(&s));
-    for (size_t n : {400000ul, 1000000ul, 2770000ul}) {
+    // wider digits: fewer passes
+    for (size_t n : {2770000ul, 5200000ul}) {
+        if (run<uint32_t, OS<256, 12, 10>>("os256x12r10", n, 19, s)) return 1;
+        if (run<uint32_t, OS<512, 8, 10>>("os512x8r10", n, 19, s)) return 1;
+        if (run<uint32_t, OS<1024, 4, 10>>("os1024x4r10", n, 19, s)) return 1;
+        if (run<uint32_t, OS<256, 16, 7>>("os256x16r7", n, 19, s)) return 1;
+        if (run<uint32_t, OS<512, 12, 10>>("os512x12r10", n, 20, s)) return 1;
+    }
+    for (size_t n : {400000ul, 1000000ul}) {
+        if (run<uint64_t, OS<256, 12, 10>>("os256x12r10", n, 60, s)) return 1;
+        if (run<uint64_t, OS<512, 8, 10>>("os512x8r10", n, 40, s)) return 1;
+        if (run<uint64_t, OS<256, 8, 9>>("os256x8r9", n, 63, s)) return 1;
+    }
+    if (0) for (size_t n : {400000ul, 1000000ul, 2770000ul}) {
         for (int bits : {64, 48, 40, 32}) {
             if (run<uint64_t, rocprim::default_config>("default", n, bits, s)) return 1;
             if (run<uint64_t, Force>("onesweep", n, bits, s)) return 1;
