@@ -1065,7 +1065,6 @@ template <int D>
 static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
 {
     constexpr int D1 = D + 1;
-    const int n = (int)L->n;
     const int n_own = (int)(L->own_end - L->own_begin);
     const int m = (int)L->m;
     const int order = L->order;
