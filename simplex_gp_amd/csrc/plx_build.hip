@@ -33,6 +33,7 @@
 // boundary pick a different simplex.
 
 #include "plx_internal.h"
+#include "plx_kernels.h"
 
 #include <math.h>
 
@@ -337,12 +338,14 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__
 template <int D>
 __global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restrict__ ekeys, int n,
                                                         uint32_t *__restrict__ table, uint32_t mask,
-                                                        uint32_t *__restrict__ eslot, int dedupe)
+                                                        uint32_t *__restrict__ eslot, int dedupe, int plane_fast)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const int r = blockIdx.y;
+    // plane_fast: the d+1 corner planes of one run of 256 points are adjacent in dispatch order, so that the workgroups
+    // run roughly in entry order e = p (d+1) + r and a later corner usually finds the smaller entry already in place
+    const int p = (plane_fast ? blockIdx.y : blockIdx.x) * kBlock + threadIdx.x;
+    const int r = plane_fast ? blockIdx.x : blockIdx.y;
     const int lane = threadIdx.x & 63;
     const bool valid = p < n;
     const size_t idx = (size_t)r * n + (valid ? p : 0);
@@ -488,12 +491,12 @@ template <int D, bool SYMMETRIC>
 __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__restrict__ vkeys, int m,
                                                           int64_t mstride, int order,
                                                           const uint32_t *__restrict__ table,
-                                                          uint32_t mask, int *__restrict__ nbr)
+                                                          uint32_t mask, int *__restrict__ nbr, int plane_fast)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int axis = blockIdx.y;
+    const int i = (plane_fast ? blockIdx.y : blockIdx.x) * kBlock + threadIdx.x;
+    const int axis = plane_fast ? blockIdx.x : blockIdx.y;
     if (i >= m) return;
     uint32_t kw[DW];
     load_key<DW>(vkeys, (size_t)i, kw);
@@ -702,6 +705,17 @@ static float taps_variance(const float *c, int R)
 // l = 0.3 307 -> 357, l = 0.25 280 -> 346: where nearly every corner has a vertex of its own (m > 0.9 nnz) the blur has
 // few neighbours to find and splat / slice lose the point-order locality of first touch, so those keep first touch.
 // Cost: one 64-bit sort of m codes + two passes over the keys, +0.1 ms of 1.25 (l = 1.0), +0.24 of 1.9 (l = 0.69).
+// Dispatch order of the per-plane kernels.  1: the d+1 corner planes of one run of 256 points (insert) / one run of 256
+// vertices (neighbours) are adjacent workgroups, so the workgroups that meet at a table slot run close together in time:
+// a later corner finds the entry, its key and usually the smaller index already in the L2s, and the atomicMin that the
+// plane-major order needs for most shared vertices (plane 0 of a later point runs long before plane 5 of an earlier
+// one) becomes rare.  N = 1e6, d = 8, l = 1: insert 335 -> 215 us, neighbours 93 -> 84 us (build 1.37 -> 1.25 ms);
+// l = 0.69: build 2.15 -> 2.05 ms; l = 0.25: 4.94 -> 4.91 ms.  The id lookup (ids_kernel) is faster plane-major (35 vs
+// 41 us) and stays so.  Giving every XCD one contiguous eighth of the (point block, plane) pairs instead: no better
+// (1.275 ms).  With only the first corner of every vertex per 256-point block probing (a workgroup-level LDS
+// de-duplication would achieve that) the plane-major insert took 219 us, with only the 4e5 first-touch corners 67 us:
+// the duplicate lookups are what costs, and time locality removes most of that without the LDS stage.
+int g_insert_plane_fast = 1;
 int g_vertex_order = 1;      // 0: first touch; 1: Morton order where it pays (kMortonMinVertices <= m <= 0.9 corners); 2: always
 constexpr int kMortonMinVertices = 65536;
 
@@ -865,9 +879,10 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, L->perm.as<uint32_t>(), n, sf, L->ekeys.as<uint32_t>(),
                                                     L->ew.as<float>(), L->counters.as<int>());
     mark();
-    insert_kernel<D><<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->ekeys.as<uint32_t>(), n,
-                                                                L->table.as<uint32_t>(), L->table_mask,
-                                                                L->eslot.as<uint32_t>(), g_insert_dedupe);
+    const int plane_fast = (g_insert_plane_fast != 0 && nblocks <= 65535) ? 1 : 0;
+    insert_kernel<D><<<plane_fast ? dim3(D1, nblocks) : dim3(nblocks, D1), kBlock, 0, stream>>>(
+        L->ekeys.as<uint32_t>(), n, L->table.as<uint32_t>(), L->table_mask, L->eslot.as<uint32_t>(), g_insert_dedupe,
+        plane_fast);
     mark();
     flag_kernel<<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n, D1,
                                                 L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
@@ -887,8 +902,7 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
                                                      L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>());
     if (!L->for_merge) PLX_TRY(renumber_vertices<D>(L, E, stream));   // (a job built from local rows renumbers the union, after the merge)
     mark();
-    ids_kernel<<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
-                                                         L->evid.as<int>());
+    ids_kernel<<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n, L->evid.as<int>());
     mark();
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -1076,16 +1090,18 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     PLX_TRY(ensure(L->nbr, (size_t)D1 * 2 * order * L->mstride * 4 + 4));
 
     if (order > 0) {
+        const int nplane_fast = (g_insert_plane_fast != 0 && ceil_div(m, kBlock) <= 65535) ? 1 : 0;
         dim3 ngrid(ceil_div(m, kBlock), D1);
+        if (nplane_fast) ngrid = dim3(D1, ceil_div(m, kBlock));
         if (g_nbr_symmetric) {
             PLX_HIP_TRY(hipMemsetAsync(L->nbr.p, 0xFF, (size_t)D1 * 2 * order * L->mstride * 4, stream));
             neighbor_kernel<D, true><<<ngrid, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, L->mstride, order,
                                                                     L->table.as<uint32_t>(), L->table_mask,
-                                                                    L->nbr.as<int>());
+                                                                    L->nbr.as<int>(), nplane_fast);
         } else {
             neighbor_kernel<D, false><<<ngrid, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, L->mstride, order,
                                                                      L->table.as<uint32_t>(), L->table_mask,
-                                                                     L->nbr.as<int>());
+                                                                     L->nbr.as<int>(), nplane_fast);
         }
     }
     PLX_TRY(build_blur_pairs(L, stream));      // composite neighbours for the two-axes-per-launch blur (coarse lattices)

@@ -39,6 +39,7 @@ extern int g_blur_ablate;
 extern int g_sort_points;
 extern int g_order_zcurve;
 extern int g_vertex_order;
+extern int g_insert_plane_fast;
 extern int g_compact_nbr;
 extern int g_insert_dedupe;
 extern int g_nbr_symmetric;
