@@ -1105,11 +1105,15 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         }
     }
     PLX_TRY(build_blur_pairs(L, stream));      // composite neighbours for the two-axes-per-launch blur (coarse lattices)
-    // compacted copy for sparse lattices (used by the vd = 1 blur when under half the neighbours exist)
+    // compacted copy for sparse lattices (used by the vd = 1 blur when under a quarter of the neighbours exist)
     // Neighbourhoods are only sparse when most corners created a vertex of their own (measured: m/E = 0.19 ->
-    // 57 % of the slots exist, 0.8 -> ~30 %, 0.99 -> 12 %), so the count + host sync is skipped for denser lattices.
+    // 57 % of the slots exist, 0.8 -> ~30 %, 0.91 -> ~20 %, 0.99 -> 12 %), so the count + host sync is skipped for
+    // denser lattices.  What the copy buys per MVM against what it costs per build (N = 1e6, d = 8): l = 0.5 / 0.4
+    // (m/E 0.53 / 0.80) nothing for 0.4-0.5 ms; l = 0.35 (0.91) 10 us for 0.52 ms; l = 0.3 / 0.25 / 0.2 (>= 0.97) 20 / 19 /
+    // 26 us for 0.56 ms, i.e. it pays from ~28 MVMs per build on: built for m/E >= 0.85 and fill < 0.25, and never for a
+    // lattice that serves one MVM (plx_filter).
     L->use_compact = false;
-    const bool maybe_sparse = g_compact_nbr == 2 || (double)m >= 0.4 * (double)L->n * D1;
+    const bool maybe_sparse = g_compact_nbr == 2 || ((double)m >= 0.85 * (double)L->n * D1 && !L->single_use);
     if (order >= 1 && order <= 3 && g_compact_nbr != 0 && maybe_sparse) {
         const int taps2 = 2 * order;
         L->nquads = ((int64_t)m + 3) / 4;
@@ -1127,7 +1131,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         for (int a = 0; a < D1; ++a) { ao.off[a] = total; L->compact_off[a] = total; total += L->h_pinned[2 + a]; }
         L->compact_off[D1] = total;
         const double fill = (double)total / ((double)m * taps2 * D1);
-        if (g_compact_nbr == 2 || fill < 0.5) {
+        if (g_compact_nbr == 2 || fill < 0.25) {
             PLX_TRY(ensure(L->cids, (size_t)total * 4 + 64));
             compact_fill_kernel<<<cgrid, kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, taps2, L->nquads,
                                                               L->nqwaves, L->cmask.as<uint32_t>(),
