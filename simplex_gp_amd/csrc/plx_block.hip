@@ -191,6 +191,7 @@ __global__ __launch_bounds__(T) void splat_block_kernel(const uint16_t *__restri
     const int p0 = b * P, np = min(P, n_own - p0);
     const int k0 = b * cpb, nc = min(cpb, nnz - k0);
     const int kb = tid * E;
+    const int base = brow_ptr[b], rows = brow_ptr[b + 1] - base;   // needed last: loaded first, off the critical path
 
     // corner records first: their latency overlaps the window gather below
     uint32_t ptw[E / 2];
@@ -272,7 +273,6 @@ __global__ __launch_bounds__(T) void splat_block_kernel(const uint16_t *__restri
         if (end) { rowsum[r++] = run; run = 0.f; }
     }
     __syncthreads();
-    const int base = brow_ptr[b], rows = brow_ptr[b + 1] - base;
     for (int j = tid; j < rows; j += T) partial[base + j] = rowsum[j];
 }
 
