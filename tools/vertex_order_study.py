@@ -28,11 +28,47 @@ for b in range(bits - 1, -1, -1):
         code = (code << np.uint64(1)) | ((a[:, i] >> b) & 1).astype(np.uint64)
 order = np.argsort(code, kind="stable")
 rank_morton = np.empty(m, np.int64); rank_morton[order] = np.arange(m)
+
+
+def hilbert_code(a, bits):
+    """Skilling's axes-to-transpose (Hilbert curve index) for the rows of a [m, d] non-negative int array."""
+    X = [a[:, i].astype(np.int64).copy() for i in range(a.shape[1])]
+    nd = len(X)
+    M = 1 << (bits - 1)
+    Q = M
+    while Q > 1:
+        P = Q - 1
+        for i in range(nd):
+            hit = (X[i] & Q) != 0
+            X[0] = np.where(hit, X[0] ^ P, X[0])
+            t = np.where(hit, 0, (X[0] ^ X[i]) & P)
+            X[0] ^= t
+            X[i] ^= t
+        Q >>= 1
+    for i in range(1, nd):
+        X[i] ^= X[i - 1]
+    t = np.zeros_like(X[0])
+    Q = M
+    while Q > 1:
+        t = np.where((X[nd - 1] & Q) != 0, t ^ (Q - 1), t)
+        Q >>= 1
+    for i in range(nd):
+        X[i] ^= t
+    h = np.zeros(a.shape[0], np.uint64)
+    for b in range(bits - 1, -1, -1):
+        for i in range(nd):
+            h = (h << np.uint64(1)) | ((X[i] >> b) & 1).astype(np.uint64)
+    return h
+
+
+horder = np.argsort(hilbert_code(a, bits), kind="stable")
+rank_hilbert = np.empty(m, np.int64); rank_hilbert[horder] = np.arange(m)
 # plain lexicographic order of a for comparison
 lex = np.lexsort(tuple(a[:, i] for i in range(d - 1, -1, -1)))
 rank_lex = np.empty(m, np.int64); rank_lex[lex] = np.arange(m)
 print(f"ell={ell} m={m} bits/coord={bits}")
-for name, rank in (("current (first touch)", np.arange(m)), ("morton(axis basis)", rank_morton), ("lexicographic(axis basis)", rank_lex)):
+for name, rank in (("current (first touch)", np.arange(m)), ("morton(axis basis)", rank_morton), ("hilbert(axis basis)", rank_hilbert),
+                   ("lexicographic(axis basis)", rank_lex)):
     rows = []
     for axis in range(d + 1):
         nb = nbr[axis].reshape(-1)
