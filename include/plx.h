@@ -251,8 +251,9 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  * caller's point order), "order_zcurve" (1; 0 = lexicographic point order, 2 = Z-curve of the
  * blur-axis coordinates), "blur_fuse_vec" (1 = two blur axes per launch for rows of 2..4 chunks; 0 = one), "vertex_order" (1: vertices numbered along
  * the Morton curve of their blur-axis coordinates where that pays, 65536 <= m <= 0.9 n (d+1); 0: always by first touch;
- * 2: always Morton -- vertex ids are internal, the PLX_ARRAY_* exports are in whichever numbering the build used), "insert_dedupe" (1), "nbr_symmetric" (1),
- * "compact_nbr" (1 = when under half of the neighbour slots exist; 0 never, 2 always), "blur_vpt" (4; vertices per
+ * 2: always Morton -- vertex ids are internal, the PLX_ARRAY_* exports are in whichever numbering the build used), "insert_dedupe" (1), "insert_plane_fast" (1 = the d+1 corner planes of a run of points are adjacent workgroups of the
+ * hashed insert / neighbour lookups; 0 = plane-major launch order), "nbr_symmetric" (1),
+ * "compact_nbr" (1 = when under a quarter of the neighbour slots exist; 0 never, 2 always), "blur_vpt" (4; vertices per
  * thread at vd = 1: 2 or 4, anything else selects the general kernel), "blur_small" (1), "blur_narrow" (1),
  * "blur_multi" (1), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1), "block_path" (1 = block
  * tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable), "block_threads" (1024; or 512), and the diagnostic
