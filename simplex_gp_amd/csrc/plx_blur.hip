@@ -265,7 +265,8 @@ __global__ __launch_bounds__(kBlock) void blur_pair_v1_kernel(const float *__res
 // the row: a pair launch moves 32 B of ids + one row read + one row written per vertex where two single passes move
 // 2 x (8 B + row + row), 128 against 208 bytes at vd = 12, and the 8 gathered rows come from the L2 / MALL like the
 // 2 x 2 of the single passes (they are near in id since the vertices are numbered along the Morton curve of the axis
-// coordinates).  Same operations in the same order as two blur_axis_narrow_kernel launches.
+// coordinates).  Same operations in the same order as two blur_axis_narrow_kernel launches.  (Two items per thread,
+// kBlock apart, all loads first: 77 us against 59 us per launch at m = 1.73e6, vd = 12 -- occupancy, not latency.)
 int g_blur_fuse_vec = 1;   // 0: one axis per launch for vd > 1; 1: axis pairs when order = 1 and the row has 2..4 chunks
 
 template <int ROWLEN>
