@@ -119,15 +119,28 @@ __global__ __launch_bounds__(kBlock) void slice_vec_kernel(const int *__restrict
         }
     }
     if (dot_partial) {
-        // one partial sum per (workgroup, column), added in thread order: reproducible
+        // one partial sum per (workgroup, column), in a fixed order: reproducible.  Two steps: K threads per column sum
+        // every K-th term of that column (a single thread per column walked all kBlock / nch terms through LDS: 85
+        // dependent reads with 12 lanes busy while the workgroup's other waves held their registers), then one thread
+        // per column adds the K partial sums in order.
+        __shared__ float part[kBlock];
         red[threadIdx.x] = prod;
         __syncthreads();
-        if ((int)threadIdx.x < 4 * nch) {
-            const int ch = threadIdx.x >> 2, j = threadIdx.x & 3;
-            const int base = (int)(((int64_t)tile * kBlock) % nch);      // chunk index of thread 0
+        const int cols = 4 * nch;                                        // <= 64 for the kernels that use this path
+        const int K = kBlock / cols;                                     // >= 4
+        const int base = (int)(((int64_t)tile * kBlock) % nch);          // chunk index of thread 0
+        if ((int)threadIdx.x < cols * K) {
+            const int col = threadIdx.x % cols, k = threadIdx.x / cols;
+            const int ch = col >> 2, j = col & 3;
             float s = 0.f;
-            for (int t = (ch - base + nch) % nch; t < kBlock; t += nch) s += reinterpret_cast<const float *>(&red[t])[j];
-            dot_partial[(size_t)tile * (4 * nch) + threadIdx.x] = s;
+            for (int t = (ch - base + nch) % nch + k * nch; t < kBlock; t += K * nch) s += reinterpret_cast<const float *>(&red[t])[j];
+            part[k * cols + col] = s;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < cols) {
+            float s = 0.f;
+            for (int k = 0; k < K; ++k) s += part[k * cols + threadIdx.x];
+            dot_partial[(size_t)tile * cols + threadIdx.x] = s;
         }
     }
 }
