@@ -170,6 +170,43 @@ __global__ __launch_bounds__(kBlock) void cg_step_direction_kernel(float *__rest
     }
 }
 
+// the same four elements per thread (16-byte loads / stores; total a multiple of 4, P and R 16-byte aligned)
+__global__ __launch_bounds__(kBlock) void cg_step_direction4_kernel(float4 *__restrict__ P, const float4 *__restrict__ R,
+                                                                    const float *__restrict__ rs_new,
+                                                                    const float *__restrict__ rs,
+                                                                    const float *__restrict__ active,
+                                                                    const float *__restrict__ b_norm, float tol,
+                                                                    int64_t quads, int vd, float *__restrict__ beta_out,
+                                                                    float *__restrict__ active_out)
+{
+    __shared__ float sbeta[kBlock];
+    if ((int)threadIdx.x < vd) {
+        const int c = threadIdx.x;
+        sbeta[c] = active[c] > 0.f ? rs_new[c] / fmaxf(rs[c], 1e-30f) : 0.f;
+    }
+    __syncthreads();
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (q < quads) {
+        const uint32_t uvd = (uint32_t)vd;
+        // column of element 4 q = 4 (blockIdx kBlock + tid) mod vd, from 32-bit residues
+        const uint32_t bm = ((blockIdx.x % uvd) * ((4u * (uint32_t)kBlock) % uvd)) % uvd;      // wave-uniform
+        uint32_t c = (bm + 4u * threadIdx.x) % uvd;
+        const float4 r = R[q];
+        float4 p = P[q];
+        p.x = r.x + p.x * sbeta[c]; c = c + 1 == uvd ? 0 : c + 1;
+        p.y = r.y + p.y * sbeta[c]; c = c + 1 == uvd ? 0 : c + 1;
+        p.z = r.z + p.z * sbeta[c]; c = c + 1 == uvd ? 0 : c + 1;
+        p.w = r.w + p.w * sbeta[c];
+        P[q] = p;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < vd) {
+        const int c = threadIdx.x;
+        const bool on = active[c] > 0.f;
+        beta_out[c] = on ? rs_new[c] / fmaxf(rs[c], 1e-30f) : 0.f;
+        active_out[c] = (on && sqrtf(rs_new[c]) / b_norm[c] > tol) ? 1.f : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void cg_direction_kernel(float *__restrict__ P, const float *__restrict__ R,
                                                               const float *__restrict__ beta, int64_t total, int vd)
 {
@@ -301,6 +338,14 @@ extern "C" int plx_cg_step_direction(float *d_p, const float *d_r, const float *
     if (d_active == d_active_out) { set_error("plx_cg_step_direction: active and active_out must be different buffers"); return PLX_ERR_INVALID; }
     if (n < 0 || vd < 1 || vd > kBlock) { set_error("plx_cg_step_direction: vd = %d outside 1..%d", vd, kBlock); return PLX_ERR_INVALID; }
     const int64_t total = n * vd;
+    if (total > 0 && (total & 3) == 0 && ((reinterpret_cast<uintptr_t>(d_p) | reinterpret_cast<uintptr_t>(d_r)) & 15) == 0) {
+        const int64_t quads = total / 4;
+        cg_step_direction4_kernel<<<ceil_div(quads, kBlock), kBlock, 0, (hipStream_t)stream>>>(
+            reinterpret_cast<float4 *>(d_p), reinterpret_cast<const float4 *>(d_r), d_rs_new, d_rs, d_active, d_b_norm, tol,
+            quads, vd, d_beta, d_active_out);
+        PLX_HIP_TRY(hipGetLastError());
+        return PLX_OK;
+    }
     const int grid = total > 0 ? ceil_div(total, kBlock) : 1;
     cg_step_direction_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(d_p, d_r, d_rs_new, d_rs, d_active, d_b_norm, tol, total,
                                                                      vd, d_beta, d_active_out);
