@@ -79,3 +79,14 @@ for name, rank in (("current (first touch)", np.arange(m)), ("morton(axis basis)
     rows = np.array(rows)
     print(f"{name:28s} share of neighbours farther than 1k/32k/87k/262k/1M ids (mean over axes): "
           + " ".join(f"{v:.3f}" for v in rows[:, :5].mean(0)) + f"   median distance per axis: {rows[:, 5].astype(int).tolist()}")
+
+# share of existing neighbours that fall into the same tile of T consecutive ids as their vertex (per axis, current ids):
+# what an LDS-staged tile of rows would serve without a global gather
+for T in (256, 512, 1024, 2048, 4096):
+    shares = []
+    for axis in range(d + 1):
+        nb = nbr[axis].reshape(-1)
+        src = np.tile(np.arange(m), 2)
+        ok = nb >= 0
+        shares.append(float((nb[ok] // T == src[ok] // T).mean()))
+    print(f"tile {T:5d}: in-tile share per axis " + " ".join(f"{v:.2f}" for v in shares))
