@@ -206,3 +206,31 @@ def test_bench_self_launches_its_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode == 2
+
+
+def test_bench_single_gpu_json_contract():
+    """`python bench.py --steps K --warmup W` (the driver's N = 1 command): ONE JSON line with the contract keys, the
+    roofline object of the dominant stage (algorithmic bytes over a launch time measured in this run, PMC traffic from
+    the committed profile) and the CPU baseline of the reference path on this host."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--skip-configs", "--skip-fine"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    res = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in res, key
+    assert res["n_gpus"] == 1 and res["steps"] == 10 and res["warmup"] == 2 and res["higher_is_better"] is True
+    assert res["dtype"] == "f32" and res["data"] == "synthetic" and res["vs_baseline"] is None
+    assert "workload" in res["config"] and "model" not in res["config"]
+    assert res["value"] > 0 and abs(res["value"] * res["ms_per_step"] / 1e3 - 1.0) < 0.02      # value = steps / time
+    roof = res["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.0 < roof["frac"] < 1.0
+    assert abs(roof["achieved"] - roof["bytes_per_launch"] / (roof["launch_us"] * 1e-6) / 1e9) < 0.02 * roof["achieved"]
+    assert roof["traffic"] is None or roof["traffic"] > 0.5 * roof["bytes_per_launch"]
+    cpu = res["cpu_baseline"]
+    assert cpu["kind"] in ("reference", "port") and cpu["cores"] == 1 and cpu["value"] > 0 and cpu["sample"]
+    assert res["config"]["builds_in_timed_region"] == 1
