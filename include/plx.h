@@ -266,8 +266,11 @@ int plx_tune(const char *key, int value);
 int plx_last_kernels(const plx_lattice *lat, char *buf, int cap);
 /* Block rows of the lattice's block tables (the single-column splat / slice path of coarse lattices: owned points
  * are cut into blocks, a block row = one distinct vertex of one block), or 0 when the lattice uses the
- * vertex-sorted CSR path instead. */
-int64_t plx_block_rows(const plx_lattice *lat);
+ * vertex-sorted CSR path instead.  The block tables serve single-column MVMs only: a build on a lattice object whose
+ * previous lattice served multi-column MVMs and no single-column one (a training loop), and a plx_filter call with
+ * vd > 1, leave them to their first user -- the first single-column plx_splat / plx_slice / plx_apply, or this call
+ * (which then builds them on the legacy stream and waits). */
+int64_t plx_block_rows(plx_lattice *lat);
 
 /* Per-stage device time of the last plx_build on this lattice, in ms, in the
  * order {order+embed, insert, number, ids, neighbours, csr}; 0 when timing is off.

@@ -542,11 +542,19 @@ int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStr
     return PLX_OK;
 }
 
+int ensure_blocks(plx_lattice *L, hipStream_t stream)
+{
+    if (L->blocks_ready) return PLX_OK;
+    PLX_TRY(build_blocks(L, stream));
+    return PLX_OK;
+}
+
 // ----------------------------------------------------------------------------
 // Block tables for the owned points of a built lattice (evid / ew / perm final).  Leaves L->use_blocks.
 int build_blocks(plx_lattice *L, hipStream_t stream)
 {
     L->use_blocks = false;
+    L->blocks_ready = true;
     const int d1 = L->d + 1;
     const int n = (int)L->n, n_own = (int)(L->own_end - L->own_begin);
     const int64_t nnz = L->nnz, m = L->m;

@@ -1145,8 +1145,12 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     // corners share vertices (plx_block.hip); the vertex-sorted CSR of the other kernels is built on first use
     // (ensure_csr), or right away when there are no block tables
     L->csr_ready = false;
-    PLX_TRY(build_blocks(L, stream));
-    if (!L->use_blocks) PLX_TRY(ensure_csr(L, stream));
+    L->blocks_ready = false;
+    L->use_blocks = false;
+    if (!L->defer_blocks) {
+        PLX_TRY(build_blocks(L, stream));
+        if (!L->use_blocks) PLX_TRY(ensure_csr(L, stream));
+    }
     mark();
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;

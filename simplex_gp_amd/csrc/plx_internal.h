@@ -116,6 +116,12 @@ struct plx_lattice {
     // block tables (plx_block.hip): vd = 1 splat / slice on lattices whose corners share vertices.  The owned
     // points, in lattice order, are cut into blocks of blk_P points; a block's corners are sorted by vertex.
     bool use_blocks = false;
+    // The block tables serve single-column MVMs only.  A lattice object whose previous build served multi-column MVMs
+    // and no single-column one (every step of a training loop: build, CG on [y | probes], backward) skips them at the
+    // next build; whoever needs them first builds them then (ensure_blocks).
+    bool blocks_ready = false;   // build_blocks has run for the current build (use_blocks is decided)
+    bool blocks_used = false, multi_used = false;   // what the current build has served so far
+    bool defer_blocks = false;   // this build left the block tables to their first user
     int blk_P = 0, blk_T = 0, blk_cpb = 0;     // points per block, threads per block workgroup, corners per full block
     int blk_max_rows = 0;                      // most distinct vertices in one block (LDS rows of the slice kernel)
     int64_t nblocks = 0, n_brows = 0;          // blocks, block rows (sum over blocks of distinct vertices)
@@ -163,6 +169,7 @@ int export_row_ptr(plx_lattice *L, hipStream_t stream);   // fills L->row_ptr on
 int ensure_csr(plx_lattice *L, hipStream_t stream);       // vertex-sorted splat CSR of the current build, built once on demand
 // plx_block.hip (block tables + the vd = 1 kernels that use them)
 int build_blocks(plx_lattice *L, hipStream_t stream);
+int ensure_blocks(plx_lattice *L, hipStream_t stream);    // the block tables of the current build, if they were deferred
 int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);
 int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStream_t stream, const float *d_affine,
                      const float *d_src);

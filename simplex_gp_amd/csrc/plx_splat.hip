@@ -544,7 +544,13 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         tmark(L, stream);
         return PLX_OK;
     }
-    if (vd == 1 && L->use_blocks) return splat_block_impl(L, d_src, d_values, stream);
+    if (vd == 1) {
+        PLX_TRY(ensure_blocks(L, stream));
+        L->blocks_used = true;
+        if (L->use_blocks) return splat_block_impl(L, d_src, d_values, stream);
+    } else {
+        L->multi_used = true;
+    }
     PLX_TRY(ensure_csr(L, stream));
     const bool all_rows_touched = (L->n_shards == 1 && !L->partial_cover);
     if (!all_rows_touched) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));

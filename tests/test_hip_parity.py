@@ -653,3 +653,42 @@ def test_one_shot_filter_skips_what_only_pays_over_many_mvms(plx):
         once.build(ref, taps)                                                          # and build() resets the mode
         assert once.stage_kernels()["vertex_order"] == ["morton"]
         many.close(); once.close()
+
+
+def test_block_tables_are_left_to_their_first_user(plx):
+    """A lattice object that served only multi-column MVMs (a training loop: build, CG on [y | probes]) builds its next
+    lattice without the block tables; the first single-column MVM builds them then, with the same result as an eager
+    build.  One-shot multi-column filters skip them as well."""
+    rng = np.random.default_rng(23)
+    n, d = 200000, 8
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    x1 = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy((rng.standard_normal((n, d)) / 0.9).astype(np.float32)).cuda()
+    v1 = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).cuda()
+    v11 = torch.from_numpy(rng.standard_normal((n, 11)).astype(np.float32)).cuda()
+    fresh = plx.Lattice().build(x2, taps)
+    want1, want11 = fresh.apply(v1).clone(), fresh.apply(v11).clone()
+    assert fresh.block_rows > 0
+    lat = plx.Lattice()
+    lat.set_timing(True)
+    lat.build(x1, taps)
+    lat.build(x1, taps)                                # (the first build also allocates)
+    eager_ms = lat.build_times_ms()["csr"]
+    lat.apply(v11)                                     # multi-column use only
+    lat.build(x2, taps)                                # -> block tables deferred
+    deferred_ms = lat.build_times_ms()["csr"]
+    assert deferred_ms < 0.25 * eager_ms, (eager_ms, deferred_ms)
+    assert torch.equal(lat.apply(v11), want11)
+    out1 = lat.apply(v1)                               # first single-column MVM builds them
+    assert lat.stage_kernels()["splat"][0] == "splat_block_kernel" and lat.block_rows == fresh.block_rows
+    assert torch.equal(out1, want1)
+    lat.build(x2, taps)                                # the lattice served single-column MVMs: eager again
+    assert lat.build_times_ms()["csr"] > 0.5 * eager_ms
+    lat.set_timing(False)
+    # block_rows alone also triggers the deferred build
+    lat.apply(v11); lat.build(x2, taps); lat.apply(v11); lat.build(x2, taps)
+    assert lat.block_rows == fresh.block_rows and torch.equal(lat.apply(v1), want1)
+    # one-shot multi-column filter: result unchanged
+    assert torch.equal(plx.Lattice().filter_once(v11, x2, taps), want11) or \
+        rel_l2(plx.Lattice().filter_once(v11, x2, taps).cpu().numpy(), want11.cpu().numpy()) <= 1e-6
+    lat.close(); fresh.close()
