@@ -8,28 +8,29 @@ namespace plx {
 
 constexpr int kDotBlocks = 1024;
 
-// threads = (row lane, column lane), column fastest; CW = power of two >= vd
+// threads = (row lane, column lane), column fastest, vd lanes per row: a workgroup step covers kBlock / vd whole rows,
+// i.e. consecutive threads read consecutive floats (with a power-of-two lane count per row, 5 of 16 lanes idled at
+// vd = 11 and every row was its own 44-byte segment: cg_step_update 51-55 -> 49 us, 46 us being its streaming floor)
 __global__ __launch_bounds__(kBlock) void coldot_partial_kernel(const float *__restrict__ a,
                                                                 const float *__restrict__ b, int64_t n, int vd,
-                                                                int logcw, float *__restrict__ partial)
+                                                                int cw, float *__restrict__ partial)
 {
     __shared__ float red[kBlock];
-    const int cw = 1 << logcw;
-    const int c = threadIdx.x & (cw - 1);
-    const int rl = threadIdx.x >> logcw;
-    const int rows_per_step = kBlock >> logcw;
+    const int c = threadIdx.x % cw;
+    const int rl = threadIdx.x / cw;
+    const int rows_per_step = kBlock / cw;
     const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(r0 + rows_per_block, n);
     float acc = 0.f;
-    if (c < vd)
+    if (rl < rows_per_step)
         for (int64_t r = r0 + rl; r < r1; r += rows_per_step) acc += a[r * vd + c] * b[r * vd + c];
     red[threadIdx.x] = acc;
     __syncthreads();
     // fixed-order sum over the row lanes of each column
     if (rl == 0 && c < vd) {
         float s = 0.f;
-        for (int k = 0; k < rows_per_step; ++k) s += red[(k << logcw) + c];
+        for (int k = 0; k < rows_per_step; ++k) s += red[k * cw + c];
         partial[(size_t)blockIdx.x * vd + c] = s;
     }
 }
@@ -67,18 +68,17 @@ __global__ __launch_bounds__(kFinalBlock) void coldot_final_kernel(const float *
 __global__ __launch_bounds__(kBlock) void cg_update_kernel(float *__restrict__ X, float *__restrict__ R,
                                                            const float *__restrict__ P, const float *__restrict__ AP,
                                                            const float *__restrict__ alpha, int64_t n, int vd,
-                                                           int logcw, float *__restrict__ partial)
+                                                           int cw, float *__restrict__ partial)
 {
     __shared__ float red[kBlock];
-    const int cw = 1 << logcw;
-    const int c = threadIdx.x & (cw - 1);
-    const int rl = threadIdx.x >> logcw;
-    const int rows_per_step = kBlock >> logcw;
+    const int c = threadIdx.x % cw;
+    const int rl = threadIdx.x / cw;
+    const int rows_per_step = kBlock / cw;
     const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(r0 + rows_per_block, n);
     float acc = 0.f;
-    if (c < vd) {
+    if (rl < rows_per_step) {                            // (the last kBlock % vd threads have no row lane)
         const float a = alpha[c];
         for (int64_t r = r0 + rl; r < r1; r += rows_per_step) {
             const int64_t i = r * vd + c;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(float *__restrict__ X
     __syncthreads();
     if (rl == 0 && c < vd) {
         float s = 0.f;
-        for (int k = 0; k < rows_per_step; ++k) s += red[(k << logcw) + c];
+        for (int k = 0; k < rows_per_step; ++k) s += red[k * cw + c];
         partial[(size_t)blockIdx.x * vd + c] = s;
     }
 }
@@ -107,19 +107,18 @@ __global__ __launch_bounds__(kBlock) void cg_step_update_kernel(float *__restric
                                                                 const float *__restrict__ P, const float *__restrict__ AP,
                                                                 const float *__restrict__ rs, const float *__restrict__ pAp,
                                                                 const float *__restrict__ active, int64_t n, int vd,
-                                                                int logcw, float *__restrict__ partial,
+                                                                int cw, float *__restrict__ partial,
                                                                 float *__restrict__ alpha_out)
 {
     __shared__ float red[kBlock];
-    const int cw = 1 << logcw;
-    const int c = threadIdx.x & (cw - 1);
-    const int rl = threadIdx.x >> logcw;
-    const int rows_per_step = kBlock >> logcw;
+    const int c = threadIdx.x % cw;
+    const int rl = threadIdx.x / cw;
+    const int rows_per_step = kBlock / cw;
     const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(r0 + rows_per_block, n);
     float acc = 0.f;
-    if (c < vd) {
+    if (rl < rows_per_step) {                            // (the last kBlock % vd threads have no row lane)
         const float a = active[c] > 0.f ? rs[c] / fmaxf(pAp[c], 1e-30f) : 0.f;
         if (blockIdx.x == 0 && rl == 0) alpha_out[c] = a;
         for (int64_t r = r0 + rl; r < r1; r += rows_per_step) {
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_update_kernel(float *__restric
     __syncthreads();
     if (rl == 0 && c < vd) {
         float s = 0.f;
-        for (int k = 0; k < rows_per_step; ++k) s += red[(k << logcw) + c];
+        for (int k = 0; k < rows_per_step; ++k) s += red[k * cw + c];
         partial[(size_t)blockIdx.x * vd + c] = s;
     }
 }
@@ -300,10 +299,9 @@ extern "C" int plx_cg_update(float *d_x, float *d_r, const float *d_p, const flo
 {
     if (!d_x || !d_r || !d_p || !d_ap || !d_alpha || !d_rs_new || !d_work) { set_error("plx_cg_update: NULL argument"); return PLX_ERR_INVALID; }
     if (n < 0 || vd < 1 || vd > kBlock) { set_error("plx_cg_update: vd = %d outside 1..%d", vd, kBlock); return PLX_ERR_INVALID; }
-    int logcw = 0;
-    while ((1 << logcw) < vd) ++logcw;
+    const int cw = vd;      // lanes per row
     hipStream_t s = (hipStream_t)stream;
-    cg_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_alpha, n, vd, logcw, d_work);
+    cg_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_alpha, n, vd, cw, d_work);
     coldot_final_kernel<<<vd, kFinalBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -318,10 +316,9 @@ extern "C" int plx_cg_step_update(float *d_x, float *d_r, const float *d_p, cons
         return PLX_ERR_INVALID;
     }
     if (n < 0 || vd < 1 || vd > kBlock) { set_error("plx_cg_step_update: vd = %d outside 1..%d", vd, kBlock); return PLX_ERR_INVALID; }
-    int logcw = 0;
-    while ((1 << logcw) < vd) ++logcw;
+    const int cw = vd;      // lanes per row
     hipStream_t s = (hipStream_t)stream;
-    cg_step_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_rs, d_pap, d_active, n, vd, logcw, d_work, d_alpha);
+    cg_step_update_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_x, d_r, d_p, d_ap, d_rs, d_pap, d_active, n, vd, cw, d_work, d_alpha);
     coldot_final_kernel<<<vd, kFinalBlock, 0, s>>>(d_work, kDotBlocks, vd, d_rs_new);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -369,10 +366,9 @@ extern "C" int plx_coldot(const float *d_a, const float *d_b, int64_t n, int vd,
 {
     if (!d_a || !d_b || !d_out || !d_work) { set_error("plx_coldot: NULL argument"); return PLX_ERR_INVALID; }
     if (n < 0 || vd < 1 || vd > kBlock) { set_error("plx_coldot: vd = %d outside 1..%d", vd, kBlock); return PLX_ERR_INVALID; }
-    int logcw = 0;
-    while ((1 << logcw) < vd) ++logcw;
+    const int cw = vd;      // lanes per row
     hipStream_t s = (hipStream_t)stream;
-    coldot_partial_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_a, d_b, n, vd, logcw, d_work);
+    coldot_partial_kernel<<<kDotBlocks, kBlock, 0, s>>>(d_a, d_b, n, vd, cw, d_work);
     coldot_final_kernel<<<vd, kFinalBlock, 0, s>>>(d_work, kDotBlocks, vd, d_out);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
