@@ -269,7 +269,7 @@ int plx_last_kernels(const plx_lattice *lat, char *buf, int cap);
  * vertex-sorted CSR path instead.  The block tables serve single-column MVMs only: a build on a lattice object whose
  * previous lattice served multi-column MVMs and no single-column one (a training loop), and a plx_filter call with
  * vd > 1, leave them to their first user -- the first single-column plx_splat / plx_slice / plx_apply, or this call
- * (which then builds them on the legacy stream and waits). */
+ * (which then builds them on the stream of the last build and waits). */
 int64_t plx_block_rows(plx_lattice *lat);
 
 /* Per-stage device time of the last plx_build on this lattice, in ms, in the

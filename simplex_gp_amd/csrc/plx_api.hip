@@ -510,9 +510,9 @@ int plx_last_kernels(const plx_lattice *L, char *buf, int cap)
 int64_t plx_block_rows(plx_lattice *L)
 {
     if (!L || !L->built) return 0;
-    if (!L->blocks_ready) {                      // deferred at build time: decide now (legacy stream, synchronous)
+    if (!L->blocks_ready) {                      // deferred at build time: decide now, on the build's stream, and wait
         DeviceGuard g(L->device);
-        if (!g.ok || ensure_blocks(L, nullptr) != PLX_OK || hipStreamSynchronize(nullptr) != hipSuccess) return 0;
+        if (!g.ok || ensure_blocks(L, L->build_stream) != PLX_OK || hipStreamSynchronize(L->build_stream) != hipSuccess) return 0;
     }
     return L->use_blocks ? L->n_brows : 0;
 }

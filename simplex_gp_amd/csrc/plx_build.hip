@@ -1147,6 +1147,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     L->csr_ready = false;
     L->blocks_ready = false;
     L->use_blocks = false;
+    L->build_stream = stream;
     if (!L->defer_blocks) {
         PLX_TRY(build_blocks(L, stream));
         if (!L->use_blocks) PLX_TRY(ensure_csr(L, stream));

@@ -122,6 +122,7 @@ struct plx_lattice {
     bool blocks_ready = false;   // build_blocks has run for the current build (use_blocks is decided)
     bool blocks_used = false, multi_used = false;   // what the current build has served so far
     bool defer_blocks = false;   // this build left the block tables to their first user
+    hipStream_t build_stream = nullptr;   // stream of the last build (plx_block_rows builds deferred tables there)
     int blk_P = 0, blk_T = 0, blk_cpb = 0;     // points per block, threads per block workgroup, corners per full block
     int blk_max_rows = 0;                      // most distinct vertices in one block (LDS rows of the slice kernel)
     int64_t nblocks = 0, n_brows = 0;          // blocks, block rows (sum over blocks of distinct vertices)
