@@ -256,21 +256,25 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  * "compact_nbr" (1 = when under a quarter of the neighbour slots exist; 0 never, 2 always), "blur_vpt" (4; vertices per
  * thread at vd = 1: 2 or 4, anything else selects the general kernel), "blur_small" (1), "blur_narrow" (1),
  * "blur_multi" (1), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1), "block_path" (1 = block
- * tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable), "block_threads" (1024; or 512), and the diagnostic
- * "splat_ablate" / "blur_ablate" (0).  Unknown keys return PLX_ERR_INVALID. */
+ * tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable), "block_e" (0 = corners per thread of the
+ * block kernels chosen per lattice; 16 or 24: a block holds 256 * e corners), "block_dense_combine" (1), "blur_fuse" (1), "scatter_store" (0), "unpermute_gather" (1), and the diagnostic
+ * "splat_ablate" / "blur_ablate" / "block_ablate" (0).  Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);
 
 /* Names of the kernels the last plx_splat / plx_blur / plx_slice (or plx_apply) on this lattice launched, as
  * "splat=a+b;blur_axis=c;slice=d;vertex_order=morton|first_touch" -- the names rocprofv3 --kernel-trace shows (without
  * template arguments) and the vertex numbering of the last build, so that a bench line can name what actually ran. */
 int plx_last_kernels(const plx_lattice *lat, char *buf, int cap);
-/* Block rows of the lattice's block tables (the single-column splat / slice path of coarse lattices: owned points
- * are cut into blocks, a block row = one distinct vertex of one block), or 0 when the lattice uses the
- * vertex-sorted CSR path instead.  The block tables serve single-column MVMs only: a build on a lattice object whose
- * previous lattice served multi-column MVMs and no single-column one (a training loop), and a plx_filter call with
- * vd > 1, leave them to their first user -- the first single-column plx_splat / plx_slice / plx_apply, or this call
- * (which then builds them on the stream of the last build and waits). */
-int64_t plx_block_rows(plx_lattice *lat);
+/* The splat / slice tables of a built lattice (block tables, their vertex-sorted half, the vertex-sorted CSR) are built
+ * by their first user: the first plx_splat / plx_slice / plx_apply that needs them, on that call's stream -- a CG-only
+ * caller never pays for single-column tables and vice versa.  plx_prepare builds, on `stream`, everything an MVM with
+ * vd columns will read, so that the first MVM costs what every later one does (and so that a profile can time the
+ * tables apart from the MVM).  Idempotent. */
+int plx_prepare(plx_lattice *lat, int vd, void *stream);
+/* Block rows of the lattice's block tables (coarse lattices: the owned points are cut into blocks, a block row = one
+ * distinct vertex of one block), or 0 when the tables have not been built (see plx_prepare) or the lattice uses the
+ * vertex-sorted CSR path instead.  A pure query: no launch, no synchronisation. */
+int64_t plx_block_rows(const plx_lattice *lat);
 
 /* Per-stage device time of the last plx_build on this lattice, in ms, in the
  * order {order+embed, insert, number, ids, neighbours, csr}; 0 when timing is off.

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 namespace plx {
@@ -39,10 +40,10 @@ static std::vector<DevBuf *> all_bufs(plx_lattice *L)
 {
     return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
             &L->sort_keys_in, &L->sort_keys_out, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
-            &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->row_ptr,
+            &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->csr_vid, &L->row_ptr,
             &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
             &L->sortkey_in, &L->sortkey_out,
-            &L->bc_pt, &L->bc_w, &L->srow, &L->brow_ptr, &L->brow_vid, &L->s2_idx, &L->s2_ptr, &L->s2_vid, &L->s2_wave, &L->partial, &L->pair_nbr, &L->inv_perm, &L->vslot, &L->vkeys_alt, &L->vslot_alt, &L->vorder};
+            &L->bc_pt, &L->bc_w, &L->srow, &L->brow_ptr, &L->brow_vid, &L->s2_idx, &L->s2_ptr, &L->s2_vid, &L->s2_wave, &L->s2_wave_v, &L->partial, &L->pair_nbr, &L->inv_perm, &L->vslot, &L->vkeys_alt, &L->vslot_alt, &L->vorder};
 }
 
 struct DeviceGuard {
@@ -113,18 +114,10 @@ void plx_destroy(plx_lattice *L)
 }
 
 // single_use: the lattice serves ONE MVM (plx_filter, the reference's one-shot contract): what only pays back over several
-// MVMs is left out of the build -- the vertex renumbering (+0.16 ms for -17 us per MVM at N = 1e6) and the axis-pair tables
-// What the build that is about to start leaves to the first user: the block tables, when the lattice this object held
-// until now served multi-column MVMs only, or when the one MVM of a one-shot call is known to be multi-column.
-static void decide_deferred_tables(plx_lattice *L, bool force_defer)
-{
-    L->defer_blocks = force_defer || (L->built && L->multi_used && !L->blocks_used);
-    L->blocks_used = false;
-    L->multi_used = false;
-}
-
+// MVMs is left out of the build -- the vertex renumbering (+0.16 ms for -17 us per MVM at N = 1e6), the axis-pair tables
+// and, for a multi-column MVM, the block tables.
 static int build_entry(plx_lattice *L, const float *d_ref, int64_t n, int d, const float *h_taps, int ntaps,
-                       int shard_index, int n_shards, void *stream, bool single_use, bool multi_column_only = false)
+                       int shard_index, int n_shards, void *stream, bool single_use)
 {
     if (!L || !d_ref || !h_taps) { set_error("plx_build: NULL argument"); return PLX_ERR_INVALID; }
     if (n <= 0) { set_error("plx_build: n = %lld must be positive", (long long)n); return PLX_ERR_INVALID; }
@@ -141,7 +134,6 @@ static int build_entry(plx_lattice *L, const float *d_ref, int64_t n, int d, con
     }
     DeviceGuard g(L->device);
     if (!g.ok) { set_error("plx_build: cannot select device %d", L->device); return PLX_ERR_HIP; }
-    decide_deferred_tables(L, multi_column_only);
     L->built = false;
     L->local_ready = false;
     L->single_use = single_use;
@@ -184,7 +176,6 @@ int plx_build_local(plx_lattice *L, const float *d_ref_local, int64_t n_local, i
     L->own_begin = 0; L->own_end = n_local;
     memset(&L->taps, 0, sizeof(L->taps));
     for (int i = 0; i < ntaps; ++i) L->taps.c[i] = h_taps[i];
-    decide_deferred_tables(L, false);
     L->for_merge = true;
     L->single_use = false;
     int rc = build_local_impl(L, d_ref_local, (hipStream_t)stream);
@@ -380,7 +371,7 @@ int plx_filter(plx_lattice *scratch, const float *d_src, const float *d_ref, int
         if (hipGetDevice(&dev) != hipSuccess) { set_error("plx_filter: hipGetDevice failed"); return PLX_ERR_HIP; }
         PLX_TRY(plx_create(dev, &L));
     }
-    int rc = build_entry(L, d_ref, n, d, h_taps, ntaps, 0, 1, stream, true, vd > 1);
+    int rc = build_entry(L, d_ref, n, d, h_taps, ntaps, 0, 1, stream, true);
     if (rc == PLX_OK) rc = plx_apply(L, d_src, vd, d_out, stream);
     if (!scratch) {
         (void)hipStreamSynchronize((hipStream_t)stream);
@@ -507,14 +498,18 @@ int plx_last_kernels(const plx_lattice *L, char *buf, int cap)
     return PLX_OK;
 }
 
-int64_t plx_block_rows(plx_lattice *L)
+int64_t plx_block_rows(const plx_lattice *L)
 {
-    if (!L || !L->built) return 0;
-    if (!L->blocks_ready) {                      // deferred at build time: decide now, on the build's stream, and wait
-        DeviceGuard g(L->device);
-        if (!g.ok || ensure_blocks(L, L->build_stream) != PLX_OK || hipStreamSynchronize(L->build_stream) != hipSuccess) return 0;
-    }
-    return L->use_blocks ? L->n_brows : 0;
+    return (L && L->built && L->blocks_ready && L->use_blocks) ? L->n_brows : 0;
+}
+
+int plx_prepare(plx_lattice *L, int vd, void *stream)
+{
+    if (!L) { set_error("plx_prepare: NULL lattice"); return PLX_ERR_INVALID; }
+    if (!L->built) { set_error("plx_prepare: lattice not built"); return PLX_ERR_STATE; }
+    if (vd < 1) { set_error("plx_prepare: vd = %d must be positive", vd); return PLX_ERR_INVALID; }
+    DeviceGuard g(L->device);
+    return prepare_tables(L, vd, (hipStream_t)stream);
 }
 
 int plx_build_times(const plx_lattice *L, float *h_ms6)

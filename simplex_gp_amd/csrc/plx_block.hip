@@ -32,12 +32,13 @@ int g_block_path = 1;        // 0 never, 1 when the lattice qualifies (see build
 int g_block_ablate = 0;      // diagnostics only: 1 combine without the partial gathers, 2 combine without idx loads too,
                              // 4 combine without stores, 8 splat_block without the LDS source reads
 int g_scatter_store = 0;     // slice's row-scattered output stores: 0 plain, 1 non-temporal, 2 agent-scope (write-through)
-int g_block_lds_sort = 1;    // 1: the corners of a block are sorted by one workgroup in LDS (256-thread blocks); 0: one global radix sort
 int g_unpermute_gather = 1;  // caller row order out of the block slice: 1 = lattice-ordered scratch + a gather pass, 0 = scatter from the slice kernel
-int g_block_threads = 256;   // threads per block workgroup (256, 512 or 1024); a block holds threads * kBlkE corners
+int g_block_e = 0;           // corners per thread of the block kernels (a block holds 256 * e corners): 0 = per lattice (choose_block_e), 16 or 24
+int g_block_dense_combine = 1;      // combine numbers the vertices by counting row ends (no s2_vid stream) when every vertex has block rows
 
-constexpr int kBlkE = 16;        // corners per thread of splat_block_kernel
+constexpr int kBlkT = 256;       // threads per block workgroup
 constexpr int kCombineRun = 256; // block rows per wave of splat_combine_kernel
+constexpr int kBlkMaxP = 1024;    // most points per block (d <= 2: fewer corners than a block could hold)
 
 // exclusive scan of one int per thread over a kBlock-thread workgroup
 __device__ __forceinline__ int wg_exclusive_scan(int val, int *total)
@@ -65,33 +66,7 @@ __device__ __forceinline__ int wg_exclusive_scan(int val, int *total)
 }
 
 // ----------------------------------------------------------------------------
-// build
-
-// sort key of an owned corner: (block of its point, vertex id); value: the corner itself
-__global__ __launch_bounds__(kBlock) void blk_keys_kernel(const int *__restrict__ evid, int n, int own_begin, int n_own,
-                                                          int P, int vbits, uint32_t *__restrict__ keys,
-                                                          uint32_t *__restrict__ vals)
-{
-    const int pl = blockIdx.x * kBlock + threadIdx.x;
-    if (pl >= n_own) return;
-    const int r = blockIdx.y;
-    const size_t dst = (size_t)r * n_own + pl;
-    keys[dst] = ((uint32_t)(pl / P) << vbits) | (uint32_t)evid[(size_t)r * n + own_begin + pl];
-    vals[dst] = (uint32_t)dst;
-}
-
-// rows (distinct vertices) of every block
-__global__ __launch_bounds__(kBlock) void blk_count_kernel(const uint32_t *__restrict__ skeys, int nnz, int cpb,
-                                                           int *__restrict__ rows)
-{
-    const int b = blockIdx.x;
-    const int k0 = b * cpb, k1 = min(k0 + cpb, nnz);
-    int cnt = 0;
-    for (int k = k0 + threadIdx.x; k < k1; k += kBlock) cnt += (k == k0 || skeys[k] != skeys[k - 1]) ? 1 : 0;
-    int total;
-    wg_exclusive_scan(cnt, &total);
-    if (threadIdx.x == 0) rows[b] = total;
-}
+// build helpers (the per-block LDS sort lives in plx_sort.hip)
 
 // rows[] -> exclusive offsets (rows[nblocks] = total); counters[0] = total, counters[1] = largest block
 __global__ __launch_bounds__(kBlock) void blk_scan_kernel(int *__restrict__ rows, int nblocks, int *__restrict__ counters)
@@ -120,39 +95,6 @@ __global__ __launch_bounds__(kBlock) void blk_scan_kernel(int *__restrict__ rows
     }
 }
 
-// per-corner records in (block, vertex) order, block-row vertex ids, and the point-major row index of every corner
-__global__ __launch_bounds__(kBlock) void blk_fill_kernel(const uint32_t *__restrict__ skeys, const uint32_t *__restrict__ svals,
-                                                          const float *__restrict__ ew, int n, int own_begin, int n_own,
-                                                          int nnz, int cpb, int P, uint32_t vmask,
-                                                          const int *__restrict__ brow_ptr, uint16_t *__restrict__ bc_pt,
-                                                          float *__restrict__ bc_w, int *__restrict__ brow_vid,
-                                                          uint16_t *__restrict__ srow, int64_t sstride)
-{
-    const int b = blockIdx.x;
-    const int k0 = b * cpb, k1 = min(k0 + cpb, nnz);
-    const int base = brow_ptr[b];
-    int carry = 0;
-    for (int kk = k0; kk < k1; kk += kBlock) {           // same trip count in every thread (barriers inside)
-        const int k = kk + threadIdx.x;
-        const bool live = k < k1;
-        const uint32_t key = live ? skeys[k] : 0u;
-        const int head = (live && (k == k0 || key != skeys[k - 1])) ? 1 : 0;
-        int total;
-        const int ex = wg_exclusive_scan(head, &total);
-        if (live) {
-            const int lrow = carry + ex + head - 1;      // block row of this corner
-            const uint32_t sv = svals[k];
-            const uint32_t r = sv / (uint32_t)n_own, pl = sv - r * (uint32_t)n_own;
-            const bool end = (k + 1 == k1) || skeys[k + 1] != key;
-            bc_pt[k] = (uint16_t)((pl - (uint32_t)b * (uint32_t)P) | (end ? 0x8000u : 0u));
-            bc_w[k] = ew[(size_t)r * n + own_begin + pl];
-            if (head) brow_vid[base + lrow] = (int)(key & vmask);
-            srow[(size_t)r * sstride + pl] = (uint16_t)lrow;
-        }
-        carry += total;
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void blk_iota_kernel(const int *__restrict__ brow_vid, int nrows,
                                                           uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
@@ -177,12 +119,13 @@ __global__ __launch_bounds__(kBlock) void blk_rowptr_kernel(const uint32_t *__re
 // ----------------------------------------------------------------------------
 // splat, stage 1: one workgroup per block.
 
-template <int E, int T>
-__global__ __launch_bounds__(T) void splat_block_kernel(const uint16_t *__restrict__ bc_pt, const float *__restrict__ bc_w,
+template <int E>
+__global__ __launch_bounds__(kBlkT) void splat_block_kernel(const uint16_t *__restrict__ bc_pt, const float *__restrict__ bc_w,
                                                            const int *__restrict__ brow_ptr, const float *__restrict__ src,
                                                            const uint32_t *__restrict__ perm, int own_begin, int n_own,
                                                            int nnz, int P, int cpb, float *__restrict__ partial)
 {
+    constexpr int T = kBlkT;
     extern __shared__ float lds_src[];                  // [P] source values of the block's points, then [rows] row sums
     __shared__ int w_cnt[T / 64];
     __shared__ float w_tail[T / 64];
@@ -284,8 +227,13 @@ __global__ __launch_bounds__(T) void splat_block_kernel(const uint16_t *__restri
 // stage 1; a row that crosses a 64-entry step is carried in a register.  (A first version with one thread per
 // vertex and a serial loop over its rows ran 35 us at N = 1e6: every wave waited for its longest row.)
 
-__global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__restrict__ s2_wave, const int *__restrict__ s2_idx,
-                                                               const int *__restrict__ s2_vid,
+// DENSE: every vertex has at least one block row (the lattice's own points touch every vertex), so the block rows of
+// a wave's range belong to consecutive vertices and the vertex of a row end is the wave's first vertex (s2_wave_v) plus
+// the row ends counted so far -- the 4-byte-per-row s2_vid stream is not read at all and the stores of a step fall on
+// consecutive floats.  !DENSE (a rank's share of a sharded lattice): the vertex comes from s2_vid at row ends.
+template <bool DENSE>
+__global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__restrict__ s2_wave, const int *__restrict__ s2_wave_v,
+                                                               const int *__restrict__ s2_idx, const int *__restrict__ s2_vid,
                                                                const float *__restrict__ partial, int nwaves,
                                                                float *__restrict__ values, int ntiles, int remap,
                                                                int ablate)
@@ -298,6 +246,7 @@ __global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__rest
     const int w = tile * (kBlock / 64) + (threadIdx.x >> 6);
     if (w >= nwaves) return;                            // whole waves leave; no workgroup barrier below
     const int e0 = s2_wave[w], e1 = s2_wave[w + 1];
+    int vnext = DENSE ? s2_wave_v[w] : 0;               // vertex of the next row end of this wave's range
     float carry = 0.f;                                  // what the row open at the start of a step already holds
     // EPL consecutive entries per lane (16-byte loads, aligned: the step starts at e0 rounded down and the entries
     // before e0 -- the tail of the previous wave's last row -- are masked), summed in the thread, then ONE wave scan
@@ -313,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__rest
                 const int kq = k0 + 4 * q;
                 ix = (ablate & 2) ? make_int4(kq, kq + 1, kq + 2, (int)(0x80000000u | (uint32_t)(kq + 3)))
                                   : *reinterpret_cast<const int4 *>(s2_idx + kq);
-                vx = *reinterpret_cast<const int4 *>(s2_vid + kq);
+                if (!DENSE) vx = *reinterpret_cast<const int4 *>(s2_vid + kq);
             }
             idx[4 * q] = ix.x; idx[4 * q + 1] = ix.y; idx[4 * q + 2] = ix.z; idx[4 * q + 3] = ix.w;
             vid[4 * q] = vx.x; vid[4 * q + 1] = vx.y; vid[4 * q + 2] = vx.z; vid[4 * q + 3] = vx.w;
@@ -347,24 +296,28 @@ __global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__rest
         float xtail = __shfl_up(itail, 1);
         if (lane == 0) { xcnt = 0; xtail = 0.f; }
         float run = xcnt > 0 ? xtail : carry + xtail;   // what the open row holds when it reaches this thread
+        int v = vnext + xcnt;                           // DENSE: vertex of this thread's first row end
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
             run += val[j];
             if (end[j]) {
-                if (!(ablate & 4)) values[vid[j]] = run;
+                if (!(ablate & 4)) values[DENSE ? v : vid[j]] = run;
+                ++v;
                 run = 0.f;
             }
         }
         const int tcnt = __shfl(icnt, 63);
         const float ttail = __shfl(itail, 63);
         carry = tcnt > 0 ? ttail : carry + ttail;
+        vnext += tcnt;
     }
 }
 
-// bit 31 of s2_idx = last block row of its vertex; s2_wave[w] = first entry >= w * kCombineRun that starts a vertex row
+// bit 31 of s2_idx = last block row of its vertex; s2_wave[w] = first entry >= w * kCombineRun that starts a vertex row,
+// s2_wave_v[w] = the vertex of that row
 __global__ __launch_bounds__(kBlock) void blk_s2_finish_kernel(int *__restrict__ s2_idx, const int *__restrict__ s2_vid,
-                                                               const int *__restrict__ s2_ptr, int nrows, int nwaves,
-                                                               int *__restrict__ s2_wave)
+                                                               const int *__restrict__ s2_ptr, int nrows, int nwaves, int m,
+                                                               int *__restrict__ s2_wave, int *__restrict__ s2_wave_v)
 {
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k < nrows) {
@@ -376,28 +329,35 @@ __global__ __launch_bounds__(kBlock) void blk_s2_finish_kernel(int *__restrict__
         if (e >= nrows) e = nrows;
         else if (e > 0 && s2_vid[e - 1] == s2_vid[e]) e = s2_ptr[s2_vid[e] + 1];   // inside a row: it belongs to the wave before
         s2_wave[k] = e;
+        s2_wave_v[k] = e < nrows ? s2_vid[e] : m;
     }
 }
 
 int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream)
 {
+    PLX_TRY(ensure_s2(L, stream));
     const int n_own = (int)(L->own_end - L->own_begin);
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
     const size_t lds = ((size_t)L->blk_P + (size_t)L->blk_max_rows) * 4;
-#define PLX_LAUNCH(T)                                                                                                  \
-    splat_block_kernel<kBlkE, T><<<(unsigned)L->nblocks, T, lds, stream>>>(                                            \
+#define PLX_LAUNCH(E)                                                                                                  \
+    splat_block_kernel<E><<<(unsigned)L->nblocks, kBlkT, lds, stream>>>(                                               \
         L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->brow_ptr.as<int>(), d_src, perm, (int)L->own_begin, n_own,    \
         (int)L->nnz, L->blk_P, L->blk_cpb, L->partial.as<float>())
-    if (L->blk_T == 256) PLX_LAUNCH(256);
-    else if (L->blk_T == 512) PLX_LAUNCH(512);
-    else PLX_LAUNCH(1024);
+    if (L->blk_E == 16) PLX_LAUNCH(16);
+    else PLX_LAUNCH(24);
 #undef PLX_LAUNCH
+    const bool dense = L->n_shards == 1 && !L->partial_cover && g_block_dense_combine != 0;
     // vertices no owned point touches (a rank's share of a sharded lattice) have no block rows: zero them first
     if (L->n_shards != 1 || L->partial_cover) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)L->m * 4, stream));
     const int nt = ceil_div(L->n_s2waves, kBlock / 64);
-    splat_combine_kernel<<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
-        L->s2_wave.as<int>(), L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->partial.as<float>(), (int)L->n_s2waves, d_values,
-        nt, g_xcd_remap, g_block_ablate);
+    if (dense)
+        splat_combine_kernel<true><<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
+            L->s2_wave.as<int>(), L->s2_wave_v.as<int>(), L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->partial.as<float>(),
+            (int)L->n_s2waves, d_values, nt, g_xcd_remap, g_block_ablate);
+    else
+        splat_combine_kernel<false><<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
+            L->s2_wave.as<int>(), L->s2_wave_v.as<int>(), L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->partial.as<float>(),
+            (int)L->n_s2waves, d_values, nt, g_xcd_remap, g_block_ablate);
     L->kn_splat = "splat_block_kernel+splat_combine_kernel";
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());
@@ -409,7 +369,7 @@ int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStr
 // in LDS.  Same arithmetic and order as slice_v1_kernel (plx_slice.hip).
 
 template <int D1>
-__global__ __launch_bounds__(1024) void slice_block_kernel(const uint16_t *__restrict__ srow, int64_t sstride,
+__global__ __launch_bounds__(kBlkT) void slice_block_kernel(const uint16_t *__restrict__ srow, int64_t sstride,
                                                            const float *__restrict__ ew, int n,
                                                            const int *__restrict__ brow_ptr, const int *__restrict__ brow_vid,
                                                            const float *__restrict__ values, const uint32_t *__restrict__ perm,
@@ -520,7 +480,7 @@ int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStr
     switch (L->d + 1) {
 #define PLX_CASE(D1)                                                                                                    \
     case D1:                                                                                                            \
-        slice_block_kernel<D1><<<(unsigned)L->nblocks, L->blk_T, lds, stream>>>(                                        \
+        slice_block_kernel<D1><<<(unsigned)L->nblocks, kBlkT, lds, stream>>>(                                           \
             L->srow.as<uint16_t>(), L->srow_stride, L->ew.as<float>(), (int)L->n, L->brow_ptr.as<int>(),                \
             L->brow_vid.as<int>(), d_values, perm, (int)L->own_begin, n_own, L->blk_P, rden, d_out, d_affine, d_src,   \
             perm ? g_scatter_store : 0);                                                                                \
@@ -542,19 +502,50 @@ int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStr
     return PLX_OK;
 }
 
+// ----------------------------------------------------------------------------
+// Block tables for the owned points of a built lattice (evid / ew / perm final), built by their first user.
+
+// Corners per thread of the block kernels, i.e. the block size (256 * e corners): the kernels are latency bound and a
+// CU holds 8 block workgroups (32 waves), so what counts is how many rounds of 2048 workgroups a launch takes and how
+// long a workgroup lives (~e): at N = 1e6, d = 8, 448-point blocks (e = 16) are 2,232 workgroups = 2 rounds, 672-point
+// blocks (e = 24) 1,489 = 1 round.
+// Points per block: a full block's corners (P * d1) are a whole number of threads (e corners each) and of 16-byte
+// vectors of the per-corner arrays, so no thread of one block ever stores into the next block's records; at most
+// kBlkMaxP (the block-local point index has 15 bits; d <= 2 has fewer corners than a block could hold).
+static int block_points(int e, int d1)
+{
+    const int mult = e == 24 ? 48 : 16;
+    const int P = (kBlkT * e / d1) / mult * mult;
+    return std::min(P, kBlkMaxP / mult * mult);
+}
+
+static int choose_block_e(int n_own, int d1)
+{
+    if (g_block_e == 16 || g_block_e == 24) return g_block_e;
+    const int64_t slots = 2048;
+    int best = 16;
+    int64_t best_cost = -1;
+    for (int e : {16, 24}) {
+        const int P = block_points(e, d1);
+        if (P < 16) continue;
+        const int64_t nb = ((int64_t)n_own + P - 1) / P;
+        const int64_t cost = ((nb + slots - 1) / slots) * e;
+        if (best_cost < 0 || cost < best_cost) { best = e; best_cost = cost; }
+    }
+    return best;
+}
+
 int ensure_blocks(plx_lattice *L, hipStream_t stream)
 {
     if (L->blocks_ready) return PLX_OK;
-    PLX_TRY(build_blocks(L, stream));
-    return PLX_OK;
+    return build_blocks(L, stream);
 }
 
-// ----------------------------------------------------------------------------
-// Block tables for the owned points of a built lattice (evid / ew / perm final).  Leaves L->use_blocks.
 int build_blocks(plx_lattice *L, hipStream_t stream)
 {
     L->use_blocks = false;
     L->blocks_ready = true;
+    L->s2_ready = false;
     const int d1 = L->d + 1;
     const int n = (int)L->n, n_own = (int)(L->own_end - L->own_begin);
     const int64_t nnz = L->nnz, m = L->m;
@@ -562,47 +553,26 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     // the path pays when corners share vertices: with m > nnz / 2 most block rows hold a single corner and the
     // two-stage splat only adds a pass (the sparse regime keeps the vertex-sorted CSR path)
     if (g_block_path == 1 && 2 * m > nnz) return PLX_OK;
-    const int T = (g_block_threads == 512) ? 512 : (g_block_threads == 1024 ? 1024 : 256);
-    const int C = T * kBlkE;
-    int P = (C / d1) & ~15;                      // points per block: every thread's 16 corners are whole 16-byte vectors of the per-corner arrays
+    const int E = choose_block_e(n_own, d1);
+    const int P = block_points(E, d1);
     if (P < 16) return PLX_OK;
-    if (P > 32760) P = 32760;                    // 15-bit block-local point index
     const int cpb = P * d1;                      // corners per (full) block
     const int64_t nblocks = (n_own + P - 1) / P;
-    int vbits = 1, bbits = 0;
+    int vbits = 1;
     while ((1ll << vbits) < m) ++vbits;
-    while ((1ll << bbits) < nblocks) ++bbits;
-    const bool lds_build = (T == 256 && vbits <= 30 && g_block_lds_sort != 0);
-    if (!lds_build && vbits + bbits > 32) return PLX_OK;   // (block, vertex) does not fit the global sort's 32-bit key: CSR path
-    L->blk_P = P; L->blk_T = T; L->blk_cpb = cpb; L->nblocks = nblocks;
+    if (vbits > 30) return PLX_OK;
+    L->blk_P = P; L->blk_E = E; L->blk_cpb = cpb; L->nblocks = nblocks;
     L->srow_stride = ((int64_t)n_own + 7) & ~7ll;
 
-    size_t temp_bytes = 0;
-    if (!lds_build) PLX_TRY(sort_pairs_temp_bytes(nnz, vbits + bbits, &temp_bytes));
-    PLX_TRY(ensure(L->sort_keys_in, (size_t)nnz * 4));
-    PLX_TRY(ensure(L->sort_keys_out, (size_t)nnz * 4 + 16));
-    PLX_TRY(ensure(L->sort_vals_in, (size_t)nnz * 4));
-    PLX_TRY(ensure(L->sort_vals_out, (size_t)nnz * 4));
-    PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
-    PLX_TRY(ensure(L->bc_pt, (size_t)nnz * 2 + 64));
-    PLX_TRY(ensure(L->bc_w, (size_t)nnz * 4 + 64));
+    PLX_TRY(ensure(L->sort_keys_in, (size_t)nblocks * cpb * 4 + 64));      // the blocks' vertex lists, block strided
+    PLX_TRY(ensure(L->bc_pt, (size_t)nnz * 2 + 128));     // slack: the last thread of the last block stores whole vectors
+    PLX_TRY(ensure(L->bc_w, (size_t)nnz * 4 + 128));
     PLX_TRY(ensure(L->srow, (size_t)d1 * L->srow_stride * 2 + 64));
     PLX_TRY(ensure(L->brow_ptr, (size_t)(nblocks + 1) * 4));
-
-    if (lds_build) {
-        // one workgroup per block: sort in LDS, per-corner records, row counts; the vertex lists go to sort_keys_in
-        PLX_TRY(sort_fill_blocks_lds(L->evid.as<int>(), L->ew.as<float>(), n, (int)L->own_begin, n_own, P, d1, cpb, vbits, nblocks,
-                                     L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->srow.as<uint16_t>(), L->srow_stride,
-                                     L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), stream));
-    } else {
-        blk_keys_kernel<<<dim3(ceil_div(n_own, kBlock), d1), kBlock, 0, stream>>>(
-            L->evid.as<int>(), n, (int)L->own_begin, n_own, P, vbits, L->sort_keys_in.as<uint32_t>(),
-            L->sort_vals_in.as<uint32_t>());
-        PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(), L->sort_keys_out.as<uint32_t>(),
-                           L->sort_vals_in.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), nnz, vbits + bbits, stream));
-        blk_count_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)nnz, cpb,
-                                                                  L->brow_ptr.as<int>());
-    }
+    // one workgroup per block: sort in LDS, per-corner records, row counts; the vertex lists go to sort_keys_in
+    PLX_TRY(sort_fill_blocks_lds(L->evid.as<int>(), L->ew.as<float>(), n, (int)L->own_begin, n_own, P, d1, cpb, vbits, E, nblocks,
+                                 L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->srow.as<uint16_t>(), L->srow_stride,
+                                 L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), stream));
     blk_scan_kernel<<<1, kBlock, 0, stream>>>(L->brow_ptr.as<int>(), (int)nblocks, L->counters.as<int>() + 40);
     PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned + 40, L->counters.as<int>() + 40, 8, hipMemcpyDeviceToHost, stream));
     PLX_HIP_TRY(hipStreamSynchronize(stream));          // R_b sizes the row tables
@@ -611,33 +581,7 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     L->blk_max_rows = L->h_pinned[41];
     if (g_block_path == 1 && 10 * nrows > 7 * nnz) return PLX_OK;   // too little sharing inside blocks: CSR path
     PLX_TRY(ensure(L->brow_vid, (size_t)nrows * 4 + 16));
-    PLX_TRY(ensure(L->s2_idx, (size_t)nrows * 4 + 64));
-    PLX_TRY(ensure(L->s2_ptr, (size_t)(m + 2) * 4));
-    PLX_TRY(ensure(L->s2_vid, (size_t)nrows * 4 + 64));
-    L->n_s2waves = (nrows + kCombineRun - 1) / kCombineRun;
-    PLX_TRY(ensure(L->s2_wave, (size_t)(L->n_s2waves + 2) * 4));
-    PLX_TRY(ensure(L->partial, (size_t)nrows * 4 + 16));
-    if (lds_build) {
-        PLX_TRY(compact_block_rows(L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), cpb, nblocks, L->brow_vid.as<int>(), stream));
-    } else {
-        blk_fill_kernel<<<(unsigned)nblocks, kBlock, 0, stream>>>(
-            L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n, (int)L->own_begin, n_own,
-            (int)nnz, cpb, P, (uint32_t)((1ull << vbits) - 1), L->brow_ptr.as<int>(), L->bc_pt.as<uint16_t>(),
-            L->bc_w.as<float>(), L->brow_vid.as<int>(), L->srow.as<uint16_t>(), L->srow_stride);
-    }
-    // vertex -> its block rows
-    size_t temp2 = 0;
-    PLX_TRY(sort_pairs_temp_bytes(nrows, vbits, &temp2));
-    PLX_TRY(ensure(L->sort_temp, temp2 + 16));
-    blk_iota_kernel<<<ceil_div(nrows, kBlock), kBlock, 0, stream>>>(L->brow_vid.as<int>(), (int)nrows,
-                                                                    L->sort_keys_in.as<uint32_t>(),
-                                                                    L->sort_vals_in.as<uint32_t>());
-    PLX_TRY(sort_pairs(L->sort_temp.p, temp2, L->sort_keys_in.as<uint32_t>(), L->s2_vid.as<uint32_t>(),
-                       L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, stream));
-    blk_rowptr_kernel<<<ceil_div(m + 1, kBlock), kBlock, 0, stream>>>(L->s2_vid.as<uint32_t>(), (int)nrows, (int)m,
-                                                                      L->s2_ptr.as<int>());
-    blk_s2_finish_kernel<<<ceil_div(std::max<int64_t>(nrows, L->n_s2waves + 1), kBlock), kBlock, 0, stream>>>(
-        L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->s2_ptr.as<int>(), (int)nrows, (int)L->n_s2waves, L->s2_wave.as<int>());
+    PLX_TRY(compact_block_rows(L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), cpb, nblocks, L->brow_vid.as<int>(), stream));
     PLX_TRY(ensure(L->inv_perm, (size_t)n_own * 4 + 16));
     inv_perm_kernel<<<ceil_div(n_own, kBlock), kBlock, 0, stream>>>(L->perm.as<uint32_t>(), (int)L->own_begin, n_own,
                                                                     L->inv_perm.as<uint32_t>());
@@ -646,5 +590,63 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     return PLX_OK;
 }
 
+// The second half of the tables, needed by the block splat only: the block rows sorted by vertex.
+int ensure_s2(plx_lattice *L, hipStream_t stream)
+{
+    if (L->s2_ready) return PLX_OK;
+    const int64_t nrows = L->n_brows, m = L->m;
+    int vbits = 1;
+    while ((1ll << vbits) < m) ++vbits;
+    PLX_TRY(ensure(L->s2_idx, (size_t)nrows * 4 + 64));
+    PLX_TRY(ensure(L->s2_ptr, (size_t)(m + 2) * 4));
+    PLX_TRY(ensure(L->s2_vid, (size_t)nrows * 4 + 64));
+    L->n_s2waves = (nrows + kCombineRun - 1) / kCombineRun;
+    PLX_TRY(ensure(L->s2_wave, (size_t)(L->n_s2waves + 2) * 4));
+    PLX_TRY(ensure(L->s2_wave_v, (size_t)(L->n_s2waves + 2) * 4));
+    PLX_TRY(ensure(L->partial, (size_t)nrows * 4 + 16));
+    size_t temp2 = 0;
+    PLX_TRY(sort_pairs_temp_bytes(nrows, vbits, &temp2));
+    PLX_TRY(ensure(L->sort_temp, temp2 + 16));
+    PLX_TRY(ensure(L->sort_keys_in, (size_t)nrows * 4 + 64));
+    PLX_TRY(ensure(L->sort_vals_in, (size_t)nrows * 4 + 64));
+    blk_iota_kernel<<<ceil_div(nrows, kBlock), kBlock, 0, stream>>>(L->brow_vid.as<int>(), (int)nrows,
+                                                                    L->sort_keys_in.as<uint32_t>(),
+                                                                    L->sort_vals_in.as<uint32_t>());
+    PLX_TRY(sort_pairs(L->sort_temp.p, temp2, L->sort_keys_in.as<uint32_t>(), L->s2_vid.as<uint32_t>(),
+                       L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, stream));
+    blk_rowptr_kernel<<<ceil_div(m + 1, kBlock), kBlock, 0, stream>>>(L->s2_vid.as<uint32_t>(), (int)nrows, (int)m,
+                                                                      L->s2_ptr.as<int>());
+    blk_s2_finish_kernel<<<ceil_div(std::max<int64_t>(nrows, L->n_s2waves + 1), kBlock), kBlock, 0, stream>>>(
+        L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->s2_ptr.as<int>(), (int)nrows, (int)L->n_s2waves, (int)m,
+        L->s2_wave.as<int>(), L->s2_wave_v.as<int>());
+    PLX_HIP_TRY(hipGetLastError());
+    L->s2_ready = true;
+    return PLX_OK;
+}
+
+// Which kernels serve a vd-column MVM on this lattice.  Builds the block tables when the answer depends on them.
+// Multi-column right-hand sides keep to the vertex-sorted CSR kernels: block kernels for rows of 2..4 sixteen-byte chunks
+// were built and measured in round 3 (LDS-staged vertex rows in slice, per-block segmented scan + per-vertex combine in
+// splat) and lost on every lattice tried -- N = 4e6, d = 8, vd = 11: slice 381 vs 431 us in caller row order but 318 vs
+// 252 us in lattice row order, splat 764 - 1020 vs 660 us ("multi-column block tables").
+int choose_paths(plx_lattice *L, int vd, hipStream_t stream, bool *splat_blocks, bool *slice_blocks)
+{
+    *splat_blocks = *slice_blocks = false;
+    if (vd != 1 || L->nnz == 0) return PLX_OK;
+    PLX_TRY(ensure_blocks(L, stream));
+    *splat_blocks = *slice_blocks = L->use_blocks;
+    return PLX_OK;
+}
+
+// plx_prepare: every table a vd-column MVM will read, now instead of inside the first MVM
+int prepare_tables(plx_lattice *L, int vd, hipStream_t stream)
+{
+    bool sp = false, sl = false;
+    PLX_TRY(choose_paths(L, vd, stream, &sp, &sl));
+    if (L->nnz == 0) return PLX_OK;
+    if (sp) PLX_TRY(ensure_s2(L, stream));
+    else PLX_TRY(ensure_csr(L, stream));
+    return PLX_OK;
+}
 
 }  // namespace plx

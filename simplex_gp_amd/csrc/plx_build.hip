@@ -1038,7 +1038,7 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
     return PLX_OK;
 }
 
-// The vertex-sorted splat CSR of the current build (csr_pt / csr_row / csr_w, sorted vertex ids in sort_keys_out):
+// The vertex-sorted splat CSR of the current build (csr_pt / csr_row / csr_w, sorted vertex ids in csr_vid):
 // stable radix sort of the owned corners by vertex id.  Needed by the multi-column splat kernels, the fused
 // backward, the structure exports and every lattice without block tables; built once per lattice build, on demand.
 int ensure_csr(plx_lattice *L, hipStream_t stream)
@@ -1048,13 +1048,13 @@ int ensure_csr(plx_lattice *L, hipStream_t stream)
     PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
     PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));
     PLX_TRY(ensure(L->csr_row, (size_t)L->nnz * 4 + 64));
+    PLX_TRY(ensure(L->csr_vid, (size_t)L->nnz * 4 + 16));   // its own buffer: the block build recycles the sort scratch
     if (L->nnz > 0) {
         int end_bit = 1;
         while ((1ll << end_bit) < (int64_t)m) ++end_bit;
         size_t temp_bytes = 0;
         PLX_TRY(sort_pairs_temp_bytes(L->nnz, end_bit, &temp_bytes));
         PLX_TRY(ensure(L->sort_keys_in, (size_t)L->nnz * 4));
-        PLX_TRY(ensure(L->sort_keys_out, (size_t)L->nnz * 4 + 16));
         PLX_TRY(ensure(L->sort_vals_in, (size_t)L->nnz * 4));
         PLX_TRY(ensure(L->sort_vals_out, (size_t)L->nnz * 4));
         PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
@@ -1062,10 +1062,10 @@ int ensure_csr(plx_lattice *L, hipStream_t stream)
             L->evid.as<int>(), n, (int)L->own_begin, n_own, L->sort_keys_in.as<uint32_t>(),
             L->sort_vals_in.as<uint32_t>());
         PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(),
-                           L->sort_keys_out.as<uint32_t>(), L->sort_vals_in.as<uint32_t>(),
+                           L->csr_vid.as<uint32_t>(), L->sort_vals_in.as<uint32_t>(),
                            L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, stream));
         csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
-            L->sort_keys_out.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
+            L->csr_vid.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
             (int)L->own_begin, (int)L->nnz, m, L->perm.as<uint32_t>(), L->csr_pt.as<int>(), L->csr_row.as<int>(),
             L->csr_w.as<float>());
     }
@@ -1141,17 +1141,12 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     }
     mark();
 
-    // splat / slice tables over the owned points: block tables for single-column right-hand sides on lattices whose
-    // corners share vertices (plx_block.hip); the vertex-sorted CSR of the other kernels is built on first use
-    // (ensure_csr), or right away when there are no block tables
+    // splat / slice tables over the owned points (block tables, their vertex-sorted half, the vertex-sorted CSR): each is
+    // built by its first user (plx_prepare, or the first MVM that needs it -- ensure_blocks / ensure_s2 / ensure_csr)
     L->csr_ready = false;
     L->blocks_ready = false;
+    L->s2_ready = false;
     L->use_blocks = false;
-    L->build_stream = stream;
-    if (!L->defer_blocks) {
-        PLX_TRY(build_blocks(L, stream));
-        if (!L->use_blocks) PLX_TRY(ensure_csr(L, stream));
-    }
     mark();
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -1234,7 +1229,7 @@ int export_row_ptr(plx_lattice *L, hipStream_t stream)
     const int m = (int)L->m;
     PLX_TRY(ensure_csr(L, stream));
     PLX_TRY(ensure(L->row_ptr, (size_t)(m + 1) * 4));
-    row_ptr_kernel<<<ceil_div((int64_t)m + 1, kBlock), kBlock, 0, stream>>>(L->sort_keys_out.as<uint32_t>(), (int)L->nnz, m,
+    row_ptr_kernel<<<ceil_div((int64_t)m + 1, kBlock), kBlock, 0, stream>>>(L->csr_vid.as<uint32_t>(), (int)L->nnz, m,
                                                                             L->row_ptr.as<int>());
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;

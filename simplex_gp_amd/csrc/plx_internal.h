@@ -84,7 +84,7 @@ struct plx_lattice {
     plx::DevBuf merge_slot, merge_flags;   // uint32 [sum of all ranks' local vertex counts] (sharded build)
     plx::DevBuf counters;   // int32  [8]            {m, error flag, ...}
     plx::DevBuf sort_keys_in, sort_vals_in, sort_vals_out, sort_temp;
-    plx::DevBuf sort_keys_out;   // int32 [nnz] sorted vertex id of every owned corner (kept: splat reads it at row ends)
+    plx::DevBuf sort_keys_out;   // build scratch (block tables: global-sort path)
 
     // structure
     plx::DevBuf vkeys;      // uint32 [m][DW]        packed vertex keys, in vertex id order
@@ -108,22 +108,20 @@ struct plx_lattice {
     plx::DevBuf csr_row;    // int32  [nnz]          the same points numbered as the caller's rows (vd = 1 splat
                             //                       gathers straight from d_src, no sorted copy)
     plx::DevBuf csr_w;      // float  [nnz]
+    plx::DevBuf csr_vid;    // int32  [nnz]          sorted vertex id of every owned corner (splat reads it at row ends)
     plx::DevBuf row_ptr;    // int32  [m+1]          produced on demand by plx_export (no kernel reads it)
-    bool csr_ready = false;      // csr_* / sort_keys_out hold the vertex-sorted splat CSR of this build (built on first
+    bool csr_ready = false;      // csr_* hold the vertex-sorted splat CSR of this build (built on first
                                  // use: only the multi-column kernels, the exports and lattices without block tables
                                  // need it -- plx::ensure_csr)
 
     // block tables (plx_block.hip): vd = 1 splat / slice on lattices whose corners share vertices.  The owned
     // points, in lattice order, are cut into blocks of blk_P points; a block's corners are sorted by vertex.
     bool use_blocks = false;
-    // The block tables serve single-column MVMs only.  A lattice object whose previous build served multi-column MVMs
-    // and no single-column one (every step of a training loop: build, CG on [y | probes], backward) skips them at the
-    // next build; whoever needs them first builds them then (ensure_blocks).
+    // The block tables are built by their first user (ensure_blocks: any single-column MVM, multi-column MVMs on
+    // lattices where the tables pay); the vertex-sorted half that only the block splat reads by ITS first user (ensure_s2).
     bool blocks_ready = false;   // build_blocks has run for the current build (use_blocks is decided)
-    bool blocks_used = false, multi_used = false;   // what the current build has served so far
-    bool defer_blocks = false;   // this build left the block tables to their first user
-    hipStream_t build_stream = nullptr;   // stream of the last build (plx_block_rows builds deferred tables there)
-    int blk_P = 0, blk_T = 0, blk_cpb = 0;     // points per block, threads per block workgroup, corners per full block
+    bool s2_ready = false;       // s2_* hold the block rows of the current build sorted by vertex
+    int blk_P = 0, blk_E = 0, blk_cpb = 0;     // points per block, corners per thread (16 / 24), corners per full block
     int blk_max_rows = 0;                      // most distinct vertices in one block (LDS rows of the slice kernel)
     int64_t nblocks = 0, n_brows = 0;          // blocks, block rows (sum over blocks of distinct vertices)
     int64_t srow_stride = 0;                   // plane stride of srow (n_own rounded up to 8)
@@ -136,6 +134,7 @@ struct plx_lattice {
     plx::DevBuf s2_ptr;     // int32  [m+1]          block rows of vertex v: s2_idx[s2_ptr[v] .. s2_ptr[v+1])
     plx::DevBuf s2_vid;     // int32  [n_brows]      vertex of every sorted block row (read at row ends)
     plx::DevBuf s2_wave;    // int32  [n_s2waves+1]  first block row of every combine wave
+    plx::DevBuf s2_wave_v;  // int32  [n_s2waves+1]  vertex of that row
     int64_t n_s2waves = 0;
     plx::DevBuf partial;    // float  [n_brows]      per-MVM block-row sums
     plx::DevBuf inv_perm;   // uint32 [n_own]        lattice-order position of every caller row of the shard
@@ -170,7 +169,10 @@ int export_row_ptr(plx_lattice *L, hipStream_t stream);   // fills L->row_ptr on
 int ensure_csr(plx_lattice *L, hipStream_t stream);       // vertex-sorted splat CSR of the current build, built once on demand
 // plx_block.hip (block tables + the vd = 1 kernels that use them)
 int build_blocks(plx_lattice *L, hipStream_t stream);
-int ensure_blocks(plx_lattice *L, hipStream_t stream);    // the block tables of the current build, if they were deferred
+int ensure_blocks(plx_lattice *L, hipStream_t stream);    // the block tables of the current build (built by their first user)
+int ensure_s2(plx_lattice *L, hipStream_t stream);        // ... and their vertex-sorted half (block splat only)
+int choose_paths(plx_lattice *L, int vd, hipStream_t stream, bool *splat_blocks, bool *slice_blocks);
+int prepare_tables(plx_lattice *L, int vd, hipStream_t stream);
 int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);
 int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStream_t stream, const float *d_affine,
                      const float *d_src);
@@ -185,7 +187,7 @@ int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_
 // block tables built in LDS, one workgroup per block (256-thread blocks): sort by vertex + every per-corner record;
 // the block's vertex list lands in rows_tmp[b * cpb + row] and is compacted once the row offsets are scanned
 int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin, int n_own, int P, int d1, int cpb, int vbits,
-                         int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
+                         int ipt, int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
                          int *rows, hipStream_t stream);
 int compact_block_rows(const int *rows_tmp, const int *brow_ptr, int cpb, int64_t nblocks, int *brow_vid, hipStream_t stream);
 // plx_splat.hip / plx_blur.hip / plx_slice.hip

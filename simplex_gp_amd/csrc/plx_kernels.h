@@ -44,13 +44,13 @@ extern int g_compact_nbr;
 extern int g_insert_dedupe;
 extern int g_nbr_symmetric;
 extern int g_block_path;
-extern int g_block_threads;
+extern int g_block_e;
+extern int g_block_dense_combine;
 extern int g_block_ablate;
 extern int g_blur_fuse;
 extern int g_blur_fuse_vec;
 extern int g_scatter_store;
 extern int g_unpermute_gather;
-extern int g_block_lds_sort;
 
 // Tile index for workgroup blockIdx.x.  With remap the launch has 8 * ceil(ntiles / 8) workgroups and
 // workgroup b takes tile (b % 8) * per + b / 8: workgroups are dealt to the 8 XCDs round-robin

@@ -150,13 +150,9 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
 {
     const int n_own = (int)(L->own_end - L->own_begin);
     if (n_own == 0) { L->kn_slice = ""; tmark(L, stream); return PLX_OK; }
-    if (vd == 1) {
-        PLX_TRY(ensure_blocks(L, stream));
-        L->blocks_used = true;
-        if (L->use_blocks) return slice_block_impl(L, d_values, d_out, stream, d_affine, d_src);
-    } else {
-        L->multi_used = true;
-    }
+    bool splat_blocks = false, slice_blocks = false;
+    PLX_TRY(choose_paths(L, vd, stream, &splat_blocks, &slice_blocks));
+    if (slice_blocks) return slice_block_impl(L, d_values, d_out, stream, d_affine, d_src);
     const int *evid = L->evid.as<int>();
     const float *ew = L->ew.as<float>();
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();

@@ -47,7 +47,7 @@ int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_
 
 
 // ----------------------------------------------------------------------------
-// Block tables (plx_block.hip), built by ONE workgroup per point block, in LDS: the block's <= 4096 corners are
+// Block tables (plx_block.hip), built by ONE workgroup per point block, in LDS: the block's <= 4096 (16 per thread) or 6144 (24 per thread) corners are
 // loaded in (corner, point) order and sorted by vertex id with rocPRIM's block radix sort (stable, so equal vertices
 // keep that order -- the order a global stable sort of (block, vertex) keys gives, which is what the other block
 // sizes use); row heads / ends, block-local row numbers and every per-corner record follow from the sorted registers.
@@ -163,12 +163,16 @@ __global__ __launch_bounds__(256) void blk_compact_kernel(const int *__restrict_
 }
 
 int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin, int n_own, int P, int d1, int cpb, int vbits,
-                         int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
+                         int ipt, int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
                          int *rows, hipStream_t stream)
 {
-    if (cpb > 256 * 16 || vbits > 30) return PLX_ERR_INVALID;
-    blk_sort_fill_kernel<16><<<(unsigned)nblocks, 256, (size_t)cpb * 2, stream>>>(evid, ew, n, own_begin, n_own, P, d1, cpb, vbits,
-                                                                                  bc_pt, bc_w, srow, sstride, rows_tmp, rows);
+    if ((ipt != 16 && ipt != 24) || cpb > 256 * ipt || vbits > 30) { set_error("sort_fill_blocks_lds: %d corners per thread, %d per block", ipt, cpb); return PLX_ERR_INVALID; }
+    if (ipt == 16)
+        blk_sort_fill_kernel<16><<<(unsigned)nblocks, 256, (size_t)cpb * 2, stream>>>(evid, ew, n, own_begin, n_own, P, d1, cpb, vbits,
+                                                                                      bc_pt, bc_w, srow, sstride, rows_tmp, rows);
+    else
+        blk_sort_fill_kernel<24><<<(unsigned)nblocks, 256, (size_t)cpb * 2, stream>>>(evid, ew, n, own_begin, n_own, P, d1, cpb, vbits,
+                                                                                      bc_pt, bc_w, srow, sstride, rows_tmp, rows);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }

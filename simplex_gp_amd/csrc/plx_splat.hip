@@ -544,13 +544,9 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         tmark(L, stream);
         return PLX_OK;
     }
-    if (vd == 1) {
-        PLX_TRY(ensure_blocks(L, stream));
-        L->blocks_used = true;
-        if (L->use_blocks) return splat_block_impl(L, d_src, d_values, stream);
-    } else {
-        L->multi_used = true;
-    }
+    bool splat_blocks = false, slice_blocks = false;
+    PLX_TRY(choose_paths(L, vd, stream, &splat_blocks, &slice_blocks));
+    if (splat_blocks) return splat_block_impl(L, d_src, d_values, stream);
     PLX_TRY(ensure_csr(L, stream));
     const bool all_rows_touched = (L->n_shards == 1 && !L->partial_cover);
     if (!all_rows_touched) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));
@@ -580,7 +576,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
             d_src, perm, (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());
     }
     const float *w = L->csr_w.as<float>();
-    const int *vid = L->sort_keys_out.as<int>();   // sorted vertex id of every corner
+    const int *vid = L->csr_vid.as<int>();   // sorted vertex id of every corner
     float *hp = L->head_partial.as<float>(), *tp = L->tail_partial.as<float>();
     const int nnz = (int)L->nnz, nch_total = vdp / 4, nchunks = (int)L->nchunks;
     if (vd == 1) {
@@ -689,7 +685,7 @@ int splat_stack_impl(plx_lattice *lat, const float *d_g, const float *d_src, con
         d_g, d_src, d_x, perm, (int)lat->own_begin, n_own, L, d, recw, rec);
     float4 *v4 = reinterpret_cast<float4 *>(d_values);
     float4 *h4 = reinterpret_cast<float4 *>(lat->head_partial.as<float>()), *t4 = reinterpret_cast<float4 *>(lat->tail_partial.as<float>());
-    const int *pt = lat->csr_pt.as<int>(), *vid = lat->sort_keys_out.as<int>();
+    const int *pt = lat->csr_pt.as<int>(), *vid = lat->csr_vid.as<int>();
     const StackSource stack{rec, recw, L, d};
     const size_t wide_lds = (size_t)(kBlock / 64) * 64 * recw * 4;   // <= 64 KB: plx_apply_backward bounds recw
     const int grid = tile_grid(nwt, g_xcd_remap);

@@ -31,8 +31,18 @@ def shard_bounds(n, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+# A group of one rank needs no communication and normally issues none.  FORCE_COLLECTIVES = True makes every collective
+# below run even then (tests/checks/rccl_world1.py: one rank on one GPU still drives RCCL through the exact calls an
+# 8-GPU job makes -- init with device_id, all_gather of keys, all_reduce of the vertex values, barrier with device_ids).
+FORCE_COLLECTIVES = False
+
+
+def _collective_needed(group=None):
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
+
+
 def all_reduce_sum(t, group=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_needed(group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -99,7 +109,7 @@ class ShardedLatticeMVM:
         recycled): local structure, ONE all-gather of the per-rank vertex keys, merge.  Used by every
         hyper-parameter step of a training loop and by bench.py's rebuild cadence."""
         self._vd = None                      # m may change: the accumulators are re-allocated on the next MVM
-        if self.world == 1:
+        if self.world == 1 and not (FORCE_COLLECTIVES and dist.is_initialized()):
             self.n = ref_local.shape[0]
             self.lo, self.hi = 0, self.n
             self.lattice.build(ref_local, coeffs)

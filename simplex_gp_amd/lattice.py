@@ -215,9 +215,16 @@ class Lattice:
             out[k] = [x for x in names.split("+") if x]
         return out
 
+    def prepare(self, vd=1):
+        """Build now every table an MVM with vd columns will read (otherwise the first such MVM builds them)."""
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_prepare(self._h, int(vd), _stream_ptr(self.device))
+        nv.check(rc, "plx_prepare")
+        return self
+
     @property
     def block_rows(self):
-        """Rows of the block tables (0: the lattice uses the vertex-sorted CSR path)."""
+        """Rows of the block tables (0: not built yet -- see prepare() -- or the lattice uses the vertex-sorted CSR path)."""
         return int(nv.lib().plx_block_rows(self._h))
 
     def apply_times_ms(self):

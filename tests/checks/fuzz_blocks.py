@@ -42,7 +42,7 @@ for c in range(cases):
     nv.check(lib.plx_tune(b"unpermute_gather", c % 3 != 0), "plx_tune")
     nv.check(lib.plx_tune(b"vertex_order", 2 if c % 4 < 2 else 0), "plx_tune")
     lat = plx.Lattice().build(x, taps)
-    used = lat.block_rows > 0
+    used = lat.prepare(1).block_rows > 0
     out = lat.apply(s)
     errs = [float(np.linalg.norm(out.cpu().numpy().astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20))]
     lat.set_lattice_row_order(True)

@@ -447,12 +447,12 @@ def test_every_tap_order_at_every_row_width(plx, ntaps):
         oracle.set_exact_mode(True)
 
 
-@pytest.mark.parametrize("threads", [256, 512, 1024])
-def test_block_tables_equal_csr_path(plx, threads):
-    """vd = 1 through the block tables (plx_block.hip: block-local splat + per-vertex combine, LDS-staged slice) against
-    the vertex-sorted CSR kernels and the oracle: caller row order, lattice row order, the affine epilogue, an owned
-    row range (sharded structure) and shapes where blocks are ragged (n not a multiple of the block, d + 1 not a
-    divisor of the block's corner count)."""
+@pytest.mark.parametrize("block_e", [16, 24])
+def test_block_tables_equal_csr_path(plx, block_e):
+    """vd = 1 through the block tables (plx_block.hip: block-local splat + per-vertex combine, LDS-staged slice; blocks of
+    256 * block_e corners) against the vertex-sorted CSR kernels and the oracle: caller row order, lattice row order, the
+    affine epilogue, an owned row range (sharded structure) and shapes where blocks are ragged (n not a multiple of the
+    block, d + 1 not a divisor of the block's corner count)."""
     from simplex_gp_amd import _native as nv
     lib = nv.lib()
     taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
@@ -468,31 +468,28 @@ def test_block_tables_equal_csr_path(plx, threads):
             x, s = torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda()
             nv.check(lib.plx_tune(b"block_path", 0), "plx_tune")
             a = plx.Lattice().build(x, taps)
-            assert a.block_rows == 0
             out_a = a.apply(s).clone()
+            assert a.block_rows == 0
             va = a.splat(s).clone()
             nv.check(lib.plx_tune(b"block_path", 2), "plx_tune")
-            nv.check(lib.plx_tune(b"block_threads", threads), "plx_tune")
+            nv.check(lib.plx_tune(b"block_e", block_e), "plx_tune")
             b = plx.Lattice().build(x, taps)
-            assert b.block_rows > 0 and b.m == a.m
-            assert b.stage_kernels() is not None
+            assert b.block_rows == 0                     # the tables are built by their first user ...
+            assert b.prepare(1).block_rows > 0 and b.m == a.m      # ... or by plx_prepare
             out_b = b.apply(s).clone()
             assert "splat_block_kernel" in b.stage_kernels()["splat"] and b.stage_kernels()["slice"][0] == "slice_block_kernel"
             assert rel_l2(out_b.cpu().numpy(), want) <= TOL_ORACLE, (n, d)
-            assert rel_l2(out_b.cpu().numpy(), out_a.cpu().numpy()) <= 2e-6, (n, d)
+            assert rel_l2(out_b.cpu().numpy(), out_a.cpu().numpy()) <= 5e-6, (n, d)          # two fixed summation trees
             # stage by stage: same vertex numbering in both builds
             vb = b.splat(s)
-            assert rel_l2(vb.cpu().numpy(), va.cpu().numpy()) <= 2e-6
+            assert rel_l2(vb.cpu().numpy(), va.cpu().numpy()) <= 5e-6
             blurred = a.blur(va.clone(), vd=1)
             assert torch.equal(b.slice(blurred, vd=1), a.slice(blurred, vd=1))        # same arithmetic, same order
             assert torch.equal(b.apply(s), out_b)                                       # reproducible bits
-            if threads == 256:
-                # the per-block LDS sort and the global radix sort of (block, vertex) keys order the corners identically
-                nv.check(lib.plx_tune(b"block_lds_sort", 0), "plx_tune")
-                c = plx.Lattice().build(x, taps)
-                nv.check(lib.plx_tune(b"block_lds_sort", 1), "plx_tune")
-                assert c.block_rows == b.block_rows and torch.equal(c.apply(s), out_b), (n, d)
-                c.close()
+            # the combine kernel that numbers vertices by counting row ends against the one that reads their ids
+            nv.check(lib.plx_tune(b"block_dense_combine", 0), "plx_tune")
+            assert torch.equal(b.splat(s), vb)
+            nv.check(lib.plx_tune(b"block_dense_combine", 1), "plx_tune")
             # affine epilogue and lattice row order
             ss = torch.tensor([0.7, 0.3], device="cuda")
             assert rel_l2(b.apply_affine(s, ss).cpu().numpy(), (0.7 * out_b + 0.3 * s).cpu().numpy()) <= 1e-6
@@ -500,9 +497,10 @@ def test_block_tables_equal_csr_path(plx, threads):
             out_l = b.from_lattice_order(b.apply(b.to_lattice_order(s)))
             b.set_lattice_row_order(False)
             assert torch.equal(out_l, out_b)
-            # multi-column right-hand sides on a lattice with block tables use the CSR built on demand
+            # multi-column right-hand sides on a lattice with block tables use the CSR built on demand, next to them
             s3 = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32)).cuda()
             assert rel_l2(b.apply(s3).cpu().numpy(), a.apply(s3).cpu().numpy()) <= 1e-6
+            assert torch.equal(b.apply(s), out_b)                                       # and the single-column tables still stand
             # an owned row range: per-shard splats add up, per-shard slices tile the output
             if n >= 4099:
                 from simplex_gp_amd.distributed import shard_bounds
@@ -510,8 +508,8 @@ def test_block_tables_equal_csr_path(plx, threads):
                 for r in range(3):
                     lo, hi = shard_bounds(n, 3, r)
                     lat = plx.Lattice().build(x, taps, shard=(r, 3))
-                    assert lat.block_rows > 0
                     part = lat.splat(s[lo:hi])
+                    assert lat.block_rows > 0 and "block" in lat.stage_kernels()["splat"][0]
                     total = part.clone() if total is None else total + part
                     parts.append((lat, lo, hi))
                 got = torch.empty_like(out_b)
@@ -523,8 +521,8 @@ def test_block_tables_equal_csr_path(plx, threads):
             b.close()
     finally:
         nv.check(lib.plx_tune(b"block_path", 1), "plx_tune")
-        nv.check(lib.plx_tune(b"block_threads", 256), "plx_tune")
-        nv.check(lib.plx_tune(b"block_lds_sort", 1), "plx_tune")
+        nv.check(lib.plx_tune(b"block_e", 0), "plx_tune")
+        nv.check(lib.plx_tune(b"block_dense_combine", 1), "plx_tune")
 
 
 def test_blur_axis_pairs_equal_single_axis_passes(plx):
@@ -655,40 +653,40 @@ def test_one_shot_filter_skips_what_only_pays_over_many_mvms(plx):
         many.close(); once.close()
 
 
-def test_block_tables_are_left_to_their_first_user(plx):
-    """A lattice object that served only multi-column MVMs (a training loop: build, CG on [y | probes]) builds its next
-    lattice without the block tables; the first single-column MVM builds them then, with the same result as an eager
-    build.  One-shot multi-column filters skip them as well."""
+def test_tables_are_built_by_their_first_user(plx):
+    """plx_build builds the lattice structure only; the splat / slice tables (block tables, their vertex-sorted half, the
+    vertex-sorted CSR) are built by the first MVM that reads them, or by plx_prepare.  Whatever the order of first use --
+    including multi-column, single-column, multi-column on one lattice, which once shared a sort buffer between the
+    block build and the CSR -- the results equal those of a lattice prepared up front."""
     rng = np.random.default_rng(23)
     n, d = 200000, 8
     taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
-    x1 = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda()
     x2 = torch.from_numpy((rng.standard_normal((n, d)) / 0.9).astype(np.float32)).cuda()
     v1 = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).cuda()
     v11 = torch.from_numpy(rng.standard_normal((n, 11)).astype(np.float32)).cuda()
+    v20 = torch.from_numpy(rng.standard_normal((n, 20)).astype(np.float32)).cuda()
     fresh = plx.Lattice().build(x2, taps)
-    want1, want11 = fresh.apply(v1).clone(), fresh.apply(v11).clone()
+    assert fresh.block_rows == 0
+    fresh.prepare(1).prepare(11).prepare(20)
     assert fresh.block_rows > 0
+    want1, want11, want20 = fresh.apply(v1).clone(), fresh.apply(v11).clone(), fresh.apply(v20).clone()
+    for order in ((v20, v1, v11, v20), (v11, v1, v20, v11), (v1, v20, v11, v1)):
+        lat = plx.Lattice().build(x2, taps)
+        for v in order:
+            want = {1: want1, 11: want11, 20: want20}[v.shape[1]]
+            assert torch.equal(lat.apply(v), want), [t.shape[1] for t in order]
+        assert lat.block_rows == fresh.block_rows
+        lat.build(x2, taps)                            # a rebuild starts over: nothing of the old tables is trusted
+        assert lat.block_rows == 0 and torch.equal(lat.apply(v11), want11) and torch.equal(lat.apply(v1), want1)
+        lat.close()
+    # timing: a build no longer contains the tables; prepare() does
     lat = plx.Lattice()
     lat.set_timing(True)
-    lat.build(x1, taps)
-    lat.build(x1, taps)                                # (the first build also allocates)
-    eager_ms = lat.build_times_ms()["csr"]
-    lat.apply(v11)                                     # multi-column use only
-    lat.build(x2, taps)                                # -> block tables deferred
-    deferred_ms = lat.build_times_ms()["csr"]
-    assert deferred_ms < 0.25 * eager_ms, (eager_ms, deferred_ms)
-    assert torch.equal(lat.apply(v11), want11)
-    out1 = lat.apply(v1)                               # first single-column MVM builds them
-    assert lat.stage_kernels()["splat"][0] == "splat_block_kernel" and lat.block_rows == fresh.block_rows
-    assert torch.equal(out1, want1)
-    lat.build(x2, taps)                                # the lattice served single-column MVMs: eager again
-    assert lat.build_times_ms()["csr"] > 0.5 * eager_ms
+    lat.build(x2, taps); lat.build(x2, taps)
+    assert lat.build_times_ms()["csr"] < 0.05
     lat.set_timing(False)
-    # block_rows alone also triggers the deferred build
-    lat.apply(v11); lat.build(x2, taps); lat.apply(v11); lat.build(x2, taps)
-    assert lat.block_rows == fresh.block_rows and torch.equal(lat.apply(v1), want1)
-    # one-shot multi-column filter: result unchanged
-    assert torch.equal(plx.Lattice().filter_once(v11, x2, taps), want11) or \
-        rel_l2(plx.Lattice().filter_once(v11, x2, taps).cpu().numpy(), want11.cpu().numpy()) <= 1e-6
+    # one-shot filters: results unchanged (a multi-column one-shot call keeps to the CSR kernels)
+    once = plx.Lattice().filter_once(v11, x2, taps)
+    assert rel_l2(once.cpu().numpy(), want11.cpu().numpy()) <= 1e-6
+    assert rel_l2(plx.Lattice().filter_once(v1, x2, taps).cpu().numpy(), want1.cpu().numpy()) <= 1e-6
     lat.close(); fresh.close()
