@@ -88,11 +88,14 @@ int plx_create(int device, plx_lattice **out)
     if (!g.ok) { set_error("plx_create: cannot select device %d", device); return PLX_ERR_HIP; }
     plx_lattice *L = new plx_lattice();
     L->device = device;
-    if (hipHostMalloc((void **)&L->h_pinned, 256, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void **)&L->h_pinned, 256, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&L->h_mail, 256, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         set_error("plx_create: hipHostMalloc failed");
+        if (L->h_pinned) (void)hipHostFree(L->h_pinned);
         delete L;
         return PLX_ERR_HIP;
     }
+    memset(L->h_mail, 0, 256);
     // on failure plx_destroy releases whatever was created so far (events not yet created are null)
     for (auto &e : L->ev)
         if (hipEventCreate(&e) != hipSuccess) { e = nullptr; plx_destroy(L); set_error("plx_create: hipEventCreate failed"); return PLX_ERR_HIP; }
@@ -108,6 +111,7 @@ void plx_destroy(plx_lattice *L)
     DeviceGuard g(L->device);
     for (DevBuf *b : all_bufs(L)) release(*b);
     if (L->h_pinned) (void)hipHostFree(L->h_pinned);
+    if (L->h_mail) (void)hipHostFree(L->h_mail);
     for (auto &e : L->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : L->tev) if (e) (void)hipEventDestroy(e);
     delete L;

@@ -574,11 +574,11 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
                                  L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->srow.as<uint16_t>(), L->srow_stride,
                                  L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), stream));
     blk_scan_kernel<<<1, kBlock, 0, stream>>>(L->brow_ptr.as<int>(), (int)nblocks, L->counters.as<int>() + 40);
-    PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned + 40, L->counters.as<int>() + 40, 8, hipMemcpyDeviceToHost, stream));
-    PLX_HIP_TRY(hipStreamSynchronize(stream));          // R_b sizes the row tables
-    const int64_t nrows = L->h_pinned[40];
+    int h_rows[2];
+    PLX_TRY(read_back(L, L->counters.as<int>() + 40, 2, h_rows, stream));   // R_b sizes the row tables
+    const int64_t nrows = h_rows[0];
     L->n_brows = nrows;
-    L->blk_max_rows = L->h_pinned[41];
+    L->blk_max_rows = h_rows[1];
     if (g_block_path == 1 && 10 * nrows > 7 * nnz) return PLX_OK;   // too little sharing inside blocks: CSR path
     PLX_TRY(ensure(L->brow_vid, (size_t)nrows * 4 + 16));
     PLX_TRY(compact_block_rows(L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), cpb, nblocks, L->brow_vid.as<int>(), stream));
@@ -604,16 +604,16 @@ int ensure_s2(plx_lattice *L, hipStream_t stream)
     PLX_TRY(ensure(L->s2_wave, (size_t)(L->n_s2waves + 2) * 4));
     PLX_TRY(ensure(L->s2_wave_v, (size_t)(L->n_s2waves + 2) * 4));
     PLX_TRY(ensure(L->partial, (size_t)nrows * 4 + 16));
-    size_t temp2 = 0;
-    PLX_TRY(sort_pairs_temp_bytes(nrows, vbits, &temp2));
-    PLX_TRY(ensure(L->sort_temp, temp2 + 16));
+    PLX_TRY(ensure(L->sort_temp, radix_temp_bytes(nrows)));
     PLX_TRY(ensure(L->sort_keys_in, (size_t)nrows * 4 + 64));
     PLX_TRY(ensure(L->sort_vals_in, (size_t)nrows * 4 + 64));
     blk_iota_kernel<<<ceil_div(nrows, kBlock), kBlock, 0, stream>>>(L->brow_vid.as<int>(), (int)nrows,
                                                                     L->sort_keys_in.as<uint32_t>(),
                                                                     L->sort_vals_in.as<uint32_t>());
-    PLX_TRY(sort_pairs(L->sort_temp.p, temp2, L->sort_keys_in.as<uint32_t>(), L->s2_vid.as<uint32_t>(),
-                       L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, stream));
+    int second = 0;
+    PLX_TRY(radix_sort_pairs32(L->sort_temp.p, L->sort_keys_in.as<uint32_t>(), L->s2_vid.as<uint32_t>(),
+                               L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, &second, stream));
+    if (!second) { std::swap(L->sort_keys_in, L->s2_vid); std::swap(L->sort_vals_in, L->s2_idx); }
     blk_rowptr_kernel<<<ceil_div(m + 1, kBlock), kBlock, 0, stream>>>(L->s2_vid.as<uint32_t>(), (int)nrows, (int)m,
                                                                       L->s2_ptr.as<int>());
     blk_s2_finish_kernel<<<ceil_div(std::max<int64_t>(nrows, L->n_s2waves + 1), kBlock), kBlock, 0, stream>>>(

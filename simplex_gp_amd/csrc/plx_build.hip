@@ -37,12 +37,16 @@
 
 #include <math.h>
 
+#include <string.h>
+
 #include <algorithm>
+#include <chrono>
 #include <utility>
 
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
+int g_order_compact = 1; // 1: point-order keys over exactly the bits every coordinate's range needs (one small read-back per build); 0: a fixed 7 / 8 bits per coordinate
 int g_order_zcurve = 1;  // 1: points ordered along the Z-curve of their rounded lattice coordinates; 0: lexicographically; 2: Z-curve of the blur-axis coordinates
 int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only and mirrors the hits
                               // (fine regime 7.2 -> 4.9 ms; an occupancy bitmap on top did not pay)
@@ -139,6 +143,52 @@ __device__ __forceinline__ int block_exclusive_scan(int val, int *total)
     return base + incl - val;
 }
 
+__global__ void iota_kernel(uint32_t *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+
+// ----------------------------------------------------------------------------
+// read_back: a few ints from device memory to the host WITHOUT synchronising the stream.  A one-wave kernel stores them
+// into the lattice's mailbox (coherent pinned host memory) and then, release-ordered at system scope, a sequence number;
+// the host spins on that word.  A hipMemcpyAsync + hipStreamSynchronize pair costs a copy submission and a wake-up
+// (~20-30 us each on this platform; a build has three to four of them); the spin sees the value a few microseconds after
+// the kernel wrote it.  If the word does not arrive within a few milliseconds (a long queue ahead of the build on this
+// stream) the host falls back to waiting for the stream.
+__global__ void mailbox_kernel(const int *__restrict__ src, int count, int *mail, int seq)
+{
+    const int t = threadIdx.x;
+    if (t < count) __hip_atomic_store(mail + 1 + t, src[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(mail, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int read_back(plx_lattice *L, const int *d_src, int count, int *h_dst, hipStream_t stream)
+{
+    if (count < 1 || count > 62) { set_error("read_back: %d values", count); return PLX_ERR_INVALID; }
+    const int seq = ++L->mail_seq;
+    mailbox_kernel<<<1, 64, 0, stream>>>(d_src, count, L->h_mail, seq);
+    PLX_HIP_TRY(hipGetLastError());
+    volatile int *mail = L->h_mail;
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (__atomic_load_n(const_cast<int *>(mail), __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 1023) == 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2e-3) {
+            PLX_HIP_TRY(hipStreamSynchronize(stream));
+            break;
+        }
+    }
+    if (__atomic_load_n(const_cast<int *>(mail), __ATOMIC_ACQUIRE) != seq) {
+        set_error("read_back: the mailbox word did not arrive");
+        return PLX_ERR_HIP;
+    }
+    for (int i = 0; i < count; ++i) h_dst[i] = mail[1 + i];
+    return PLX_OK;
+}
+
 // h:398-402, same association order as the reference expression
 template <int D>
 __device__ __forceinline__ void elevate(const float (&pos)[D], const ScaleArgs &sf, float (&el)[D + 1])
@@ -151,15 +201,106 @@ __device__ __forceinline__ void elevate(const float (&pos)[D], const ScaleArgs &
 }
 
 // ----------------------------------------------------------------------------
-// order: sort key of a point = (shard, rounded lattice coordinates, most
-// significant first).  Coordinates are clamped into `bits` bits each: a clamp
-// only costs locality for far outliers, never correctness.
+// order: sort key of a point = (shard, rounded lattice coordinates bit-interleaved along their Z-curve, or
+// lexicographically).  The keys are COMPACT: a first pass finds the range of every rounded coordinate, the host reads
+// the 2 (d+1) numbers back through the mailbox (read_back: no stream synchronisation) and gives every coordinate exactly
+// the bits its range needs, so the radix sort runs over the significant bits only (N = 1e6, d = 8, l = 1: 36 bits
+// instead of 63).  Outliers cost bits, never correctness: past 62 key bits the widest coordinates lose low bits.
 
+constexpr int kMaxOrderCoords = 16;
 struct OrderArgs {
-    int n_shards, bits, ncoord;      // ncoord = min(d+1, 16) leading coordinates are used
+    int n_shards, ncoord;            // ncoord = min(d+1, 16) leading coordinates are used
     int zcurve;                      // g_order_zcurve
+    int maxbits;                     // widest coordinate
     long long base, extra;           // shard layout: first `extra` shards have base+1 rows
+    int lo[kMaxOrderCoords], bits[kMaxOrderCoords], drop[kMaxOrderCoords];   // per coordinate: smallest value, key bits, low bits dropped
 };
+
+// rounded lattice coordinates of a point (the cell of its nearest zero-colour vertex, in units of d+1)
+template <int D>
+__device__ __forceinline__ void order_coords(const float *__restrict__ x, int p, const ScaleArgs &sf, int zcurve, int (&q)[D + 1])
+{
+    constexpr int D1 = D + 1;
+    float pos[D], el[D1];
+#pragma unroll
+    for (int i = 0; i < D; ++i) pos[i] = x[(size_t)p * D + i];
+    elevate<D>(pos, sf, el);
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+        float c = rintf(el[i] * (1.0f / (float)D1));
+        c = fminf(fmaxf(c, -1.0e6f), 1.0e6f);                // NaN -> -1e6 (fmaxf), rejected later by embed
+        q[i] = (int)c;
+    }
+    if (zcurve == 2) {
+        // the vertices' own curve (renumber_vertices): blur-axis coordinates a_i = q_d - q_i, i < d.  A point and the
+        // vertices of its simplex differ by at most one step in every a_i, so points and vertices that meet in splat and
+        // slice are close on the same curve.  Measured against mode 1 (N = 1e6, d = 8): +-3 % per MVM (l = 1.0 93.7 vs
+        // 91.4 us, l = 0.5 299 vs 309, CG iteration 34.8 vs 35.0 ms): not the default.
+#pragma unroll
+        for (int i = 0; i < D; ++i) q[i] = q[D] - q[i];
+    }
+}
+
+// range[2c] = max q_c, range[2c+1] = max -q_c over all points (range[] preset to a very negative number)
+template <int D>
+__global__ __launch_bounds__(kBlock) void coord_range_kernel(const float *__restrict__ x, int n, ScaleArgs sf, int zcurve,
+                                                             int ncoord, int *__restrict__ range)
+{
+    constexpr int D1 = D + 1;
+    __shared__ int red[kBlock / 64][2 * kMaxOrderCoords];
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int q[D1];
+    order_coords<D>(x, min(p, n - 1), sf, zcurve, q);          // a padding thread repeats the last point: no effect on the range
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+        if (i < kMaxOrderCoords) {
+            int hi = q[i], lo = -q[i];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                hi = max(hi, __shfl_xor(hi, off));
+                lo = max(lo, __shfl_xor(lo, off));
+            }
+            if (lane == 0) { red[wave][2 * i] = hi; red[wave][2 * i + 1] = lo; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * ncoord) {
+        int v = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) v = max(v, red[w][threadIdx.x]);
+        // (a plain read first: after the first few workgroups hardly any extreme still moves, and 4,000 workgroups
+        // adding to the same 18 words one after the other were 50 us of a 0.8 ms build)
+        if (v > __hip_atomic_load(&range[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&range[threadIdx.x], v);
+    }
+}
+
+// bit widths of a compact interleaved key from per-coordinate ranges; returns the number of key bits below `head_bits`
+// reserved bits (shard id), at most 62 in all
+static int layout_key_bits(const int *range, int ncoord, int head_bits, int *lo, int *bits, int *drop, int *maxbits)
+{
+    int total = 0;
+    for (int c = 0; c < ncoord; ++c) {
+        const long long hi = range[2 * c], lw = -(long long)range[2 * c + 1];
+        lo[c] = (int)lw;
+        long long span = hi - lw;                               // values 0 .. span
+        int b = 0;
+        while (span >> b) ++b;
+        bits[c] = b;
+        drop[c] = 0;
+        total += b;
+    }
+    while (total + head_bits > 62) {                           // outliers: the widest coordinate gives up its lowest bit
+        int w = 0;
+        for (int c = 1; c < ncoord; ++c)
+            if (bits[c] > bits[w]) w = c;
+        if (bits[w] == 0) break;
+        --bits[w]; ++drop[w]; --total;
+    }
+    *maxbits = 0;
+    for (int c = 0; c < ncoord; ++c) *maxbits = std::max(*maxbits, bits[c]);
+    return total;
+}
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void sortkey_kernel(const float *__restrict__ x, int n, ScaleArgs sf,
@@ -169,50 +310,34 @@ __global__ __launch_bounds__(kBlock) void sortkey_kernel(const float *__restrict
     constexpr int D1 = D + 1;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
-    float pos[D], el[D1];
-#pragma unroll
-    for (int i = 0; i < D; ++i) pos[i] = x[(size_t)p * D + i];
-    elevate<D>(pos, sf, el);
+    int q[D1];
+    order_coords<D>(x, p, sf, oa.zcurve, q);
     const long long split = (oa.base + 1) * oa.extra;
     const unsigned long long shard =
         (oa.n_shards <= 1) ? 0ull
         : (unsigned long long)((p < split) ? p / (oa.base + 1) : oa.extra + (p - split) / (oa.base > 0 ? oa.base : 1));
     unsigned long long key = shard;
-    const int half = 1 << (oa.bits - 1), top = (1 << oa.bits) - 1;
-    int q[D1];
 #pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        float c = rintf(el[i] * (1.0f / (float)D1));
-        c = fminf(fmaxf(c, -1.0e6f), 1.0e6f);                // NaN -> -1e6 (fmaxf), rejected later by embed
-        q[i] = (int)c;
-    }
-    if (oa.zcurve == 2) {
-        // the vertices' own curve (renumber_vertices): blur-axis coordinates a_i = q_d - q_i, i < d.  A point and the
-        // vertices of its simplex differ by at most one step in every a_i, so points and vertices that meet in splat and
-        // slice are close on the same curve.  Measured against mode 1 (N = 1e6, d = 8): +-3 % per MVM (l = 1.0 93.7 vs
-        // 91.4 us, l = 0.5 299 vs 309, CG iteration 34.8 vs 35.0 ms): not the default.
-#pragma unroll
-        for (int i = 0; i < D; ++i) q[i] = q[D] - q[i];
-    }
-#pragma unroll
-    for (int i = 0; i < D1; ++i) {
-        const int v = q[i] + half;
-        q[i] = v < 0 ? 0 : (v > top ? top : v);
-    }
+    for (int i = 0; i < D1; ++i)
+        if (i < kMaxOrderCoords && i < oa.ncoord) {
+            const int v = (q[i] - oa.lo[i]) >> oa.drop[i];
+            const int top = (1 << oa.bits[i]) - 1;
+            q[i] = v < 0 ? 0 : (v > top ? top : v);
+        }
     if (oa.zcurve) {
-        // Z-order: bit b of every coordinate before bit b-1 of any.  Every blur axis changes all d+1
+        // Z-order: bit b of every coordinate (that has one) before bit b-1 of any.  Every blur axis changes all d+1
         // coordinates, so under the lexicographic order each neighbour is about a slab of the leading
         // coordinate away (median 13k-320k vertex ids at N = 1e6, d = 8, l = 0.69); along the Z-curve
         // the medians are 6k-16k and the medium-regime blur is 3-5 % faster (tools/ab_order.py).
         // Ordering by the blur-axis coordinates q_i - q_d instead was measured too: no gain.
-        for (int b = oa.bits - 1; b >= 0; --b)
+        for (int b = oa.maxbits - 1; b >= 0; --b)
 #pragma unroll
             for (int i = 0; i < D1; ++i)
-                if (i < oa.ncoord) key = (key << 1) | (unsigned long long)((q[i] >> b) & 1);
+                if (i < kMaxOrderCoords && i < oa.ncoord && oa.bits[i] > b) key = (key << 1) | (unsigned long long)((q[i] >> b) & 1);
     } else {
 #pragma unroll
         for (int i = 0; i < D1; ++i)
-            if (i < oa.ncoord) key = (key << oa.bits) | (unsigned long long)q[i];
+            if (i < kMaxOrderCoords && i < oa.ncoord) key = (key << oa.bits[i]) | (unsigned long long)q[i];
     }
     keys[p] = key;
     iota[p] = (uint32_t)p;
@@ -334,6 +459,12 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__
 // index e = p*(d+1)+r among the corners that share the slot's key.  Invariant:
 // every value ever stored in a slot belongs to a corner with the same key, so a
 // stale plain load can only cost an extra atomic, never a wrong match.
+// (Round 3 tried a workgroup form: one workgroup per 256 consecutive points de-duplicates its 2,304 corners in an LDS
+// hash table -- ~700 distinct keys at N = 1e6, d = 8 -- and only the distinct keys probe the global table, dealt evenly
+// to the threads.  Structure bit-exact, but N = 1e6 203 -> 194 us, N = 4e6 667 -> 573 us, and the fine regime (every
+// key distinct) 428 -> 591 us: the kernel is bound by the latency of its dependent random accesses -- a wave lives
+// ~17 us for four of them -- and the LDS stage adds a dependent key compare per corner while removing only the cheap
+// duplicate probes that the plane-adjacent dispatch order below already serves from the L2s.  Dropped.)
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restrict__ ekeys, int n,
@@ -719,13 +850,12 @@ int g_insert_plane_fast = 1;
 int g_vertex_order = 1;      // 0: first touch; 1: Morton order where it pays (kMortonMinVertices <= m <= 0.9 corners); 2: always
 constexpr int kMortonMinVertices = 65536;
 
+// blur-axis coordinates a_c = (k_d - k_c) / (d+1), c < d, of a vertex (k_d = -sum k_c; exact: all coordinates of a lattice
+// point agree mod d+1)
 template <int D>
-__global__ __launch_bounds__(kBlock) void vertex_code_kernel(const uint32_t *__restrict__ vkeys, int m, int bits,
-                                                             unsigned long long *__restrict__ code, uint32_t *__restrict__ ids)
+__device__ __forceinline__ void vertex_axis_coords(const uint32_t *__restrict__ vkeys, int v, int (&a)[D])
 {
     constexpr int DW = (D + 1) / 2;
-    const int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= m) return;
     uint32_t kw[DW];
     load_key<DW>(vkeys, (size_t)v, kw);
     int key[D], kd = 0;
@@ -734,17 +864,64 @@ __global__ __launch_bounds__(kBlock) void vertex_code_kernel(const uint32_t *__r
         key[c] = (int)(int16_t)((kw[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu);
         kd -= key[c];
     }
-    const int half = 1 << (bits - 1), top = (1 << bits) - 1;
+#pragma unroll
+    for (int c = 0; c < D; ++c) a[c] = (kd - key[c]) / (D + 1);
+}
+
+// range[2c] = max a_c, range[2c+1] = max -a_c over the vertices (preset to a very negative number); c < min(d, 16)
+template <int D>
+__global__ __launch_bounds__(kBlock) void vertex_range_kernel(const uint32_t *__restrict__ vkeys, int m, int ncoord,
+                                                              int *__restrict__ range)
+{
+    __shared__ int red[kBlock / 64][2 * kMaxOrderCoords];
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int a[D];
+    vertex_axis_coords<D>(vkeys, min(v, m - 1), a);
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        const int q = (kd - key[c]) / (D + 1) + half;       // exact: all coordinates of a lattice point agree mod d+1
-        a[c] = q < 0 ? 0 : (q > top ? top : q);              // a clamp costs locality for far outliers only
-    }
-    unsigned long long z = 0;
-    for (int b = bits - 1; b >= 0; --b)
+        if (c < kMaxOrderCoords) {
+            int hi = a[c], lo = -a[c];
 #pragma unroll
-        for (int c = 0; c < D; ++c) z = (z << 1) | (unsigned long long)((a[c] >> b) & 1);
+            for (int off = 32; off >= 1; off >>= 1) {
+                hi = max(hi, __shfl_xor(hi, off));
+                lo = max(lo, __shfl_xor(lo, off));
+            }
+            if (lane == 0) { red[wave][2 * c] = hi; red[wave][2 * c + 1] = lo; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * ncoord) {
+        int r = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) r = max(r, red[w][threadIdx.x]);
+        if (r > __hip_atomic_load(&range[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&range[threadIdx.x], r);
+    }
+}
+
+struct CodeArgs { int ncoord, maxbits; int lo[kMaxOrderCoords], bits[kMaxOrderCoords], drop[kMaxOrderCoords]; };
+
+// Morton code over exactly the bits every coordinate's range needs (coordinates past the 16th do not take part)
+template <int D>
+__global__ __launch_bounds__(kBlock) void vertex_code_kernel(const uint32_t *__restrict__ vkeys, int m, CodeArgs ca,
+                                                             unsigned long long *__restrict__ code, uint32_t *__restrict__ ids)
+{
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= m) return;
+    int a[D];
+    vertex_axis_coords<D>(vkeys, v, a);
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (c < kMaxOrderCoords) {
+            const int q = (a[c] - ca.lo[c]) >> ca.drop[c];
+            const int top = (1 << ca.bits[c]) - 1;
+            a[c] = q < 0 ? 0 : (q > top ? top : q);
+        }
+    unsigned long long z = 0;
+    for (int b = ca.maxbits - 1; b >= 0; --b)
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+            if (c < kMaxOrderCoords && ca.bits[c] > b) z = (z << 1) | (unsigned long long)((a[c] >> b) & 1);
     code[v] = z;
     ids[v] = (uint32_t)v;
 }
@@ -780,13 +957,10 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
     if (g_vertex_order == 0 || m < 2) return PLX_OK;
     if (g_vertex_order == 1 && (L->single_use || m < kMortonMinVertices || 10 * (int64_t)m > 9 * corners)) return PLX_OK;
     L->vertex_order = 1;
-    int bits = 64 / D;
-    if (bits > 8) bits = 8;
-    if (bits < 1) return PLX_OK;                              // d > 64 does not occur (PLX_MAX_DIM = 32)
-    const int key_bits = bits * D;
-    size_t temp = 0;
-    PLX_TRY(sort_pairs64_temp_bytes(m, key_bits, &temp));
-    PLX_TRY(ensure(L->sort_temp, temp + 16));
+    CodeArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.ncoord = D < kMaxOrderCoords ? D : kMaxOrderCoords;
+    PLX_TRY(ensure(L->sort_temp, radix_temp_bytes(m)));
     PLX_TRY(ensure(L->sortkey_in, (size_t)m * 8));
     PLX_TRY(ensure(L->sortkey_out, (size_t)m * 8));
     PLX_TRY(ensure(L->iota, (size_t)m * 4));
@@ -794,10 +968,19 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
     PLX_TRY(ensure(L->vkeys_alt, (size_t)m * DW * 4 + 16));
     PLX_TRY(ensure(L->vslot_alt, (size_t)m * 4 + 16));
     const int nb = ceil_div(m, kBlock);
-    vertex_code_kernel<D><<<nb, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, bits, L->sortkey_in.as<unsigned long long>(),
+    // range of every blur-axis coordinate -> exactly the code bits it needs (counters[32 ..] preset to a very negative int)
+    int *range = L->counters.as<int>() + 32;
+    PLX_HIP_TRY(hipMemsetAsync(range, 0x80, 2 * kMaxOrderCoords * sizeof(int), stream));
+    vertex_range_kernel<D><<<nb, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, ca.ncoord, range);
+    int h_range[2 * kMaxOrderCoords];
+    PLX_TRY(read_back(L, range, 2 * ca.ncoord, h_range, stream));
+    const int key_bits = layout_key_bits(h_range, ca.ncoord, 0, ca.lo, ca.bits, ca.drop, &ca.maxbits);
+    vertex_code_kernel<D><<<nb, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, ca, L->sortkey_in.as<unsigned long long>(),
                                                      L->iota.as<uint32_t>());
-    PLX_TRY(sort_pairs64(L->sort_temp.p, temp, L->sortkey_in.as<uint64_t>(), L->sortkey_out.as<uint64_t>(),
-                         L->iota.as<uint32_t>(), L->vorder.as<uint32_t>(), m, key_bits, stream));
+    int second = 0;
+    PLX_TRY(radix_sort_pairs64(L->sort_temp.p, L->sortkey_in.as<uint64_t>(), L->sortkey_out.as<uint64_t>(),
+                               L->iota.as<uint32_t>(), L->vorder.as<uint32_t>(), m, key_bits, &second, stream));
+    if (!second) std::swap(L->iota, L->vorder);
     vertex_permute_kernel<D><<<nb, kBlock, 0, stream>>>(L->vorder.as<uint32_t>(), m, L->vkeys.as<uint32_t>(),
                                                         L->vslot.as<uint32_t>(), L->vkeys_alt.as<uint32_t>(),
                                                         L->vslot_alt.as<uint32_t>(), L->table.as<uint32_t>());
@@ -836,24 +1019,20 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
 
     // ---- point order
     OrderArgs oa;
+    memset(&oa, 0, sizeof(oa));
     oa.n_shards = L->n_shards;
     oa.zcurve = g_order_zcurve;
-    oa.ncoord = D1 < 16 ? D1 : 16;
-    if (oa.zcurve == 2) oa.ncoord = D < 16 ? D : 16;
+    oa.ncoord = D1 < kMaxOrderCoords ? D1 : kMaxOrderCoords;
+    if (oa.zcurve == 2) oa.ncoord = D < kMaxOrderCoords ? D : kMaxOrderCoords;
     int shard_bits = 0;
     while ((1 << shard_bits) < L->n_shards) ++shard_bits;
-    oa.bits = (64 - shard_bits) / oa.ncoord;
-    if (oa.bits > 8) oa.bits = 8;
     oa.base = L->n / L->n_shards;
     oa.extra = L->n % L->n_shards;
-    const int key_bits = shard_bits + oa.bits * oa.ncoord;
-    size_t order_temp = 0;
-    PLX_TRY(sort_pairs64_temp_bytes(n, key_bits, &order_temp));
     PLX_TRY(ensure(L->perm, (size_t)n * 4));
     PLX_TRY(ensure(L->iota, (size_t)n * 4));
     PLX_TRY(ensure(L->sortkey_in, (size_t)n * 8));
     PLX_TRY(ensure(L->sortkey_out, (size_t)n * 8));
-    PLX_TRY(ensure(L->sort_temp, order_temp + 16));
+    PLX_TRY(ensure(L->sort_temp, radix_temp_bytes(n)));
 
     PLX_TRY(ensure(L->ekeys, (size_t)E * DW * 4));
     PLX_TRY(ensure(L->ew, (size_t)E * 4));
@@ -868,13 +1047,31 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     PLX_HIP_TRY(hipMemsetAsync(L->table.p, 0xFF, (size_t)cap * 4, stream));
 
     mark();
-    sortkey_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, n, sf, oa, L->sortkey_in.as<unsigned long long>(),
-                                                      L->iota.as<uint32_t>());
     if (g_sort_points) {
-        PLX_TRY(sort_pairs64(L->sort_temp.p, order_temp, L->sortkey_in.as<uint64_t>(), L->sortkey_out.as<uint64_t>(),
-                             L->iota.as<uint32_t>(), L->perm.as<uint32_t>(), n, key_bits, stream));
+        int key_bits;
+        if (g_order_compact) {
+            // range of every rounded coordinate -> exactly the key bits it needs (counters[32 ..] preset to a very negative int)
+            int *range = L->counters.as<int>() + 32;
+            PLX_HIP_TRY(hipMemsetAsync(range, 0x80, 2 * kMaxOrderCoords * sizeof(int), stream));
+            coord_range_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, n, sf, oa.zcurve, oa.ncoord, range);
+            int h_range[2 * kMaxOrderCoords];
+            PLX_TRY(read_back(L, range, 2 * oa.ncoord, h_range, stream));
+            key_bits = shard_bits + layout_key_bits(h_range, oa.ncoord, shard_bits, oa.lo, oa.bits, oa.drop, &oa.maxbits);
+        } else {
+            int b = (64 - shard_bits) / oa.ncoord;
+            if (b > 8) b = 8;
+            for (int c = 0; c < oa.ncoord; ++c) { oa.lo[c] = -(1 << (b - 1)); oa.bits[c] = b; oa.drop[c] = 0; }
+            oa.maxbits = b;
+            key_bits = shard_bits + b * oa.ncoord;
+        }
+        sortkey_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, n, sf, oa, L->sortkey_in.as<unsigned long long>(),
+                                                          L->iota.as<uint32_t>());
+        int second = 0;
+        PLX_TRY(radix_sort_pairs64(L->sort_temp.p, L->sortkey_in.as<uint64_t>(), L->sortkey_out.as<uint64_t>(),
+                                   L->iota.as<uint32_t>(), L->perm.as<uint32_t>(), n, key_bits, &second, stream));
+        if (!second) std::swap(L->iota, L->perm);          // the sorted point ids are wherever the last pass left them
     } else {
-        PLX_HIP_TRY(hipMemcpyAsync(L->perm.p, L->iota.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+        iota_kernel<<<nblocks, kBlock, 0, stream>>>(L->perm.as<uint32_t>(), n);
     }
     embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, L->perm.as<uint32_t>(), n, sf, L->ekeys.as<uint32_t>(),
                                                     L->ew.as<float>(), L->counters.as<int>());
@@ -887,13 +1084,13 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     flag_kernel<<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n, D1,
                                                 L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
     scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
-    PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned, L->counters.p, 8, hipMemcpyDeviceToHost, stream));
-    PLX_HIP_TRY(hipStreamSynchronize(stream));   // m sizes everything below
-    if (L->h_pinned[1] != 0) {
+    int h_cnt[2];
+    PLX_TRY(read_back(L, L->counters.as<int>(), 2, h_cnt, stream));   // m sizes everything below
+    if (h_cnt[1] != 0) {
         set_error("a lattice coordinate left the int16 key range (|x/lengthscale| too large, NaN or Inf)");
         return PLX_ERR_KEY_RANGE;
     }
-    const int m = L->h_pinned[0];
+    const int m = h_cnt[0];
     L->m = m;
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));
     PLX_TRY(ensure(L->vslot, (size_t)m * 4 + 16));
@@ -1019,9 +1216,9 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
     merge_flag_kernel<<<nblocks, kBlock, 0, stream>>>(L->merge_slot.as<uint32_t>(), L->table.as<uint32_t>(), (int)M,
                                                       L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>());
     scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
-    PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned, L->counters.p, 8, hipMemcpyDeviceToHost, stream));
-    PLX_HIP_TRY(hipStreamSynchronize(stream));
-    const int m = L->h_pinned[0];
+    int h_cnt[2];
+    PLX_TRY(read_back(L, L->counters.as<int>(), 2, h_cnt, stream));
+    const int m = h_cnt[0];
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));   // local keys are no longer needed: all_keys holds them
     PLX_TRY(ensure(L->vslot, (size_t)m * 4 + 16));
     merge_assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>(),
@@ -1052,18 +1249,18 @@ int ensure_csr(plx_lattice *L, hipStream_t stream)
     if (L->nnz > 0) {
         int end_bit = 1;
         while ((1ll << end_bit) < (int64_t)m) ++end_bit;
-        size_t temp_bytes = 0;
-        PLX_TRY(sort_pairs_temp_bytes(L->nnz, end_bit, &temp_bytes));
-        PLX_TRY(ensure(L->sort_keys_in, (size_t)L->nnz * 4));
+        PLX_TRY(ensure(L->sort_keys_in, (size_t)L->nnz * 4 + 16));
         PLX_TRY(ensure(L->sort_vals_in, (size_t)L->nnz * 4));
         PLX_TRY(ensure(L->sort_vals_out, (size_t)L->nnz * 4));
-        PLX_TRY(ensure(L->sort_temp, temp_bytes + 16));
+        PLX_TRY(ensure(L->sort_temp, radix_temp_bytes(L->nnz)));
         csr_keys_kernel<<<dim3(ceil_div(n_own, kBlock), D1), kBlock, 0, stream>>>(
             L->evid.as<int>(), n, (int)L->own_begin, n_own, L->sort_keys_in.as<uint32_t>(),
             L->sort_vals_in.as<uint32_t>());
-        PLX_TRY(sort_pairs(L->sort_temp.p, temp_bytes, L->sort_keys_in.as<uint32_t>(),
-                           L->csr_vid.as<uint32_t>(), L->sort_vals_in.as<uint32_t>(),
-                           L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, stream));
+        int second = 0;
+        PLX_TRY(radix_sort_pairs32(L->sort_temp.p, L->sort_keys_in.as<uint32_t>(), L->csr_vid.as<uint32_t>(),
+                                   L->sort_vals_in.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->nnz, end_bit, &second,
+                                   stream));
+        if (!second) { std::swap(L->sort_keys_in, L->csr_vid); std::swap(L->sort_vals_in, L->sort_vals_out); }
         csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
             L->csr_vid.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
             (int)L->own_begin, (int)L->nnz, m, L->perm.as<uint32_t>(), L->csr_pt.as<int>(), L->csr_row.as<int>(),
@@ -1124,11 +1321,11 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         compact_count_kernel<<<cgrid, kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, taps2, L->nquads,
                                                            L->nqwaves, L->cmask.as<uint32_t>(), L->cbase.as<uint32_t>());
         compact_scan_kernel<<<D1, kBlock, 0, stream>>>(L->cbase.as<uint32_t>(), L->nqwaves, L->counters.as<int>());
-        PLX_HIP_TRY(hipMemcpyAsync(L->h_pinned, L->counters.p, 4 * (2 + D1), hipMemcpyDeviceToHost, stream));
-        PLX_HIP_TRY(hipStreamSynchronize(stream));
+        int h_axis[2 + PLX_MAX_DIM + 1];
+        PLX_TRY(read_back(L, L->counters.as<int>(), 2 + D1, h_axis, stream));
         AxisOffsets ao;
         int64_t total = 0;
-        for (int a = 0; a < D1; ++a) { ao.off[a] = total; L->compact_off[a] = total; total += L->h_pinned[2 + a]; }
+        for (int a = 0; a < D1; ++a) { ao.off[a] = total; L->compact_off[a] = total; total += h_axis[2 + a]; }
         L->compact_off[D1] = total;
         const double fill = (double)total / ((double)m * taps2 * D1);
         if (g_compact_nbr == 2 || fill < 0.25) {

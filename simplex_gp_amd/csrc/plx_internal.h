@@ -148,7 +148,9 @@ struct plx_lattice {
     // kernels launched by the last splat / blur / slice on this lattice (names as rocprofv3 shows them, '+'-joined)
     const char *kn_splat = "", *kn_blur = "", *kn_slice = "";
 
-    int32_t *h_pinned = nullptr;   // pinned host staging for {m, err}
+    int32_t *h_pinned = nullptr;   // pinned host staging (exports)
+    int *h_mail = nullptr;         // mailbox of read_back: coherent pinned host memory, word 0 = sequence number, then up to 62 values
+    int mail_seq = 0;
     hipEvent_t ev[8] = {};
     // per-launch timing of plx_apply (timing on): events between consecutive launches
     hipEvent_t tev[PLX_MAX_DIM + 8] = {};
@@ -165,6 +167,7 @@ int build_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);
 int build_local_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);
 int build_merge_impl(plx_lattice *L, const uint32_t *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank,
                      hipStream_t stream);
+int read_back(plx_lattice *L, const int *d_src, int count, int *h_dst, hipStream_t stream);   // a few device ints to the host, no stream synchronisation
 int export_row_ptr(plx_lattice *L, hipStream_t stream);   // fills L->row_ptr on demand (plx_export only)
 int ensure_csr(plx_lattice *L, hipStream_t stream);       // vertex-sorted splat CSR of the current build, built once on demand
 // plx_block.hip (block tables + the vd = 1 kernels that use them)
@@ -176,7 +179,14 @@ int prepare_tables(plx_lattice *L, int vd, hipStream_t stream);
 int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);
 int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStream_t stream, const float *d_affine,
                      const float *d_src);
-// plx_sort.hip (rocPRIM radix sort of (vertex id, entry index) pairs)
+// plx_sort.hip: plx::radix (plx_radix.h) behind plain functions -- stable LSD sort of bits [0, end_bit), ping-ponging between
+// the two buffer pairs; *in_second: 0 = result in keys_a / vals_a, 1 = in keys_b / vals_b
+size_t radix_temp_bytes(int64_t n);
+int radix_sort_pairs64(void *temp, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
+                       int *in_second, hipStream_t stream);
+int radix_sort_pairs32(void *temp, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
+                       int *in_second, hipStream_t stream);
+// (rocPRIM radix sort of (vertex id, entry index) pairs: the CSR of the multi-column kernels)
 int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit,

@@ -38,6 +38,7 @@ extern int g_splat_ablate;
 extern int g_blur_ablate;
 extern int g_sort_points;
 extern int g_order_zcurve;
+extern int g_order_compact;
 extern int g_vertex_order;
 extern int g_insert_plane_fast;
 extern int g_compact_nbr;

@@ -7,7 +7,23 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include "plx_radix.h"
+
 namespace plx {
+
+size_t radix_temp_bytes(int64_t n) { return radix::temp_bytes(n); }
+
+int radix_sort_pairs64(void *temp, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
+                       int *in_second, hipStream_t stream)
+{
+    return radix::sort_pairs<uint64_t>(temp, keys_a, keys_b, vals_a, vals_b, n, end_bit, in_second, stream);
+}
+
+int radix_sort_pairs32(void *temp, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
+                       int *in_second, hipStream_t stream)
+{
+    return radix::sort_pairs<uint32_t>(temp, keys_a, keys_b, vals_a, vals_b, n, end_bit, in_second, stream);
+}
 
 int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes)
 {

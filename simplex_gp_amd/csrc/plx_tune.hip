@@ -21,7 +21,7 @@ int g_blur_ablate = 0;  // diagnostics only: 1 no neighbour gathers, 2 no neighb
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"order_zcurve", &g_order_zcurve}, {"vertex_order", &g_vertex_order}, {"insert_plane_fast", &g_insert_plane_fast}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap}, {"blur_small", &g_blur_small}, {"blur_multi", &g_blur_multi}, {"blur_narrow", &g_blur_narrow}, {"splat_group", &g_splat_group},
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"order_zcurve", &g_order_zcurve}, {"order_compact", &g_order_compact}, {"vertex_order", &g_vertex_order}, {"insert_plane_fast", &g_insert_plane_fast}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap}, {"blur_small", &g_blur_small}, {"blur_multi", &g_blur_multi}, {"blur_narrow", &g_blur_narrow}, {"splat_group", &g_splat_group},
                           {"splat_direct", &g_splat_direct}, {"splat_wide", &g_splat_wide}, {"block_path", &g_block_path}, {"block_e", &g_block_e}, {"block_dense_combine", &g_block_dense_combine}, {"block_ablate", &g_block_ablate}, {"blur_fuse", &g_blur_fuse}, {"blur_fuse_vec", &g_blur_fuse_vec}, {"scatter_store", &g_scatter_store}, {"unpermute_gather", &g_unpermute_gather}, {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
     return t;
 }
