@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- lattice K.v MVMs/sec on MI355X (BASELINE.json metric).
 
-Headline workload (config.workload): synthetic N=1e6 points per GPU, d=8,
+Headline workload (config.workload): synthetic N=1e6 points, d=8,
 RBFLattice order=1 (taps [0.34608543, 1, 0.34608543]), vd=1, lengthscale 1.0,
 x ~ N(0, I) from torch.Generator().manual_seed(1234), driven the way
 the reference's CG loop drives it (BASELINE.json configs[2]): ONE lattice build
@@ -34,14 +34,16 @@ Extra keys on the same JSON line (one GPU):
 Multi-GPU (one rank per GPU, RCCL): points are sharded by contiguous row blocks.
 Build: every rank embeds / inserts its own rows, ONE all-gather of the per-rank
 vertex keys, merge into one numbering.  MVM: splat own rows, ONE all-reduce of the
-vertex accumulators, replicated blur, slice own rows.
-  --scaling weak    (default) 1e6 points PER GPU; value = (n_total / 1e6) x MVMs/s,
-                    i.e. 1e6-point row blocks of K.v produced per second by the job;
-                    `mvms_per_s` is the plain rate of the n_total-point operator
-  --scaling strong  N=1e6 TOTAL (BASELINE.json's metric as written); value = MVMs/s
-  --scaling config4 N=4e6 TOTAL; value = MVMs/s
-Whatever the mode, a multi-GPU line also carries `strong` and `config4` legs, so
-that one 1/2/4/8 sweep yields all three curves.
+vertex accumulators, replicated blur, slice own rows.  `value` is ALWAYS the plain
+rate of one operator, MVMs/s -- never scaled by the problem size:
+  --scaling strong  (default) N=1e6 TOTAL, BASELINE.json's metric as written
+  --scaling config4 N=4e6 TOTAL (BASELINE.json configs[3])
+  --scaling weak    1e6 points PER GPU: the operator grows with the rank count
+Whatever the mode, a multi-GPU line also carries the other legs (`strong`, `config4`
+with vd 1 and 11, `weak_1e6_per_gpu`, `weak_4e6_per_gpu`), each with per-stage us per
+rank and `exchange: {kind, bytes, us}`, so that one 1/2/4/8 sweep yields every curve.
+PLX_BENCH_SINGLE_RANK_RCCL=1 makes a one-GPU run open a world-size-1 "nccl" group and
+take the multi-rank code path (RCCL calls included) -- a rehearsal switch, not a mode.
 """
 import argparse
 import json
@@ -69,12 +71,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--points", dest="n", type=int, default=1_000_000, help="points per GPU (weak) / in total (strong)")
+    ap.add_argument("--points", dest="n", type=int, default=1_000_000, help="points in total (strong) / per GPU (weak)")
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--vd", type=int, default=1)
     ap.add_argument("--ell", type=float, default=1.0)
     ap.add_argument("--rebuild-every", type=int, default=50)
-    ap.add_argument("--scaling", choices=["weak", "strong", "config4"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong", "config4"], default="strong")
     ap.add_argument("--skip-cpu-baseline", dest="no_cpu_baseline", action="store_true")
     ap.add_argument("--skip-fine", dest="no_fine", action="store_true")
     ap.add_argument("--skip-configs", dest="no_configs", action="store_true", help="skip the config 3/4/5 legs")
@@ -107,6 +109,7 @@ def alg_bytes(n, d, m, vd, r):
 
 
 SYNTH_BLOCK = 1_000_000
+PREWARM_MVMS = 200          # untimed MVMs before the warm-up steps (about 20 ms: brings the GPU to its steady clocks)
 
 
 def synth(n, d, vd, seed=1234, lo=0, hi=None):
@@ -286,7 +289,7 @@ class Job:
         self.op.rebuild(self.ref, self.taps)
 
     def mvm(self):
-        if self.ctx.world == 1:
+        if self.ctx.dist is None:
             self.lat.apply(self.v, self.out)
         else:
             self.op.matmul(self.v, self.out)
@@ -331,9 +334,21 @@ class Ctx:
         self.dev = torch.device("cuda", self.dev_index)
         self.dist = None
         self.backend = args.backend
-        if self.world > 1:
+        self.forced = self.world == 1 and os.environ.get("PLX_BENCH_SINGLE_RANK_RCCL") == "1"
+        if self.world > 1 or self.forced:
             import torch.distributed as dist
-            if args.backend == "nccl":
+            if self.forced:
+                # one rank, real RCCL: every collective of the multi-rank path runs (as a no-op on the data)
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                if "MASTER_PORT" not in os.environ:
+                    with socket.socket() as sk:
+                        sk.bind(("127.0.0.1", 0))
+                        os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                from simplex_gp_amd import distributed as pd
+                pd.FORCE_COLLECTIVES = True
+                dist.init_process_group(args.backend, rank=0, world_size=1,
+                                        **({"device_id": self.dev} if args.backend == "nccl" else {}))
+            elif args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=self.dev)
             else:
                 dist.init_process_group(args.backend)
@@ -419,16 +434,40 @@ def config5_leg(ctx, n=10623, d=18):
         "m_vertices": m, "warm_mvm_us": round(wall / reps * 1e6, 1), "cold_call_us": round(wall_cold / 10 * 1e6, 1)}}
 
 
+def exchange_record(job, vd, stage_us):
+    """The one exchange step of a sharded MVM: what moves, how many bytes per rank, and its device time."""
+    return {"kind": "all_reduce(sum) of the vertex accumulator values[m, %d] (fp32), RCCL" % job.lat.values_stride(vd),
+            "bytes": job.op.exchange_bytes(vd), "us": stage_us.get("exchange")}
+
+
 def sharded_leg(ctx, n_total, d, ell, vds, steps):
-    """A fixed-total-size operator sharded over the ranks (strong scaling / config 4): plain MVMs/s per vd."""
+    """A fixed-total-size operator sharded over the ranks (strong scaling / config 4): plain MVMs/s per vd, per-stage
+    device time per rank (max over ranks) and the exchange."""
+    multi = ctx.dist is not None
     out = {"n_total": n_total, "lengthscale": ell, "rccl_ranks": ctx.world}
     for vd in vds:
         job = Job(ctx, n_total, d, vd, ell)
         out["m_vertices"] = job.op.m
         out[f"mvms_per_s_vd{vd}"] = round(job.rate(steps), 1)
-        if ctx.world > 1:
-            out[f"stage_us_vd{vd}"] = job.stage_us(10)
-            out[f"allreduce_bytes_vd{vd}"] = job.op.exchange_bytes(vd)
+        if multi:
+            st = job.stage_us(10)
+            out[f"stage_us_vd{vd}"] = st
+            out[f"exchange_vd{vd}"] = exchange_record(job, vd, st)
+        elif vd > 1:
+            # one GPU: the same operator driven the way a CG solve drives it -- rows in lattice order, columns padded to
+            # whole 16-byte vectors (solvers.khat_solve); the caller-order figure above pays two row permutations per MVM
+            import torch
+            lat = job.lat
+            lat.set_lattice_row_order(True)
+            vdp = lat.values_stride(vd)
+            v_l = torch.zeros((job.v.shape[0], vdp), device=job.v.device)
+            v_l[:, :vd] = lat.to_lattice_order(job.v)
+            out_l = torch.empty_like(v_l)
+            for _ in range(3):
+                lat.apply(v_l, out_l)
+            wall = time_region(lambda i: lat.apply(v_l, out_l), steps, ctx.sync, ctx.barrier)
+            out[f"mvms_per_s_vd{vd}_lattice_rows"] = round(steps / wall, 1)
+            lat.set_lattice_row_order(False)
         job.close()
         del job
     return out
@@ -450,6 +489,7 @@ def main():
     import simplex_gp_amd as plx
 
     d, vd, r = args.d, args.vd, 1
+    multi = ctx.dist is not None                 # several ranks (or the single-rank RCCL rehearsal): the sharded code path
     if args.scaling == "weak":
         n_total = args.n * world
     elif args.scaling == "strong":
@@ -473,17 +513,23 @@ def main():
         np.savez(f"{args.dump}.rank{rank}.npz", out=job.out.cpu().numpy(), lo=job.lo, hi=job.hi, n_total=n_total, d=d,
                  vd=vd, ell=args.ell, m=m)
 
+    # clocks first: a GPU that has idled through data generation starts the first milliseconds below its steady clocks
+    # (measured: the same 20-step region 155 us / step cold, 143 us after 20 ms of MVMs); the requested warm-up steps
+    # (which include a build) follow
+    job.build()
+    for _ in range(PREWARM_MVMS):
+        job.mvm()
     for i in range(args.warmup):
         step(i)
     wall = ctx.max_over_ranks(time_region(step, args.steps, ctx.sync, ctx.barrier))
     builds = len([i for i in range(args.steps) if i % args.rebuild_every == 0])
     mvms_per_s = args.steps / wall
-    weak_units = world > 1 and args.scaling == "weak"
-    value = mvms_per_s * (n_total / 1e6) if weak_units else mvms_per_s
-    scaling = "weak" if args.scaling == "weak" else "strong"
+    value = mvms_per_s                            # always the plain rate of the n_total-point operator
+    scaling = "weak" if (args.scaling == "weak" and world > 1) else "strong"
 
     result = {
-        "metric": "lattice K.v MVMs/sec, N=1e6 d=8 order=1" + (" (1e6 points per GPU)" if args.scaling == "weak" else ""),
+        "metric": "lattice K.v MVMs/sec, N=1e6 d=8 order=1" + (" (1e6 points per GPU)" if scaling == "weak" else
+                                                              (" (N=4e6: configs[3])" if args.scaling == "config4" else "")),
         "value": round(value, 2), "unit": "MVMs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
@@ -494,20 +540,21 @@ def main():
                         f"build(s) + {args.steps} MVMs (rebuild every {args.rebuild_every} MVMs: the CG loop of "
                         f"BASELINE.json configs[2])",
             "n_total": n_total, "m_vertices": m, "rebuild_every": args.rebuild_every,
-            "builds_in_timed_region": builds, "scaling_mode": args.scaling,
+            "builds_in_timed_region": builds, "scaling_mode": args.scaling, "prewarm_mvms": PREWARM_MVMS,
             "parallelism": "single GPU" if world == 1 else f"points sharded x{world}; build: local + all-gather of vertex "
                                                               "keys + merge; MVM: RCCL all-reduce of vertex values, replicated blur",
-            "value_definition": "(n_total/1e6) x MVMs/s of the n_total operator" if weak_units else "MVMs/s of the n_total operator",
+            "value_definition": "MVMs/s of the n_total-point operator (never scaled by the problem size)",
         },
         "mvms_per_s": round(mvms_per_s, 2),
     }
 
-    if world > 1:
-        # ---- what the ranks spent where, the exchange, and the other two scaling curves
+    if multi:
+        # ---- what the ranks spent where, the exchange, and the other scaling curves
         result["rccl_ranks"] = dist.get_world_size()
         result["backend"] = args.backend
         result["warm_mvms_per_s"] = round(job.rate(args.steps), 1)
         result["stage_us"] = job.stage_us(20)
+        result["exchange"] = exchange_record(job, vd, result["stage_us"])
         result["allreduce_bytes"] = job.op.exchange_bytes(vd)
         result["build_key_bytes_exchanged"] = getattr(job.op, "key_bytes_exchanged", None)
         job.close()
@@ -517,11 +564,11 @@ def main():
                 result["strong"] = sharded_leg(ctx, args.n, d, args.ell, [1], short)
             if args.scaling != "config4":
                 result["config4"] = sharded_leg(ctx, 4_000_000, d, 1.0, [1, 11], short)
+            if args.scaling != "weak":
+                result["weak_1e6_per_gpu"] = sharded_leg(ctx, args.n * world, d, args.ell, [1], short)
             # weak scaling with 4e6 points per GPU: where the sharded splat / slice outweigh the replicated blur and the
-            # all-reduce; value of this leg = (n_total / 4e6) x MVMs/s
-            big = sharded_leg(ctx, 4_000_000 * world, d, 1.0, [1], short)
-            big["blocks_4e6_per_s"] = round(big["mvms_per_s_vd1"] * world, 1)
-            result["weak_4e6_per_gpu"] = big
+            # all-reduce
+            result["weak_4e6_per_gpu"] = sharded_leg(ctx, 4_000_000 * world, d, 1.0, [1], short)
     else:
         # ---- warm / cold rates and per-stage times on the same lattice
         ref, v, out = job.ref, job.v, job.out
@@ -533,6 +580,14 @@ def main():
         lat.build(ref, RBF1)
         build_ms = lat.build_times_ms()
         lat.set_timing(False)
+        build_ms.pop("csr", None)
+        # the splat / slice tables are built by their first user; plx_prepare builds them now, so they can be timed
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        lat.prepare(vd)
+        ev1.record()
+        ctx.sync()
+        build_ms["tables"] = ev0.elapsed_time(ev1)
         kt = kernel_times(lat, v, out, reps=max(10, args.steps), mvm_ms=wall_warm / args.steps * 1e3)
         roof, stages = roofline_for(lat, kt, n_local, d, m, vd, r, args.ell)
         result["warm_mvms_per_s"] = round(args.steps / wall_warm, 1)
@@ -570,6 +625,13 @@ def main():
             lat_f.build(ref_f, RBF1)
             fine_build = lat_f.build_times_ms()
             lat_f.set_timing(False)
+            fine_build.pop("csr", None)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            lat_f.prepare(vd)
+            ev1.record()
+            ctx.sync()
+            fine_build["tables"] = ev0.elapsed_time(ev1)
             for _ in range(3):
                 lat_f.apply(v, out)
             wf = time_region(lambda i: lat_f.apply(v, out), 20, ctx.sync, ctx.barrier)
@@ -595,10 +657,9 @@ def main():
             lat_f.close()
             del ref_f
 
-        if not args.no_configs and args.scaling == "weak" and args.n == 1_000_000 and d == 8:
+        if not args.no_configs and args.n == 1_000_000 and d == 8:
             result.update(config3_leg(ctx))
             result["config4"] = sharded_leg(ctx, 4_000_000, d, 1.0, [1, 11], 20)
-            result["weak_4e6_per_gpu"] = dict(result["config4"], blocks_4e6_per_s=result["config4"]["mvms_per_s_vd1"])
             result.update(config5_leg(ctx))
 
         if not args.no_cpu_baseline:

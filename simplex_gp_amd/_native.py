@@ -8,7 +8,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplx.so")
+# PLX_LIBRARY selects another build of the same C ABI -- libplx_diag.so (make -C simplex_gp_amd/csrc diag), which has the
+# diagnostic ablation switches of tools/ablate_*.py compiled in.  Never a fallback: the named file must exist.
+LIB_PATH = os.environ.get("PLX_LIBRARY") or os.path.join(_HERE, "libplx.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "plx.h")
 
 PLX_OK = 0

@@ -29,8 +29,9 @@
 namespace plx {
 
 int g_block_path = 1;        // 0 never, 1 when the lattice qualifies (see build_blocks), 2 whenever representable
-int g_block_ablate = 0;      // diagnostics only: 1 combine without the partial gathers, 2 combine without idx loads too,
-                             // 4 combine without stores, 8 splat_block without the LDS source reads
+#ifdef PLX_DIAG
+int g_block_ablate = 0;      // libplx_diag.so only: 1 combine without the partial gathers, 2 combine without idx loads too, 4 combine without stores
+#endif
 int g_scatter_store = 0;     // slice's row-scattered output stores: 0 plain, 1 non-temporal, 2 agent-scope (write-through)
 int g_unpermute_gather = 1;  // caller row order out of the block slice: 1 = lattice-ordered scratch + a gather pass, 0 = scatter from the slice kernel
 int g_block_e = 0;           // corners per thread of the block kernels (a block holds 256 * e corners): 0 = per lattice (choose_block_e), 16 or 24
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__rest
 {
     // XCD-aware tile order: every XCD sweeps one contiguous eighth of the vertex-sorted rows, whose partials lie in
     // about one eighth of the partial array (blocks and vertices both follow the lattice order): L2-resident gathers
+    ablate = PLX_DIAG_VALUE(ablate);
     const int tile = tile_index(ntiles, remap);
     if (tile < 0) return;
     const int lane = threadIdx.x & 63;
@@ -353,11 +355,11 @@ int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStr
     if (dense)
         splat_combine_kernel<true><<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
             L->s2_wave.as<int>(), L->s2_wave_v.as<int>(), L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->partial.as<float>(),
-            (int)L->n_s2waves, d_values, nt, g_xcd_remap, g_block_ablate);
+            (int)L->n_s2waves, d_values, nt, g_xcd_remap, PLX_DIAG_VALUE(g_block_ablate));
     else
         splat_combine_kernel<false><<<tile_grid(nt, g_xcd_remap), kBlock, 0, stream>>>(
             L->s2_wave.as<int>(), L->s2_wave_v.as<int>(), L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->partial.as<float>(),
-            (int)L->n_s2waves, d_values, nt, g_xcd_remap, g_block_ablate);
+            (int)L->n_s2waves, d_values, nt, g_xcd_remap, PLX_DIAG_VALUE(g_block_ablate));
     L->kn_splat = "splat_block_kernel+splat_combine_kernel";
     tmark(L, stream);
     PLX_HIP_TRY(hipGetLastError());

@@ -18,6 +18,7 @@ __global__ __launch_bounds__(kBlock) void blur_axis_v1_kernel(const float *__res
                                                               int64_t mstride, TapArgs taps, int ablate, int ntiles,
                                                               int remap)
 {
+    ablate = PLX_DIAG_VALUE(ablate);                   // diagnostics are compiled into libplx_diag.so only
     using ivec = typename std::conditional<VPT == 4, int4, int2>::type;
     using fvec = typename std::conditional<VPT == 4, float4, float2>::type;
     const int tile = tile_index(ntiles, remap);
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void blur_pair_narrow_kernel(const float4 *
                                                                   uint32_t mstride, TapArgs taps, int ntiles, int remap,
                                                                   int ablate)
 {
+    ablate = PLX_DIAG_VALUE(ablate);                   // diagnostics are compiled into libplx_diag.so only
     const int tile = tile_index(ntiles, remap);
     if (tile < 0) return;
     const uint32_t item = (uint32_t)tile * kBlock + threadIdx.x;
@@ -313,9 +315,9 @@ static void launch_blur_pair_narrow(const float4 *cur, float4 *nxt, const int *p
     const int nt = ceil_div((int64_t)total, kBlock);
     const int grid = tile_grid(nt, remap);
     switch (rowlen) {
-    case 2: blur_pair_narrow_kernel<2><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, g_blur_ablate); break;
-    case 3: blur_pair_narrow_kernel<3><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, g_blur_ablate); break;
-    default: blur_pair_narrow_kernel<4><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, g_blur_ablate); break;
+    case 2: blur_pair_narrow_kernel<2><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, PLX_DIAG_VALUE(g_blur_ablate)); break;
+    case 3: blur_pair_narrow_kernel<3><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, PLX_DIAG_VALUE(g_blur_ablate)); break;
+    default: blur_pair_narrow_kernel<4><<<grid, kBlock, 0, stream>>>(cur, nxt, pn, total, (uint32_t)mstride, taps, nt, remap, PLX_DIAG_VALUE(g_blur_ablate)); break;
     }
 }
 
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(kBlock) void blur_axis_kernel(const V *__restrict__
                                                            int rowlen, int order_rt, TapArgs taps, int ntiles, int remap,
                                                            int ablate)
 {
+    ablate = PLX_DIAG_VALUE(ablate);                   // diagnostics are compiled into libplx_diag.so only
     using O = VecOps<V>;
     const int order = ORDER > 0 ? ORDER : order_rt;
     const int tile = tile_index(ntiles, remap);
@@ -530,9 +533,9 @@ static void launch_blur_v1(const float *cur, float *nxt, const int *nb, int m, i
 {
     const int nt4 = ceil_div(ceil_div(m, 4), kBlock), nt2 = ceil_div(ceil_div(m, 2), kBlock);
     if (g_blur_vpt == 4)
-        blur_axis_v1_kernel<ORDER, 4><<<tile_grid(nt4, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate, nt4, g_xcd_remap);
+        blur_axis_v1_kernel<ORDER, 4><<<tile_grid(nt4, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, PLX_DIAG_VALUE(g_blur_ablate), nt4, g_xcd_remap);
     else
-        blur_axis_v1_kernel<ORDER, 2><<<tile_grid(nt2, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, g_blur_ablate, nt2, g_xcd_remap);
+        blur_axis_v1_kernel<ORDER, 2><<<tile_grid(nt2, g_xcd_remap), kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, taps, PLX_DIAG_VALUE(g_blur_ablate), nt2, g_xcd_remap);
 }
 
 template <class V>
@@ -542,10 +545,10 @@ static void launch_blur_general(const V *cur, V *nxt, const int *nb, int m, int6
     const int nt = ceil_div((int64_t)m * rowlen, kBlock);
     const int grid = tile_grid(nt, g_xcd_remap);
     switch (order) {
-    case 1: blur_axis_kernel<V, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
-    case 2: blur_axis_kernel<V, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
-    case 3: blur_axis_kernel<V, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
-    default: blur_axis_kernel<V, 0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, g_blur_ablate); break;
+    case 1: blur_axis_kernel<V, 1><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, PLX_DIAG_VALUE(g_blur_ablate)); break;
+    case 2: blur_axis_kernel<V, 2><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, PLX_DIAG_VALUE(g_blur_ablate)); break;
+    case 3: blur_axis_kernel<V, 3><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, PLX_DIAG_VALUE(g_blur_ablate)); break;
+    default: blur_axis_kernel<V, 0><<<grid, kBlock, 0, stream>>>(cur, nxt, nb, m, mstride, rowlen, order, taps, nt, g_xcd_remap, PLX_DIAG_VALUE(g_blur_ablate)); break;
     }
 }
 

@@ -46,6 +46,7 @@
 namespace plx {
 
 int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
+int g_readback_spin = 1; // read_back: 1 = spin on the mailbox word, 0 = wait for the stream (A/B)
 int g_order_compact = 1; // 1: point-order keys over exactly the bits every coordinate's range needs (one small read-back per build); 0: a fixed 7 / 8 bits per coordinate
 int g_order_zcurve = 1;  // 1: points ordered along the Z-curve of their rounded lattice coordinates; 0: lexicographically; 2: Z-curve of the blur-axis coordinates
 int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only and mirrors the hits
@@ -172,6 +173,7 @@ int read_back(plx_lattice *L, const int *d_src, int count, int *h_dst, hipStream
     mailbox_kernel<<<1, 64, 0, stream>>>(d_src, count, L->h_mail, seq);
     PLX_HIP_TRY(hipGetLastError());
     volatile int *mail = L->h_mail;
+    if (!g_readback_spin) PLX_HIP_TRY(hipStreamSynchronize(stream));
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
     while (__atomic_load_n(const_cast<int *>(mail), __ATOMIC_ACQUIRE) != seq) {

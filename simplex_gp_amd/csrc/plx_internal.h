@@ -36,6 +36,7 @@ void set_error(const char *fmt, ...);
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    hipStream_t owner = nullptr;   // stream the buffer was allocated on (stream-ordered: hipMallocAsync)
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 

@@ -25,6 +25,18 @@
 
 namespace plx {
 
+// Diagnostic ablations (kernels with parts of their memory traffic switched off, for A/B profiles) exist only in
+// libplx_diag.so (make diag: -DPLX_DIAG); in the shipped library the switches and the branches behind them are
+// compiled out.
+#ifdef PLX_DIAG
+#define PLX_DIAG_VALUE(x) (x)
+extern int g_splat_ablate;
+extern int g_blur_ablate;
+extern int g_block_ablate;
+#else
+#define PLX_DIAG_VALUE(x) 0
+#endif
+
 // kernel-variant switches (plx_tune); defined in plx_tune.hip and plx_build.hip
 extern int g_blur_vpt;
 extern int g_blur_small;
@@ -34,11 +46,10 @@ extern int g_blur_narrow;
 extern int g_blur_multi;
 extern int g_splat_group;
 extern int g_splat_wide;
-extern int g_splat_ablate;
-extern int g_blur_ablate;
 extern int g_sort_points;
 extern int g_order_zcurve;
 extern int g_order_compact;
+extern int g_readback_spin;
 extern int g_vertex_order;
 extern int g_insert_plane_fast;
 extern int g_compact_nbr;
@@ -47,7 +58,6 @@ extern int g_nbr_symmetric;
 extern int g_block_path;
 extern int g_block_e;
 extern int g_block_dense_combine;
-extern int g_block_ablate;
 extern int g_blur_fuse;
 extern int g_blur_fuse_vec;
 extern int g_scatter_store;

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(kSplatBlock) void splat_scan_kernel(const int *__re
                                                             V *__restrict__ tail_partial, int ablate, int nchunks,
                                                             int remap)
 {
+    ablate = PLX_DIAG_VALUE(ablate);                   // diagnostics are compiled into libplx_diag.so only
     using O = VecOps<V>;
     constexpr int EPT = kSplatChunk / kSplatBlock;   // corners per thread
     static_assert(EPT % 4 == 0, "vector loads below take 4 corners at a time");
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(kBlock) void splat_group_kernel(const int *__restri
                                                              V *__restrict__ tail_partial, int ntiles, int remap,
                                                              int ablate)
 {
+    ablate = PLX_DIAG_VALUE(ablate);                   // diagnostics are compiled into libplx_diag.so only
     using O = VecOps<V>;
     constexpr int G = 64 / NCHP;                       // groups per wave
     constexpr int WC = G * RUN;                  // corners per wave = one chunk of the partial protocol
@@ -582,7 +584,7 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     if (vd == 1) {
         // (one lane per run of corners -- splat_group_kernel<float, 1, 16> -- was measured 18-75 % slower here:
         // the scan kernel's 16-byte index loads and coalesced stores win on single-column rows)
-        splat_scan_kernel<float, 1><<<tile_grid(nchunks, g_xcd_remap), kSplatBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, g_splat_ablate, nchunks, g_xcd_remap);
+        splat_scan_kernel<float, 1><<<tile_grid(nchunks, g_xcd_remap), kSplatBlock, 0, stream>>>(pt, w, vid, ss, 1, nnz, d_values, hp, tp, PLX_DIAG_VALUE(g_splat_ablate), nchunks, g_xcd_remap);
     } else {
         const float4 *s4 = reinterpret_cast<const float4 *>(ss);
         float4 *v4 = reinterpret_cast<float4 *>(d_values), *h4 = reinterpret_cast<float4 *>(hp), *t4 = reinterpret_cast<float4 *>(tp);
@@ -616,11 +618,11 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
             t4 = reinterpret_cast<float4 *>(L->tail_partial.as<float>());
             const int grid = tile_grid(nt, g_xcd_remap);
             switch (nchp) {
-            case 2: splat_group_kernel<float4, 2, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
-            case 3: splat_group_kernel<float4, 3, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
-            case 4: splat_group_kernel<float4, 4, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
-            case 8: splat_group_kernel<float4, 8, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
-            default: splat_group_kernel<float4, 16, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, g_splat_ablate); break;
+            case 2: splat_group_kernel<float4, 2, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, PLX_DIAG_VALUE(g_splat_ablate)); break;
+            case 3: splat_group_kernel<float4, 3, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, PLX_DIAG_VALUE(g_splat_ablate)); break;
+            case 4: splat_group_kernel<float4, 4, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, PLX_DIAG_VALUE(g_splat_ablate)); break;
+            case 8: splat_group_kernel<float4, 8, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, PLX_DIAG_VALUE(g_splat_ablate)); break;
+            default: splat_group_kernel<float4, 16, kGroupRun><<<grid, kBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, nt, g_xcd_remap, PLX_DIAG_VALUE(g_splat_ablate)); break;
             }
             splat_fixup_kernel<<<ceil_div((int64_t)nwchunks * vdp, kBlock), kBlock, 0, stream>>>(
                 pt, vid, nwchunks, wc, nnz, vdp, L->head_partial.as<float>(), L->tail_partial.as<float>(), d_values);
@@ -633,9 +635,9 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         const int nch = nch_total <= 3 ? nch_total : (nch_total % 3 == 0 ? 3 : (nch_total % 2 == 0 ? 2 : 3));
         dim3 grid((unsigned)tile_grid(nchunks, g_xcd_remap), (unsigned)ceil_div(nch_total, nch));
         switch (nch) {
-        case 1: splat_scan_kernel<float4, 1><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
-        case 2: splat_scan_kernel<float4, 2><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
-        default: splat_scan_kernel<float4, 3><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, g_splat_ablate, nchunks, g_xcd_remap); break;
+        case 1: splat_scan_kernel<float4, 1><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, PLX_DIAG_VALUE(g_splat_ablate), nchunks, g_xcd_remap); break;
+        case 2: splat_scan_kernel<float4, 2><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, PLX_DIAG_VALUE(g_splat_ablate), nchunks, g_xcd_remap); break;
+        default: splat_scan_kernel<float4, 3><<<grid, kSplatBlock, 0, stream>>>(pt, w, vid, s4, nch_total, nnz, v4, h4, t4, PLX_DIAG_VALUE(g_splat_ablate), nchunks, g_xcd_remap); break;
         }
     }
     splat_fixup_kernel<<<ceil_div((int64_t)nchunks * vdp, kBlock), kBlock, 0, stream>>>(pt, vid, nchunks, kSplatChunk, nnz, vdp,

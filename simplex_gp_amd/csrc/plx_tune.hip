@@ -16,13 +16,19 @@ int g_blur_narrow = 1;   // vd 2..16 blur: row length compiled in, branch-free (
 int g_blur_multi = 1;    // vd > 1 blur: 4 items per thread (0: one item per thread, blur_axis_kernel)
 int g_splat_group = 1;   // vd 2..64: lane-group streaming splat (0: segmented-scan kernel)
 int g_splat_wide = 1;    // row-parallel splat for rows of 32..128 chunks (vd 125..512)
-int g_splat_ablate = 0; // diagnostics only: 1 no value gather, 2 no stores, 4 no row-id loads
-int g_blur_ablate = 0;  // diagnostics only: 1 no neighbour gathers, 2 no neighbour-id loads either
+#ifdef PLX_DIAG
+int g_splat_ablate = 0; // libplx_diag.so only: 1 no value gather, 2 no stores, 4 no row-id loads
+int g_blur_ablate = 0;  // libplx_diag.so only: 1 no neighbour gathers, 2 no neighbour-id loads either
+#endif
 
 Tunable *tunables()
 {
-    static Tunable t[] = {{"sort_points", &g_sort_points}, {"order_zcurve", &g_order_zcurve}, {"order_compact", &g_order_compact}, {"vertex_order", &g_vertex_order}, {"insert_plane_fast", &g_insert_plane_fast}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap}, {"blur_small", &g_blur_small}, {"blur_multi", &g_blur_multi}, {"blur_narrow", &g_blur_narrow}, {"splat_group", &g_splat_group},
-                          {"splat_direct", &g_splat_direct}, {"splat_wide", &g_splat_wide}, {"block_path", &g_block_path}, {"block_e", &g_block_e}, {"block_dense_combine", &g_block_dense_combine}, {"block_ablate", &g_block_ablate}, {"blur_fuse", &g_blur_fuse}, {"blur_fuse_vec", &g_blur_fuse_vec}, {"scatter_store", &g_scatter_store}, {"unpermute_gather", &g_unpermute_gather}, {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {nullptr, nullptr}};
+    static Tunable t[] = {{"sort_points", &g_sort_points}, {"order_zcurve", &g_order_zcurve}, {"order_compact", &g_order_compact}, {"readback_spin", &g_readback_spin}, {"vertex_order", &g_vertex_order}, {"insert_plane_fast", &g_insert_plane_fast}, {"compact_nbr", &g_compact_nbr}, {"insert_dedupe", &g_insert_dedupe}, {"nbr_symmetric", &g_nbr_symmetric}, {"blur_vpt", &g_blur_vpt}, {"xcd_remap", &g_xcd_remap}, {"blur_small", &g_blur_small}, {"blur_multi", &g_blur_multi}, {"blur_narrow", &g_blur_narrow}, {"splat_group", &g_splat_group},
+                          {"splat_direct", &g_splat_direct}, {"splat_wide", &g_splat_wide}, {"block_path", &g_block_path}, {"block_e", &g_block_e}, {"block_dense_combine", &g_block_dense_combine}, {"blur_fuse", &g_blur_fuse}, {"blur_fuse_vec", &g_blur_fuse_vec}, {"scatter_store", &g_scatter_store}, {"unpermute_gather", &g_unpermute_gather}, 
+#ifdef PLX_DIAG
+                          {"splat_ablate", &g_splat_ablate}, {"blur_ablate", &g_blur_ablate}, {"block_ablate", &g_block_ablate},
+#endif
+                          {nullptr, nullptr}};
     return t;
 }
 

@@ -429,7 +429,8 @@ class LatticeGP(nn.Module):
                                                  device=x.device, dtype=x.dtype)
 
 
-def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, pre_size=0):
+def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, pre_size=0, reduce=None,
+                            n_total=None):
     """Per-datapoint log marginal likelihood (the quantity GPyTorch's
     ExactMarginalLogLikelihood returns) of a LatticeGP, differentiable with
     respect to every hyper-parameter.
@@ -445,6 +446,10 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     probes are drawn from N(0, P), logdet = logdet P + SLQ of P^-1/2 (sK + sigma^2 I) P^-1/2,
     and the log-det gradient pairs w_i with P^-1 z_i  (E[P^-1 z z^T] = I).
     """
+    if reduce is not None or n_total is not None:
+        # kept in the signature for one release: the old row-sharded form evaluated a block-diagonal likelihood
+        raise NotImplementedError("marginal_log_likelihood is single-process; for a row-sharded solve use "
+                                  "simplex_gp_amd.distributed.sharded_solve (the reduce= / n_total= arguments were removed)")
     # Single-process only: the kernel operator below is built from `x` alone.  A row-sharded job has to go through
     # distributed.ShardedLatticeMVM (whose vertex all-reduce couples the ranks); distributed.sharded_solve does the
     # solve that way, a sharded marginal likelihood with gradients is not implemented.

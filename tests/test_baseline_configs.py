@@ -214,6 +214,25 @@ def test_predict_matches_dense_formulas_on_gpu(plx):
     assert rel_l2(mean.cpu().numpy(), mean_dense.cpu().numpy()) <= 2e-2
     assert (var > 0).all()
     assert float((var.double() - var_dense.clamp_min(1e-8)).abs().max()) <= 0.05 * float(s)
+    # and against the ORACLE's operators: K(x, x) and K(xs, x) column by column through the CPU restatement's filter
+    # (py:133-134 square; py:150-156 rectangular = one square filter over the stacked points [x; xs], rows of xs), then
+    # the dense predictive mean -- nothing of the HIP path in this reference value
+    ell = model.kernel.lengthscale.detach().cpu()
+    taps = model.kernel.dkernel_fn.get_coeffs().numpy()
+    xo, xso = (x.cpu() / ell).numpy(), (xs.cpu() / ell).numpy()
+    oracle.set_exact_mode(False)
+    try:
+        K_o = oracle.filter(np.eye(n, dtype=np.float32), xo, taps)
+        stacked = np.concatenate([xo, xso], 0)
+        rhs = np.concatenate([np.eye(n, dtype=np.float32), np.zeros((ns, n), np.float32)], 0)
+        Ks_o = oracle.filter(rhs, stacked, taps)[n:]                              # [ns, n]
+    finally:
+        oracle.set_exact_mode(True)
+    assert rel_l2(K.cpu().numpy(), K_o) <= 1e-5 and rel_l2(Ks.cpu().numpy(), Ks_o) <= 1e-5
+    sd, nd = float(s), float(noise)
+    Khat_o = sd * K_o.astype(np.float64) + nd * np.eye(n)
+    mean_o = float(model.mean) + sd * Ks_o.astype(np.float64) @ np.linalg.solve(Khat_o, r.cpu().numpy())
+    assert rel_l2(mean.cpu().numpy(), mean_o[:, 0]) <= 2e-2
 
 
 def test_lengthscale_gradient_vs_central_differences(plx):
@@ -255,7 +274,7 @@ def test_bench_self_launches_its_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     dump = str(tmp_path / "dump")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--points", "30000",
-           "--rebuild-every", "2", "--backend", "gloo", "--skip-configs", "--dump", dump]
+           "--rebuild-every", "2", "--backend", "gloo", "--skip-configs", "--dump", dump, "--scaling", "weak"]
     proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-3000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
@@ -263,14 +282,16 @@ def test_bench_self_launches_its_ranks(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["steps"] == 4 and res["scaling"] == "weak"
     assert res["config"]["n_total"] == 60000 and res["config"]["builds_in_timed_region"] == 2
-    assert res["value"] > 0 and res["allreduce_bytes"] == res["config"]["m_vertices"] * 4
+    assert res["value"] > 0 and res["value"] == res["mvms_per_s"]          # the plain rate, never scaled by the size
+    assert res["allreduce_bytes"] == res["config"]["m_vertices"] * 4
     assert set(res["stage_us"]) == {"splat", "exchange", "blur", "slice"}
+    assert res["exchange"]["bytes"] == res["allreduce_bytes"] and res["exchange"]["us"] > 0 and "all_reduce" in res["exchange"]["kind"]
     check = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "check_bench_dump.py"), dump], env=env,
                            capture_output=True, text=True, timeout=600)
     assert check.returncode == 0 and "OK" in check.stdout, check.stdout + check.stderr
-    # strong scaling: same total size whatever the rank count
+    # the default: strong scaling, BASELINE.json's metric as written -- same total size whatever the rank count
     cmd2 = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "30000",
-            "--backend", "gloo", "--skip-configs", "--scaling", "strong"]
+            "--backend", "gloo", "--skip-configs"]
     proc2 = subprocess.run(cmd2, env=env, capture_output=True, text=True, timeout=900)
     assert proc2.returncode == 0, proc2.stderr[-3000:]
     res2 = json.loads([ln for ln in proc2.stdout.splitlines() if ln.startswith("{")][0])
@@ -279,6 +300,22 @@ def test_bench_self_launches_its_ranks(tmp_path):
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode == 2
+
+
+def test_bench_single_rank_rccl_rehearsal():
+    """bench.py's own multi-rank code path on real RCCL: PLX_BENCH_SINGLE_RANK_RCCL=1 makes the one-GPU run open a
+    world-size-1 "nccl" group (init with device_id, barrier with device_ids, all_reduce of the timings on the device,
+    sharded build with its key all-gather, MVMs with the vertex all-reduce) and report like a multi-GPU job."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PLX_BENCH_SINGLE_RANK_RCCL"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--points", "200000", "--skip-configs"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    res = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 1 and res["rccl_ranks"] == 1 and res["backend"] == "nccl" and res["value"] > 0
+    assert res["exchange"]["bytes"] == res["config"]["m_vertices"] * 4 and res["exchange"]["us"] > 0
+    assert res["build_key_bytes_exchanged"] > 0
 
 
 def test_bench_single_gpu_json_contract():

@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3c
-timeout -k 10 1000 python -m pytest tests/ -x -q -m gpu > gpurun_out/r3c/pytest_all.log 2>&1; echo "rc all $?"
-tail -4 gpurun_out/r3c/pytest_all.log
+for i in 1 2 3; do python bench.py --steps 20 --warmup 3 --skip-configs --skip-fine --skip-cpu-baseline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print(r['value'], r['ms_per_step'], r['warm_mvms_per_s'])"; done

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """What a blur pass costs without its neighbour gathers / id loads (diagnostic blur_ablate switch)."""
+# needs the diagnostics build: make -C simplex_gp_amd/csrc diag && PLX_LIBRARY=$PWD/simplex_gp_amd/libplx_diag.so python tools/ablate_blur.py
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

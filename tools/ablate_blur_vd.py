@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Multi-column blur: time per pass with the neighbour gathers on (0) / replaced by the centre row (1), with and
 without the XCD tile remap.  Shows how much of a pass is the stream (centre read + write) and how much the gathers."""
+# needs the diagnostics build: make -C simplex_gp_amd/csrc diag && PLX_LIBRARY=$PWD/simplex_gp_amd/libplx_diag.so python tools/ablate_blur_vd.py
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,4 @@
+# needs the diagnostics build: make -C simplex_gp_amd/csrc diag && PLX_LIBRARY=$PWD/simplex_gp_amd/libplx_diag.so python tools/ablate_group.py
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")

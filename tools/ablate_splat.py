@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# needs the diagnostics build: make -C simplex_gp_amd/csrc diag && PLX_LIBRARY=$PWD/simplex_gp_amd/libplx_diag.so python tools/ablate_splat.py
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
