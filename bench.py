@@ -216,14 +216,31 @@ def roofline_for(lat, kt, n, d, m, vd, r, ell=1.0):
     return roof, stages
 
 
+def kernel_sources_sha16():
+    """Fingerprint of the kernel sources (simplex_gp_amd/csrc/*.hip, *.h): a PMC table is only quoted for the sources it
+    was collected on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "simplex_gp_amd", "csrc", "*.hip")) +
+                       glob.glob(os.path.join(ROOT, "simplex_gp_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_names, ell):
     """HBM bytes per launch of a stage's kernels (summed) from the newest committed PMC table (profiles/*_pmc.json,
     written by tools/summarize_profile.py from separate rocprofv3 --pmc passes of this same command), corrected as
-    the microarch guide prescribes for gfx950 (FETCH_SIZE x2 + WRITE_SIZE).  None when a kernel is not in the table."""
+    the microarch guide prescribes for gfx950 (FETCH_SIZE x2 + WRITE_SIZE).  None when a kernel is not in the table, or
+    when the table was collected on other kernel sources than the ones in the tree (a stale table is not quoted)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
-            table = json.load(open(path))["by_lengthscale"].get(str(ell), {})
+            doc = json.load(open(path))
+            if doc.get("kernel_sources_sha16") != kernel_sources_sha16():
+                continue
+            table = doc["by_lengthscale"].get(str(ell), {})
         except Exception:                      # noqa: BLE001
             continue
         total, found = 0.0, 0

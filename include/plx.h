@@ -246,19 +246,26 @@ int plx_copy_point_perm(plx_lattice *lat, void *d_dst, void *stream);
 /* size in bytes of an exportable array, or -1 */
 int64_t plx_export_bytes(const plx_lattice *lat, int which);
 
-/* Select a kernel variant by name (process-wide, not synchronised with running builds / MVMs: for A/B measurements
- * in one process -- the defaults are the shipped configuration).  Keys (default): "sort_points" (1; 0 keeps the
- * caller's point order), "order_zcurve" (1; 0 = lexicographic point order, 2 = Z-curve of the
- * blur-axis coordinates), "blur_fuse_vec" (1 = two blur axes per launch for rows of 2..4 chunks; 0 = one), "vertex_order" (1: vertices numbered along
- * the Morton curve of their blur-axis coordinates where that pays, 65536 <= m <= 0.9 n (d+1); 0: always by first touch;
- * 2: always Morton -- vertex ids are internal, the PLX_ARRAY_* exports are in whichever numbering the build used), "insert_dedupe" (1), "insert_plane_fast" (1 = the d+1 corner planes of a run of points are adjacent workgroups of the
- * hashed insert / neighbour lookups; 0 = plane-major launch order), "nbr_symmetric" (1),
- * "compact_nbr" (1 = when under a quarter of the neighbour slots exist; 0 never, 2 always), "blur_vpt" (4; vertices per
- * thread at vd = 1: 2 or 4, anything else selects the general kernel), "blur_small" (1), "blur_narrow" (1),
- * "blur_multi" (1), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1), "block_path" (1 = block
- * tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable), "block_e" (0 = corners per thread of the
- * block kernels chosen per lattice; 16 or 24: a block holds 256 * e corners), "block_dense_combine" (1), "blur_fuse" (1), "scatter_store" (0), "unpermute_gather" (1), and the diagnostic
- * "splat_ablate" / "blur_ablate" / "block_ablate" (0).  Unknown keys return PLX_ERR_INVALID. */
+/* Select a kernel variant by name: for A/B measurements in one process -- the defaults are the shipped configuration.
+ * Process-wide and not synchronised: every entry point reads the switches once, when it is called, and whatever a build
+ * decided (block size, vertex numbering, which tables exist) is recorded in the lattice and stays valid under later
+ * changes; do not call plx_tune while another thread is inside a plx_* call.  Keys (default):
+ *   "sort_points" (1; 0 keeps the caller's point order), "order_zcurve" (1; 0 = lexicographic point order, 2 = Z-curve of
+ *   the blur-axis coordinates), "order_compact" (1 = point-order keys laid out over exactly the bits each coordinate's
+ *   range needs; 0 = a fixed 7 bits per coordinate), "readback_spin" (1 = counts come back through the mailbox; 0 = stream
+ *   synchronisation), "vertex_order" (1: vertices numbered along the Morton curve of their blur-axis coordinates where
+ *   that pays, 65536 <= m <= 0.9 n (d+1); 0: always by first touch; 2: always Morton -- vertex ids are internal, the
+ *   PLX_ARRAY_* exports are in whichever numbering the build used), "insert_dedupe" (1), "insert_plane_fast" (1 = the
+ *   d+1 corner planes of a run of points are adjacent workgroups of the hashed insert / neighbour lookups; 0 =
+ *   plane-major launch order), "nbr_symmetric" (1), "compact_nbr" (1 = when under a quarter of the neighbour slots exist;
+ *   0 never, 2 always), "blur_vpt" (4; vertices per thread at vd = 1: 2 or 4, anything else selects the general kernel),
+ *   "blur_small" (1), "blur_narrow" (1), "blur_multi" (1), "blur_fuse" (1), "blur_fuse_vec" (1 = two blur axes per launch
+ *   for rows of 2..4 chunks; 0 = one), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1),
+ *   "block_path" (1 = block tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable),
+ *   "block_e" (0 = corners per thread of the block kernels chosen per lattice; 16 or 24: a block holds 256 * e corners),
+ *   "block_dense_combine" (1), "scatter_store" (0), "unpermute_gather" (1).
+ * The diagnostic ablations "splat_ablate" / "blur_ablate" / "block_ablate" exist only in libplx_diag.so (make diag).
+ * Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);
 
 /* Names of the kernels the last plx_splat / plx_blur / plx_slice (or plx_apply) on this lattice launched, as

@@ -7,7 +7,7 @@
 // a plain three-kernel pass -- per-tile digit counts, per-bin row scans, stable scatter -- over exactly
 // the significant digits (8 to 10 bits each) is 3 short launches per pass and nothing else.
 //
-//   count    tile t (4096 keys, 256 threads): LDS histogram of the digit        -> counts[bin][tile]
+//   count    tile t (2048 or 4096 keys, 256 threads): LDS histogram of the digit        -> counts[bin][tile]
 //   scan     workgroup b: exclusive scan of row b over the tiles, row total     -> counts[bin][tile], totals[bin]
 //   scatter  tile t: bin starts (scan of totals over the bins) + its row offsets; every wave owns a contiguous quarter
 //            of the tile and walks it 64 keys at a time: the lanes holding equal digits find each other with one
@@ -23,16 +23,14 @@ namespace plx {
 namespace radix {
 
 constexpr int kThreads = 256;
-constexpr int kKeysPerThread = 16;
-constexpr int kTile = kThreads * kKeysPerThread;      // 4096 keys per workgroup
 constexpr int kMaxDigitBits = 10;                     // widest digit: 1024 bins (11- and 12-bit digits were measured slower per
                                                       // key bit at every size: the scatter's write locality goes first)
 
-template <class K, int DB>
+template <class K, int DB, int KPT>
 __global__ __launch_bounds__(kThreads) void count_kernel(const K *__restrict__ keys, int n, int shift, int ntiles,
                                                          int *__restrict__ counts)
 {
-    constexpr int BINS = 1 << DB;
+    constexpr int BINS = 1 << DB, kKeysPerThread = KPT, kTile = kThreads * KPT;
     __shared__ int hist[BINS];
     const int tid = threadIdx.x, tile = blockIdx.x;
     for (int b = tid; b < BINS; b += kThreads) hist[b] = 0;
@@ -93,12 +91,13 @@ __global__ __launch_bounds__(kThreads) void scan_rows_kernel(int *__restrict__ c
     if (tid == 0) totals[blockIdx.x] = carry;
 }
 
-template <class K, int DB, bool HAS_VALS>
+template <class K, int DB, int KPT, bool HAS_VALS>
 __global__ __launch_bounds__(kThreads) void scatter_kernel(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                            K *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int n,
                                                            int shift, int ntiles, const int *__restrict__ counts,
                                                            const int *__restrict__ totals)
 {
+    constexpr int kKeysPerThread = KPT, kTile = kThreads * KPT;
     constexpr int BINS = 1 << DB, W = kThreads / 64, PER_WAVE = kTile / W, BPT = BINS / kThreads;   // bins per thread
     extern __shared__ int run_lds[];                    // [W][BINS] per wave: count of each digit, then the running output offset
     __shared__ int wsum[W];
@@ -165,22 +164,33 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const K *__restrict__
     }
 }
 
-inline int num_tiles(int64_t n) { return (int)((n + kTile - 1) / kTile); }
+// keys per thread: 2048-key tiles below 7e5 keys (4e5 64-bit keys: 71 vs 87 us -- twice the workgroups per CU), 4096-key
+// tiles above (2.8e6 keys: 80 vs 112 us)
+inline int keys_per_thread(int64_t n) { return n < 700000 ? 8 : 16; }
+inline int num_tiles(int64_t n) { const int tile = kThreads * keys_per_thread(n); return (int)((n + tile - 1) / tile); }
 inline size_t temp_bytes(int64_t n) { return (((size_t)1 << kMaxDigitBits) * num_tiles(n) + ((size_t)1 << kMaxDigitBits)) * sizeof(int) + 64; }
+
+template <class K, int DB, int KPT>
+static int one_pass_kpt(int *counts, int *totals, const K *src, K *dst, const uint32_t *vsrc, uint32_t *vdst, int n, int shift,
+                        int ntiles, hipStream_t stream)
+{
+    constexpr int BINS = 1 << DB;
+    const size_t lds = (size_t)(kThreads / 64) * BINS * sizeof(int);
+    count_kernel<K, DB, KPT><<<ntiles, kThreads, 0, stream>>>(src, n, shift, ntiles, counts);
+    scan_rows_kernel<<<BINS, kThreads, 0, stream>>>(counts, ntiles, totals);
+    if (vsrc)
+        scatter_kernel<K, DB, KPT, true><<<ntiles, kThreads, lds, stream>>>(src, vsrc, dst, vdst, n, shift, ntiles, counts, totals);
+    else
+        scatter_kernel<K, DB, KPT, false><<<ntiles, kThreads, lds, stream>>>(src, nullptr, dst, nullptr, n, shift, ntiles, counts, totals);
+    return PLX_OK;
+}
 
 template <class K, int DB>
 static int one_pass(int *counts, int *totals, const K *src, K *dst, const uint32_t *vsrc, uint32_t *vdst, int n, int shift,
                     int ntiles, hipStream_t stream)
 {
-    constexpr int BINS = 1 << DB;
-    const size_t lds = (size_t)(kThreads / 64) * BINS * sizeof(int);
-    count_kernel<K, DB><<<ntiles, kThreads, 0, stream>>>(src, n, shift, ntiles, counts);
-    scan_rows_kernel<<<BINS, kThreads, 0, stream>>>(counts, ntiles, totals);
-    if (vsrc)
-        scatter_kernel<K, DB, true><<<ntiles, kThreads, lds, stream>>>(src, vsrc, dst, vdst, n, shift, ntiles, counts, totals);
-    else
-        scatter_kernel<K, DB, false><<<ntiles, kThreads, lds, stream>>>(src, nullptr, dst, nullptr, n, shift, ntiles, counts, totals);
-    return PLX_OK;
+    return keys_per_thread(n) == 8 ? one_pass_kpt<K, DB, 8>(counts, totals, src, dst, vsrc, vdst, n, shift, ntiles, stream)
+                                   : one_pass_kpt<K, DB, 16>(counts, totals, src, dst, vsrc, vdst, n, shift, ntiles, stream);
 }
 
 // Digit width for end_bit key bits of n keys.  Measured (MI355X, us per pass, 8- / 10-bit digits): n = 1e6 64-bit keys
