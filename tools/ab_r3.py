@@ -49,6 +49,6 @@ for var in args.variants:
         pass
     # defaults of the keys this script touches
     for k in seen:
-        d = {"block_e": 0, "block_multi": 1, "block_multi_splat_pct": 40, "block_dense_combine": 1, "block_path": 1}.get(k)
+        d = {"block_e": 0, "block_dense_combine": 1, "block_path": 1, "order_zcurve": 1, "vertex_order": 1, "order_compact": 1}.get(k)
         if d is not None:
             nv.check(nv.lib().plx_tune(k.encode(), d), "plx_tune")
