@@ -283,6 +283,12 @@ int plx_prepare(plx_lattice *lat, int vd, void *stream);
  * vertex-sorted CSR path instead.  A pure query: no launch, no synchronisation. */
 int64_t plx_block_rows(const plx_lattice *lat);
 
+/* Self test of the build's stable radix sort (plx_radix.h) on the current device: n (key, position) pairs with many
+ * duplicate keys of key_bytes (4 or 8) bytes and end_bit significant bits are sorted and checked on the device --
+ * ascending, equal keys in input order, every value still with its key.  *mismatches = offending positions (0 = pass).
+ * Synchronises the stream.  For tests; no lattice needed. */
+int plx_selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, void *stream, int64_t *mismatches);
+
 /* Per-stage device time of the last plx_build on this lattice, in ms, in the
  * order {order+embed, insert, number, ids, neighbours, csr}; 0 when timing is off.
  * plx_set_timing(lat, 1) turns hipEvent timing on (adds event records only). */

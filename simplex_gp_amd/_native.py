@@ -72,6 +72,7 @@ _SIGNATURES = {
     "plx_last_kernels": (_i32, [_vp, ctypes.c_char_p, _i32]),
     "plx_block_rows": (_i64, [_vp]),
     "plx_prepare": (_i32, [_vp, _i32, _vp]),
+    "plx_selftest_sort": (_i32, [_i64, _i32, _i32, ctypes.c_uint64, _vp, ctypes.POINTER(_i64)]),
     "plx_set_timing": (_i32, [_vp, _i32]),
     "plx_build_times": (_i32, [_vp, _f32p]),
     "plx_apply_times": (_i32, [_vp, _f32p, _i32, ctypes.POINTER(_i32)]),

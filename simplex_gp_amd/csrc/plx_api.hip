@@ -545,6 +545,15 @@ int plx_prepare(plx_lattice *L, int vd, void *stream)
     return prepare_tables(L, vd, (hipStream_t)stream);
 }
 
+int plx_selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, void *stream, int64_t *mismatches)
+{
+    if (n < 1 || n > (1ll << 31) - 8192 || (key_bytes != 4 && key_bytes != 8) || end_bit < 1 || end_bit > 8 * key_bytes || !mismatches) {
+        set_error("plx_selftest_sort: n = %lld, %d-byte keys, %d bits", (long long)n, key_bytes, end_bit);
+        return PLX_ERR_INVALID;
+    }
+    return selftest_sort(n, key_bytes, end_bit, seed, (hipStream_t)stream, mismatches);
+}
+
 int plx_build_times(const plx_lattice *L, float *h_ms6)
 {
     if (!L || !h_ms6) return PLX_ERR_INVALID;

@@ -187,7 +187,8 @@ int radix_sort_pairs64(void *temp, uint64_t *keys_a, uint64_t *keys_b, uint32_t 
                        int *in_second, hipStream_t stream);
 int radix_sort_pairs32(void *temp, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
                        int *in_second, hipStream_t stream);
-// (rocPRIM radix sort of (vertex id, entry index) pairs: the CSR of the multi-column kernels)
+int selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, hipStream_t stream, int64_t *mismatches);
+// (rocPRIM radix sort of (vertex id, entry index) pairs: kept for the 64-bit sorts above 3e6 items)
 int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes);
 int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
                const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit,

@@ -44,6 +44,67 @@ int radix_sort_pairs32(void *temp, uint32_t *keys_a, uint32_t *keys_b, uint32_t 
     return radix::sort_pairs<uint32_t>(temp, keys_a, keys_b, vals_a, vals_b, n, end_bit, in_second, stream);
 }
 
+// ---- self test of the radix sort (plx_selftest_sort): keys with many duplicates, values = positions; sorted + stable?
+template <class K>
+__global__ void selftest_fill_kernel(K *keys, uint32_t *vals, int64_t n, K mask, uint64_t seed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const K wide = (K)h & mask;
+    keys[i] = (h >> 61) ? wide : (wide & (K)0x3FF);          // one key in eight from a 1024-value pool: long runs of equal keys
+    vals[i] = (uint32_t)i;
+}
+
+template <class K>
+__global__ void selftest_check_kernel(const K *keys, const uint32_t *vals, int64_t n, K mask, uint64_t seed,
+                                      unsigned long long *bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = (uint64_t)vals[i] * 0x9E3779B97F4A7C15ull + seed;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const K wide = (K)h & mask;
+    const K want = (h >> 61) ? wide : (wide & (K)0x3FF);
+    bool wrong = keys[i] != want;                              // the value still belongs to its key
+    if (i > 0) wrong = wrong || keys[i - 1] > keys[i] || (keys[i - 1] == keys[i] && vals[i - 1] >= vals[i]);   // sorted, stable
+    if (wrong) atomicAdd(bad, 1ull);
+}
+
+template <class K>
+static int selftest_typed(int64_t n, int end_bit, uint64_t seed, hipStream_t stream, int64_t *mismatches)
+{
+    K *ka = nullptr, *kb = nullptr;
+    uint32_t *va = nullptr, *vb = nullptr;
+    void *tmp = nullptr;
+    unsigned long long *bad = nullptr, h_bad = 0;
+    const K mask = end_bit >= (int)sizeof(K) * 8 ? ~(K)0 : (((K)1 << end_bit) - 1);
+    PLX_HIP_TRY(hipMalloc(&ka, n * sizeof(K))); PLX_HIP_TRY(hipMalloc(&kb, n * sizeof(K)));
+    PLX_HIP_TRY(hipMalloc(&va, n * 4)); PLX_HIP_TRY(hipMalloc(&vb, n * 4));
+    PLX_HIP_TRY(hipMalloc(&tmp, radix_temp_bytes(n))); PLX_HIP_TRY(hipMalloc(&bad, 8));
+    PLX_HIP_TRY(hipMemsetAsync(bad, 0, 8, stream));
+    const int grid = (int)((n + 255) / 256);
+    selftest_fill_kernel<K><<<grid, 256, 0, stream>>>(ka, va, n, mask, seed);
+    int second = 0;
+    int rc = sizeof(K) == 8 ? radix_sort_pairs64(tmp, (uint64_t *)ka, (uint64_t *)kb, va, vb, n, end_bit, &second, stream)
+                            : radix_sort_pairs32(tmp, (uint32_t *)ka, (uint32_t *)kb, va, vb, n, end_bit, &second, stream);
+    if (rc == PLX_OK) {
+        selftest_check_kernel<K><<<grid, 256, 0, stream>>>(second ? kb : ka, second ? vb : va, n, mask, seed, bad);
+        PLX_HIP_TRY(hipMemcpyAsync(&h_bad, bad, 8, hipMemcpyDeviceToHost, stream));
+        PLX_HIP_TRY(hipStreamSynchronize(stream));
+        *mismatches = (int64_t)h_bad;
+    }
+    (void)hipFree(ka); (void)hipFree(kb); (void)hipFree(va); (void)hipFree(vb); (void)hipFree(tmp); (void)hipFree(bad);
+    return rc;
+}
+
+int selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, hipStream_t stream, int64_t *mismatches)
+{
+    return key_bytes == 8 ? selftest_typed<uint64_t>(n, end_bit, seed, stream, mismatches)
+                          : selftest_typed<uint32_t>(n, end_bit, seed, stream, mismatches);
+}
+
 int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes)
 {
     size_t tb = 0;

@@ -543,3 +543,20 @@ def test_torch_extension_matches_ctypes_path(plx):
         ext.filter(v.double(), x, taps)
     with pytest.raises(RuntimeError, match="odd number of taps"):
         ext.filter(v, x, torch.tensor([0.5, 0.5]))
+
+
+def test_radix_sort_selftest(plx):
+    """The build's own stable radix sort (plx_radix.h; rocPRIM above 3e6 64-bit keys) on keys with long runs of
+    duplicates: ascending, equal keys in input order, values still with their keys -- at the sizes and bit counts the
+    build uses (point order, vertex Morton codes, block rows, CSR) and at the edges (1 key, tile boundaries, one bit)."""
+    import ctypes
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cases = [(1, 8, 36), (2, 4, 19), (2047, 8, 40), (2048, 8, 40), (2049, 4, 1), (4097, 4, 19), (100003, 8, 63), (400000, 8, 40),
+             (699999, 8, 37), (700001, 8, 37), (1000000, 8, 36), (2770000, 4, 19), (3000001, 8, 36), (9000000, 4, 21), (1000000, 4, 32),
+             (300000, 8, 64)]
+    for n, key_bytes, bits in cases:
+        bad = ctypes.c_int64(-1)
+        nv.check(lib.plx_selftest_sort(n, key_bytes, bits, 1234 + n, stream, ctypes.byref(bad)), "plx_selftest_sort")
+        assert bad.value == 0, (n, key_bytes, bits, bad.value)
