@@ -454,6 +454,48 @@ __global__ __launch_bounds__(kBlock) void unpermute_kernel(const float *__restri
     }
 }
 
+// The same for rows of vd columns: tmp is [n_own][vdp] in lattice order (whole 16-byte chunks), out is the caller's
+// [n_own][vd].  One thread per (caller row, chunk): a 16-byte gather, then up to four floats of the output row -- lanes
+// run along the output, so the stores of a wave are one contiguous stretch.  (slice_vec_kernel writing the caller's rows
+// itself scatters 4 vd-byte rows: 677 MB of memory-side writes for a 176 MB result at N = 4e6, vd = 11.)
+__global__ __launch_bounds__(kBlock) void unpermute_rows_kernel(const float4 *__restrict__ tmp, const uint32_t *__restrict__ inv,
+                                                                int n_own, int nch, int vd, float *__restrict__ out,
+                                                                const float *__restrict__ affine, const float *__restrict__ src)
+{
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= (int64_t)n_own * nch) return;
+    const int j = (int)(item / nch), ch = (int)(item - (int64_t)j * nch);
+    float4 r = tmp[(size_t)inv[j] * nch + ch];
+    float *o = out + (size_t)j * vd + 4 * ch;
+    const int left = vd - 4 * ch;
+    if (affine) {
+        const float a = affine[0], b = affine[1];
+        const float *sp = src + (size_t)j * vd + 4 * ch;
+        r.x = a * r.x + b * sp[0];
+        if (left > 1) r.y = a * r.y + b * sp[1];
+        if (left > 2) r.z = a * r.z + b * sp[2];
+        if (left > 3) r.w = a * r.w + b * sp[3];
+    }
+    if (left >= 4 && (vd & 3) == 0) {
+        *reinterpret_cast<float4 *>(o) = r;
+    } else {
+        o[0] = r.x;
+        if (left > 1) o[1] = r.y;
+        if (left > 2) o[2] = r.z;
+        if (left > 3) o[3] = r.w;
+    }
+}
+
+int unpermute_rows(plx_lattice *L, const float *d_tmp, int vd, float *d_out, const float *d_affine, const float *d_src,
+                   hipStream_t stream)
+{
+    const int n_own = (int)(L->own_end - L->own_begin), nch = values_stride(vd) / 4;
+    unpermute_rows_kernel<<<ceil_div((int64_t)n_own * nch, kBlock), kBlock, 0, stream>>>(
+        reinterpret_cast<const float4 *>(d_tmp), L->inv_perm.as<uint32_t>(), n_own, nch, vd, d_out, d_affine, d_src);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
 // inv_perm[caller row within the shard] = position of that row in lattice order (within the shard)
 __global__ __launch_bounds__(kBlock) void inv_perm_kernel(const uint32_t *__restrict__ perm, int own_begin, int n_own,
                                                           uint32_t *__restrict__ inv)
@@ -537,6 +579,20 @@ static int choose_block_e(int n_own, int d1)
     return best;
 }
 
+// lattice-order position of every caller row of the shard: the gather-out passes of slice (built by their first user)
+int ensure_inv_perm(plx_lattice *L, hipStream_t stream)
+{
+    if (L->inv_perm_ready) return PLX_OK;
+    const int n_own = (int)(L->own_end - L->own_begin);
+    PLX_TRY(ensure(L->inv_perm, (size_t)n_own * 4 + 16));
+    if (n_own > 0)
+        inv_perm_kernel<<<ceil_div(n_own, kBlock), kBlock, 0, stream>>>(L->perm.as<uint32_t>(), (int)L->own_begin, n_own,
+                                                                        L->inv_perm.as<uint32_t>());
+    PLX_HIP_TRY(hipGetLastError());
+    L->inv_perm_ready = true;
+    return PLX_OK;
+}
+
 int ensure_blocks(plx_lattice *L, hipStream_t stream)
 {
     if (L->blocks_ready) return PLX_OK;
@@ -584,9 +640,7 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     if (g_block_path == 1 && 10 * nrows > 7 * nnz) return PLX_OK;   // too little sharing inside blocks: CSR path
     PLX_TRY(ensure(L->brow_vid, (size_t)nrows * 4 + 16));
     PLX_TRY(compact_block_rows(L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), cpb, nblocks, L->brow_vid.as<int>(), stream));
-    PLX_TRY(ensure(L->inv_perm, (size_t)n_own * 4 + 16));
-    inv_perm_kernel<<<ceil_div(n_own, kBlock), kBlock, 0, stream>>>(L->perm.as<uint32_t>(), (int)L->own_begin, n_own,
-                                                                    L->inv_perm.as<uint32_t>());
+    PLX_TRY(ensure_inv_perm(L, stream));
     PLX_HIP_TRY(hipGetLastError());
     L->use_blocks = true;
     return PLX_OK;

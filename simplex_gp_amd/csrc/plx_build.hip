@@ -1345,6 +1345,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     L->csr_ready = false;
     L->blocks_ready = false;
     L->s2_ready = false;
+    L->inv_perm_ready = false;
     L->use_blocks = false;
     mark();
     PLX_HIP_TRY(hipGetLastError());

@@ -139,6 +139,7 @@ struct plx_lattice {
     int64_t n_s2waves = 0;
     plx::DevBuf partial;    // float  [n_brows]      per-MVM block-row sums
     plx::DevBuf inv_perm;   // uint32 [n_own]        lattice-order position of every caller row of the shard
+    bool inv_perm_ready = false;
 
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
@@ -174,7 +175,10 @@ int ensure_csr(plx_lattice *L, hipStream_t stream);       // vertex-sorted splat
 // plx_block.hip (block tables + the vd = 1 kernels that use them)
 int build_blocks(plx_lattice *L, hipStream_t stream);
 int ensure_blocks(plx_lattice *L, hipStream_t stream);    // the block tables of the current build (built by their first user)
-int ensure_s2(plx_lattice *L, hipStream_t stream);        // ... and their vertex-sorted half (block splat only)
+int ensure_s2(plx_lattice *L, hipStream_t stream);
+int ensure_inv_perm(plx_lattice *L, hipStream_t stream);  // caller row -> lattice position (gather-out passes of slice)
+int unpermute_rows(plx_lattice *L, const float *d_tmp, int vd, float *d_out, const float *d_affine, const float *d_src,
+                   hipStream_t stream);              // out[j][0..vd) = tmp[inv_perm[j]][0..vd) (+ affine epilogue)        // ... and their vertex-sorted half (block splat only)
 int choose_paths(plx_lattice *L, int vd, hipStream_t stream, bool *splat_blocks, bool *slice_blocks);
 int prepare_tables(plx_lattice *L, int vd, hipStream_t stream);
 int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);

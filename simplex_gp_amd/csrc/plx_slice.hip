@@ -173,18 +173,40 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
     } else {
         L->kn_slice = "slice_vec_kernel";
         const int nch = values_stride(vd) / 4;
+        // caller row order on LARGE outputs: slice into a lattice-ordered scratch of whole 16-byte chunks (coalesced), then
+        // gather the rows out.  Scattering 4 vd-byte rows from the slice kernel costs 3.8x the output in memory-side writes
+        // once the output no longer sits in the caches (N = 4e6, vd = 11: slice 422 -> 371 us with the two steps); while it
+        // does, the extra pass costs more than it saves (N = 1e6, vd = 11: 65.7 -> 74.3 us), so the gate is the output size.
+        // Not used when the caller wants the column dots (those callers run in lattice row order anyway).
+        const bool two_step = perm != nullptr && d_dot_partial == nullptr && g_unpermute_gather != 0 &&
+                              (int64_t)n_own * vd * 4 > (96ll << 20);
+        float *slice_out = d_out;
+        const float *slice_affine = d_affine;
+        int slice_vd = vd;
+        if (two_step) {
+            PLX_TRY(ensure_inv_perm(L, stream));
+            PLX_TRY(ensure(L->ssrc, (size_t)n_own * nch * 16 + 16));
+            slice_out = L->ssrc.as<float>();
+            slice_affine = nullptr;
+            slice_vd = 4 * nch;
+            perm = nullptr;
+        }
         const int nt = ceil_div((int64_t)n_own * nch, kBlock);
         const float4 *v4 = reinterpret_cast<const float4 *>(d_values);
         const float rden = 1.0f / L->slice_denom;
         const int grid = tile_grid(nt, g_xcd_remap);
         switch (L->d + 1 <= kSliceMaxD1 ? L->d + 1 : 0) {
 #define PLX_CASE(D1) \
-    case D1: slice_vec_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, L->d + 1, v4, nch, vd, rden, d_out, nt, g_xcd_remap, d_affine, d_src, d_dot_partial); break;
+    case D1: slice_vec_kernel<D1><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, L->d + 1, v4, nch, slice_vd, rden, slice_out, nt, g_xcd_remap, slice_affine, d_src, d_dot_partial); break;
             PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9) PLX_CASE(10)
             PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17) PLX_CASE(18)
             PLX_CASE(19) PLX_CASE(20)
 #undef PLX_CASE
-        default: slice_vec_kernel<0><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, L->d + 1, v4, nch, vd, rden, d_out, nt, g_xcd_remap, d_affine, d_src, d_dot_partial); break;
+        default: slice_vec_kernel<0><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, L->d + 1, v4, nch, slice_vd, rden, slice_out, nt, g_xcd_remap, slice_affine, d_src, d_dot_partial); break;
+        }
+        if (two_step) {
+            PLX_TRY(unpermute_rows(L, slice_out, vd, d_out, d_affine, d_src, stream));
+            L->kn_slice = "slice_vec_kernel+unpermute_rows_kernel";
         }
     }
     tmark(L, stream);
