@@ -51,7 +51,7 @@ int g_order_compact = 1; // 1: point-order keys over exactly the bits every coor
 int g_order_zcurve = 1;  // 1: points ordered along the Z-curve of their rounded lattice coordinates; 0: lexicographically; 2: Z-curve of the blur-axis coordinates
 int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only and mirrors the hits
                               // (fine regime 7.2 -> 4.9 ms; an occupancy bitmap on top did not pay)
-int g_insert_dedupe = 1;      // wave-level skip of repeated keys in the hashed insert (0.38 -> 0.32 ms at m = 4e5)
+int g_insert_dedupe = 2;      // hashed insert: 2 = every key of a wave probes once (in-wave match by hash ballots), 1 = runs of equal neighbouring lanes probe once, 0 = every lane probes
 int g_compact_nbr = 1;        // 0 never, 1 when under half of the neighbour slots exist, 2 always (A/B)
 
 // ----------------------------------------------------------------------------
@@ -487,23 +487,43 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restri
     uint32_t k[DW];
     load_key<DW>(ekeys, idx, k);
 
-    // Points are in lattice order, so the lanes of a wave (consecutive points, same corner index r)
-    // often carry the same key.  Only the first lane of each run of equal keys probes the table (it
-    // also has the smallest entry index of the run); the others copy its slot.
-    bool same_as_prev = false;
-    if (dedupe) {
-        same_as_prev = lane > 0 && valid;
+    // Points are in lattice order, so the lanes of a wave (64 consecutive points, same corner index r) carry few distinct
+    // keys: 0.47 per lane at N = 1e6, d = 8 (0.85 if only runs of equal NEIGHBOURING lanes are merged, the round-1 form:
+    // dedupe = 1).  dedupe = 2: every lane finds the lowest lane of the wave with its key -- candidates by 10 bits of the
+    // key hash (one ballot per bit), confirmed by comparing the key itself with that lane's -- and only those leaders
+    // probe the table; a leader has the smallest entry index of its group.  A lane whose candidate turns out to hold
+    // another key (a hash collision inside the wave, < 1 %) simply probes for itself.
+    const uint32_t hk = mix_hash(k, DW);
+    int leader = lane;
+    if (dedupe == 2) {
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 10; ++b) {
+            const bool bit = (hk >> (22 + b)) & 1u;
+            const unsigned long long mb = __ballot(bit);
+            peers &= bit ? mb : ~mb;
+        }
+        const int cand = valid ? __ffsll((long long)peers) - 1 : lane;
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < DW; ++j) same = same && (__shfl(k[j], cand) == k[j]);
+        leader = same ? cand : lane;
+    } else if (dedupe) {
+        bool same_as_prev = lane > 0 && valid;
 #pragma unroll
         for (int j = 0; j < DW; ++j) {
             const uint32_t prev = __shfl_up(k[j], 1);
             same_as_prev = same_as_prev && (prev == k[j]);
         }
+        // slot of the nearest leader at or below this lane
+        const unsigned long long heads = __ballot(valid && !same_as_prev);
+        const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+        leader = below ? 63 - __clzll(below) : lane;
     }
-    const unsigned long long leaders = __ballot(valid && !same_as_prev);
 
     uint32_t h = 0;
-    if (valid && !same_as_prev) {
-        h = mix_hash(k, DW) & mask;
+    if (valid && leader == lane) {
+        h = hk & mask;
         for (;;) {
             uint32_t o = table[h];
             if (o == kEmpty) {
@@ -521,29 +541,32 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restri
             h = (h + 1) & mask;
         }
     }
-    if (dedupe) {
-        // slot of the nearest leader at or below this lane
-        const unsigned long long below = leaders & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-        const int src = below ? 63 - __clzll(below) : lane;
-        h = __shfl(h, src);
-    }
+    if (dedupe) h = __shfl(h, leader);
     if (valid) eslot[idx] = h;
 }
 
 // ----------------------------------------------------------------------------
 // number: first-touch flags per point, counted per workgroup ...
 
+template <int D1>
 __global__ __launch_bounds__(kBlock) void flag_kernel(const uint32_t *__restrict__ eslot,
-                                                      const uint32_t *__restrict__ table, int n, int d1,
+                                                      const uint32_t *__restrict__ table, int n,
                                                       uint32_t *__restrict__ flagmask,
                                                       int *__restrict__ blockcnt)
 {
+    // d+1 compiled in: all slot loads, then all table gathers, are in flight together (with a runtime trip count every
+    // corner waited for its own slot and then for its own table word: 2 (d+1) dependent round trips per thread)
     const int p = blockIdx.x * kBlock + threadIdx.x;
     uint32_t bits = 0, bits_hi = 0;
     if (p < n) {
-        for (int r = 0; r < d1; ++r) {
-            uint32_t slot = eslot[(size_t)r * n + p];
-            bool first = table[slot] == (uint32_t)p * d1 + r;
+        uint32_t slot[D1], owner[D1];
+#pragma unroll
+        for (int r = 0; r < D1; ++r) slot[r] = eslot[(size_t)r * n + p];
+#pragma unroll
+        for (int r = 0; r < D1; ++r) owner[r] = table[slot[r]];
+#pragma unroll
+        for (int r = 0; r < D1; ++r) {
+            const bool first = owner[r] == (uint32_t)p * D1 + r;
             if (r < 32) bits |= (first ? 1u : 0u) << r;
             else bits_hi |= (first ? 1u : 0u) << (r - 32);
         }
@@ -1083,8 +1106,8 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
         L->ekeys.as<uint32_t>(), n, L->table.as<uint32_t>(), L->table_mask, L->eslot.as<uint32_t>(), g_insert_dedupe,
         plane_fast);
     mark();
-    flag_kernel<<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n, D1,
-                                                L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
+    flag_kernel<D1><<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
+                                                    L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
     scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
     int h_cnt[2];
     PLX_TRY(read_back(L, L->counters.as<int>(), 2, h_cnt, stream));   // m sizes everything below

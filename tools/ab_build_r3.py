@@ -16,7 +16,7 @@ ap.add_argument("--variants", nargs="*", default=[""])
 args = ap.parse_args()
 x, v = bench.synth(args.n, args.d, args.vd)
 ref = (x / args.ell).contiguous().cuda()
-DEFAULTS = {"order_compact": 1, "block_e": 0, "vertex_order": 1, "sort_points": 1, "order_zcurve": 1}
+DEFAULTS = {"order_compact": 1, "block_e": 0, "vertex_order": 1, "sort_points": 1, "order_zcurve": 1, "insert_dedupe": 2}
 lat = plx.Lattice()
 for var in args.variants:
     for k, val in DEFAULTS.items():

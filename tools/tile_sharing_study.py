@@ -66,3 +66,19 @@ for T in (256, 1024):
 for B, T in ((448, 256), (448, 1024)):
     seg = np.unique((pid // B) * (m // T + 1) + evm // T).size
     print(f"(block {B}, tile {T}) segments: {seg}  = {seg/((n+B-1)//B):.1f} per block")
+
+# hashed insert, one wave = corner plane r of 64 consecutive points: how many distinct keys does a wave probe
+# (a) as it is (lanes equal to their left neighbour copy its slot), (b) with a full in-wave de-duplication,
+# (c) if a wave took ALL d+1 corners of 7 consecutive points (63 lanes) and de-duplicated those
+W = 64
+nw = n // W
+evw = evm[: nw * W].reshape(nw, W, d + 1)
+adj = (evw[:, 1:, :] != evw[:, :-1, :]).sum() + nw * (d + 1)
+full = sum(len(np.unique(evw[i, :, r])) for i in range(0, nw, 50) for r in range(d + 1)) * 50 / 1.0
+print(f"probes per corner: adjacent-lane dedupe {adj / (nw * W * (d + 1)):.3f}, full in-wave dedupe {full / (nw * W * (d + 1)):.3f}")
+g7 = evm[: (n // 7) * 7].reshape(-1, 7 * (d + 1))
+c7 = sum(len(np.unique(g7[i])) for i in range(0, g7.shape[0], 50)) * 50
+print(f"all corners of 7 consecutive points per wave, de-duplicated: {c7 / (g7.shape[0] * 7 * (d + 1)):.3f} probes per corner")
+g28 = evm[: (n // 28) * 28].reshape(-1, 28 * (d + 1))
+c28 = sum(len(np.unique(g28[i])) for i in range(0, g28.shape[0], 50)) * 50
+print(f"all corners of 28 consecutive points per workgroup (252 threads), de-duplicated: {c28 / (g28.shape[0] * 28 * (d + 1)):.3f} probes per corner")
