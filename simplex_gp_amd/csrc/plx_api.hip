@@ -35,7 +35,11 @@ int ensure(DevBuf &b, size_t bytes)
     const hipStream_t s = g_entry_stream;
     if (b.p) {
         // work queued on another stream may still read the old buffer: wait for that stream, not for the device
-        if (b.owner != s) PLX_HIP_TRY(hipStreamSynchronize(b.owner));
+        // (that stream may have been destroyed by its owner since: then wait for the device instead)
+        if (b.owner != s && hipStreamSynchronize(b.owner) != hipSuccess) {
+            (void)hipGetLastError();
+            PLX_HIP_TRY(hipDeviceSynchronize());
+        }
         PLX_HIP_TRY(hipFreeAsync(b.p, s));
         b.p = nullptr;
         b.cap = 0;
