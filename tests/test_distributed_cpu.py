@@ -129,6 +129,40 @@ def test_sharded_build_from_local_rows_matches_oracle(tmp_path, world):
         oracle.set_exact_mode(True)
 
 
+def _forced_world1_worker(rank, world, port, n, d, vd, outdir):
+    """distributed.FORCE_COLLECTIVES with ONE rank (the switch behind tests/checks/rccl_world1.py and bench.py's
+    single-rank RCCL rehearsal), here under gloo: the build takes the local-rows path (key all-gather, merge) and every
+    MVM runs its all-reduce; the numbers equal those of the plain path."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.oracle_lattice_adapter import OracleLattice
+    from simplex_gp_amd import distributed as pd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn(n, d, generator=g)
+        v = torch.randn(n, vd, generator=g)
+        plain = ShardedLatticeMVM.from_local_rows(x, RBF1, lattice=OracleLattice(), n_total=n)
+        assert not hasattr(plain, "key_bytes_exchanged")                # one rank, nothing forced: no exchange at all
+        want = plain.matmul(v)
+        pd.FORCE_COLLECTIVES = True
+        try:
+            op = ShardedLatticeMVM.from_local_rows(x, RBF1, lattice=OracleLattice(), n_total=n)
+            assert op.key_bytes_exchanged > 0 and (op.lo, op.hi, op.n) == (0, n, n) and op.m == plain.m
+            got = op.matmul(v)
+        finally:
+            pd.FORCE_COLLECTIVES = False
+        np.save(os.path.join(outdir, "diff.npy"), np.array(float((got - want).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collectives_with_one_rank(tmp_path):
+    mp.spawn(_forced_world1_worker, args=(1, _free_port(), 600, 3, 2, str(tmp_path)), nprocs=1, join=True)
+    assert float(np.load(tmp_path / "diff.npy")) <= 1e-6
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 1000, 1001):
         for world in (1, 2, 3, 8):

@@ -82,3 +82,12 @@ print(f"all corners of 7 consecutive points per wave, de-duplicated: {c7 / (g7.s
 g28 = evm[: (n // 28) * 28].reshape(-1, 28 * (d + 1))
 c28 = sum(len(np.unique(g28[i])) for i in range(0, g28.shape[0], 50)) * 50
 print(f"all corners of 28 consecutive points per workgroup (252 threads), de-duplicated: {c28 / (g28.shape[0] * 28 * (d + 1)):.3f} probes per corner")
+
+# per-block range of (Morton) vertex ids: how many key bits would a per-block sort need after subtracting the block minimum?
+for B in (448, 672):
+    nb = n // B
+    blk = evm[: nb * B].reshape(nb, B * (d + 1))
+    span = blk.max(1) - blk.min(1)
+    bits = np.ceil(np.log2(span + 2)).astype(int)
+    print(f"blocks of {B} points: vertex-id span bits: median {int(np.median(bits))}, 90 % <= {int(np.percentile(bits, 90))}, max {bits.max()} (m needs {int(np.ceil(np.log2(m)))}); "
+          f"share of blocks needing <= 16 bits: {(bits <= 16).mean():.2f}, <= 12: {(bits <= 12).mean():.2f}")
