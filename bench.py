@@ -453,7 +453,8 @@ def config5_leg(ctx, n=10623, d=18):
 
 def exchange_record(job, vd, stage_us):
     """The one exchange step of a sharded MVM: what moves, how many bytes per rank, and its device time."""
-    return {"kind": "all_reduce(sum) of the vertex accumulator values[m, %d] (fp32), RCCL" % job.lat.values_stride(vd),
+    transport = "RCCL" if job.ctx.backend == "nccl" else job.ctx.backend
+    return {"kind": "all_reduce(sum) of the vertex accumulator values[m, %d] (fp32), %s" % (job.lat.values_stride(vd), transport),
             "bytes": job.op.exchange_bytes(vd), "us": stage_us.get("exchange")}
 
 
