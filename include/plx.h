@@ -247,9 +247,13 @@ int plx_copy_point_perm(plx_lattice *lat, void *d_dst, void *stream);
 int64_t plx_export_bytes(const plx_lattice *lat, int which);
 
 /* Select a kernel variant by name: for A/B measurements in one process -- the defaults are the shipped configuration.
- * Process-wide and not synchronised: every entry point reads the switches once, when it is called, and whatever a build
- * decided (block size, vertex numbering, which tables exist) is recorded in the lattice and stays valid under later
- * changes; do not call plx_tune while another thread is inside a plx_* call.  Keys (default):
+ * plx_tune sets the PROCESS DEFAULT of a switch.  A lattice never reads the defaults while it works: every build
+ * (plx_build, plx_build_local, plx_filter) starts by copying them into the lattice, and every later call on that lattice
+ * (its merge, tables, MVMs, exports) runs under that copy -- so a plx_tune call changes nothing for lattices that are
+ * already built, two lattices built under different settings keep their own, and a thread that tunes while another
+ * thread is inside a plx_* call on a built lattice does not disturb it (concurrent plx_tune and build calls still need
+ * the caller's own ordering: the copy is a plain struct copy).  plx_lattice_tune changes a switch in ONE lattice's copy,
+ * effective from its next call until its next build (A/B of MVM-side variants over the same tables).  Keys (default):
  *   "sort_points" (1; 0 keeps the caller's point order), "order_zcurve" (1; 0 = lexicographic point order, 2 = Z-curve of
  *   the blur-axis coordinates), "order_compact" (1 = point-order keys laid out over exactly the bits each coordinate's
  *   range needs; 0 = a fixed 7 bits per coordinate), "readback_spin" (1 = counts come back through the mailbox; 0 = stream
@@ -267,6 +271,7 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  * The diagnostic ablations "splat_ablate" / "blur_ablate" / "block_ablate" exist only in libplx_diag.so (make diag).
  * Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);
+int plx_lattice_tune(plx_lattice *lat, const char *key, int value);
 
 /* Names of the kernels the last plx_splat / plx_blur / plx_slice (or plx_apply) on this lattice launched, as
  * "splat=a+b;blur_axis=c;slice=d;vertex_order=morton|first_touch" -- the names rocprofv3 --kernel-trace shows (without

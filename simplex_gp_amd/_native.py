@@ -69,6 +69,7 @@ _SIGNATURES = {
     "plx_export_bytes": (_i64, [_vp, _i32]),
     "plx_copy_point_perm": (_i32, [_vp, _vp, _vp]),
     "plx_tune": (_i32, [ctypes.c_char_p, _i32]),
+    "plx_lattice_tune": (_i32, [_vp, ctypes.c_char_p, _i32]),
     "plx_last_kernels": (_i32, [_vp, ctypes.c_char_p, _i32]),
     "plx_block_rows": (_i64, [_vp]),
     "plx_prepare": (_i32, [_vp, _i32, _vp]),

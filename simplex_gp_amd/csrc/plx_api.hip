@@ -22,10 +22,17 @@ void set_error(const char *fmt, ...)
 // The stream of the entry point that is running on this thread: buffers grow stream-ordered on it (hipFreeAsync +
 // hipMallocAsync), so the first MVM that needs a wider workspace does not synchronise the device the way hipFree does.
 static thread_local hipStream_t g_entry_stream = nullptr;
-struct StreamScope {
+// ... and the switches of the lattice it serves (Tune): a build takes a fresh snapshot of the process defaults first.
+struct EntryScope {
     hipStream_t prev;
-    explicit StreamScope(void *s) : prev(g_entry_stream) { g_entry_stream = (hipStream_t)s; }
-    ~StreamScope() { g_entry_stream = prev; }
+    const Tune *prev_tune;
+    EntryScope(plx_lattice *L, void *s, bool new_build = false) : prev(g_entry_stream), prev_tune(tl_tune)
+    {
+        g_entry_stream = (hipStream_t)s;
+        if (L && new_build) L->tn = g_tune_defaults;
+        tl_tune = L ? &L->tn : &g_tune_defaults;
+    }
+    ~EntryScope() { g_entry_stream = prev; tl_tune = prev_tune; }
 };
 
 int ensure(DevBuf &b, size_t bytes)
@@ -144,7 +151,7 @@ void plx_destroy(plx_lattice *L)
 static int build_entry(plx_lattice *L, const float *d_ref, int64_t n, int d, const float *h_taps, int ntaps,
                        int shard_index, int n_shards, void *stream, bool single_use)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream, true);
     if (!L || !d_ref || !h_taps) { set_error("plx_build: NULL argument"); return PLX_ERR_INVALID; }
     if (n <= 0) { set_error("plx_build: n = %lld must be positive", (long long)n); return PLX_ERR_INVALID; }
     if (d < 1 || d > PLX_MAX_DIM) { set_error("plx_build: d = %d outside 1..%d", d, PLX_MAX_DIM); return PLX_ERR_DIM; }
@@ -184,7 +191,7 @@ int plx_build(plx_lattice *L, const float *d_ref, int64_t n, int d, const float 
 int plx_build_local(plx_lattice *L, const float *d_ref_local, int64_t n_local, int d, const float *h_taps, int ntaps,
                     void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream, true);
     if (!L || !d_ref_local || !h_taps) { set_error("plx_build_local: NULL argument"); return PLX_ERR_INVALID; }
     if (n_local <= 0) { set_error("plx_build_local: n_local = %lld must be positive", (long long)n_local); return PLX_ERR_INVALID; }
     if (d < 1 || d > PLX_MAX_DIM) { set_error("plx_build_local: d = %d outside 1..%d", d, PLX_MAX_DIM); return PLX_ERR_DIM; }
@@ -217,7 +224,7 @@ int64_t plx_local_vertices(const plx_lattice *L) { return (L && (L->local_ready 
 
 int plx_copy_local_keys(plx_lattice *L, void *d_dst, void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     if (!L || !d_dst) { set_error("plx_copy_local_keys: NULL argument"); return PLX_ERR_INVALID; }
     if (!L->local_ready) { set_error("plx_copy_local_keys: call plx_build_local first"); return PLX_ERR_STATE; }
     DeviceGuard g(L->device);
@@ -229,7 +236,7 @@ int plx_copy_local_keys(plx_lattice *L, void *d_dst, void *stream)
 int plx_build_merge(plx_lattice *L, const void *d_all_keys, const int64_t *h_counts, int n_ranks, int my_rank, int64_t total_points,
                     void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     if (!L || !d_all_keys || !h_counts) { set_error("plx_build_merge: NULL argument"); return PLX_ERR_INVALID; }
     if (!L->local_ready) { set_error("plx_build_merge: call plx_build_local first"); return PLX_ERR_STATE; }
     if (n_ranks < 1 || my_rank < 0 || my_rank >= n_ranks) {
@@ -283,7 +290,7 @@ static int check_apply(const plx_lattice *L, const void *a, const void *b, int v
 
 int plx_splat(plx_lattice *L, const float *d_src, int vd, float *d_values, void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     // a rank that owns no rows has no source block: only the accumulator is required
     if (L && L->built && L->own_end == L->own_begin && !d_src) d_src = d_values;
     PLX_TRY(check_apply(L, d_src, d_values, vd, "plx_splat"));
@@ -293,7 +300,7 @@ int plx_splat(plx_lattice *L, const float *d_src, int vd, float *d_values, void 
 
 int plx_blur(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch, void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     PLX_TRY(check_apply(L, d_values, d_scratch, vd, "plx_blur"));
     if (!result_in_scratch) { set_error("plx_blur: result_in_scratch is NULL"); return PLX_ERR_INVALID; }
     DeviceGuard g(L->device);
@@ -302,7 +309,7 @@ int plx_blur(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *res
 
 int plx_slice(plx_lattice *L, const float *d_values, int vd, float *d_out, void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     if (L && L->built && L->own_end == L->own_begin && !d_out) d_out = const_cast<float *>(d_values);
     PLX_TRY(check_apply(L, d_values, d_out, vd, "plx_slice"));
     DeviceGuard g(L->device);
@@ -339,7 +346,7 @@ int64_t plx_affine_dot_work_floats(const plx_lattice *L, int vd)
 int plx_apply_affine_dot(plx_lattice *L, const float *d_src, int vd, float *d_out, const float *d_scale_shift,
                          float *d_dot, float *d_work, void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     if (!d_scale_shift || !d_dot || !d_work) { set_error("plx_apply_affine_dot: NULL argument"); return PLX_ERR_INVALID; }
     if (d_src == d_out) { set_error("plx_apply_affine_dot: d_out must not alias d_src"); return PLX_ERR_INVALID; }
     if (vd < 2 || vd > 256) { set_error("plx_apply_affine_dot: vd = %d outside 2..256 (use plx_apply_affine + plx_coldot)", vd); return PLX_ERR_INVALID; }
@@ -361,7 +368,7 @@ int plx_apply_affine_dot(plx_lattice *L, const float *d_src, int vd, float *d_ou
 static int apply_common(plx_lattice *L, const float *d_src, int vd, float *d_out, const float *d_affine, void *stream,
                         const char *who)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     PLX_TRY(check_apply(L, d_src, d_out, vd, who));
     DeviceGuard g(L->device);
     PLX_TRY(ensure(L->val_a, (size_t)L->m * values_stride(vd) * 4));
@@ -378,7 +385,7 @@ static int apply_common(plx_lattice *L, const float *d_src, int vd, float *d_out
 int plx_apply_backward(plx_lattice *L, const float *d_g, const float *d_src, const float *d_ref, int nrhs,
                        float *d_grad_ref, float *d_grad_src, void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     if (!L) { set_error("plx_apply_backward: NULL lattice"); return PLX_ERR_INVALID; }
     if (!L->built) { set_error("plx_apply_backward: lattice not built"); return PLX_ERR_STATE; }
     if (L->n_shards != 1 || L->partial_cover) {
@@ -434,7 +441,7 @@ int64_t plx_export_bytes(const plx_lattice *L, int which)
 
 int plx_export(plx_lattice *L, int which, void *h_dst, int64_t bytes, void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     if (!L || !h_dst) { set_error("plx_export: NULL argument"); return PLX_ERR_INVALID; }
     if (!L->built) { set_error("plx_export: lattice not built"); return PLX_ERR_STATE; }
     const int64_t want = plx_export_bytes(L, which);
@@ -491,9 +498,18 @@ int plx_export(plx_lattice *L, int which, void *h_dst, int64_t bytes, void *stre
 int plx_tune(const char *key, int value)
 {
     if (!key) return PLX_ERR_INVALID;
-    for (Tunable *t = tunables(); t->name; ++t)
-        if (strcmp(t->name, key) == 0) { *t->value = value; return PLX_OK; }
+    for (const Tunable *t = tunables(); t->name; ++t)
+        if (strcmp(t->name, key) == 0) { g_tune_defaults.*(t->member) = value; return PLX_OK; }
     set_error("plx_tune: unknown key %s", key);
+    return PLX_ERR_INVALID;
+}
+
+int plx_lattice_tune(plx_lattice *L, const char *key, int value)
+{
+    if (!L || !key) { set_error("plx_lattice_tune: NULL argument"); return PLX_ERR_INVALID; }
+    for (const Tunable *t = tunables(); t->name; ++t)
+        if (strcmp(t->name, key) == 0) { L->tn.*(t->member) = value; return PLX_OK; }
+    set_error("plx_lattice_tune: unknown key %s", key);
     return PLX_ERR_INVALID;
 }
 
@@ -541,7 +557,7 @@ int64_t plx_block_rows(const plx_lattice *L)
 
 int plx_prepare(plx_lattice *L, int vd, void *stream)
 {
-    StreamScope sc(stream);
+    EntryScope sc(L, stream);
     if (!L) { set_error("plx_prepare: NULL lattice"); return PLX_ERR_INVALID; }
     if (!L->built) { set_error("plx_prepare: lattice not built"); return PLX_ERR_STATE; }
     if (vd < 1) { set_error("plx_prepare: vd = %d must be positive", vd); return PLX_ERR_INVALID; }

@@ -28,15 +28,6 @@
 
 namespace plx {
 
-int g_block_path = 1;        // 0 never, 1 when the lattice qualifies (see build_blocks), 2 whenever representable
-#ifdef PLX_DIAG
-int g_block_ablate = 0;      // libplx_diag.so only: 1 combine without the partial gathers, 2 combine without idx loads too, 4 combine without stores
-#endif
-int g_scatter_store = 0;     // slice's row-scattered output stores: 0 plain, 1 non-temporal, 2 agent-scope (write-through)
-int g_unpermute_gather = 1;  // caller row order out of the block slice: 1 = lattice-ordered scratch + a gather pass, 0 = scatter from the slice kernel
-int g_block_e = 0;           // corners per thread of the block kernels (a block holds 256 * e corners): 0 = per lattice (choose_block_e), 16 or 24
-int g_block_dense_combine = 1;      // combine numbers the vertices by counting row ends (no s2_vid stream) when every vertex has block rows
-
 constexpr int kBlkT = 256;       // threads per block workgroup
 constexpr int kCombineRun = 256; // block rows per wave of splat_combine_kernel
 constexpr int kBlkMaxP = 1024;    // most points per block (d <= 2: fewer corners than a block could hold)

@@ -173,7 +173,6 @@ __global__ __launch_bounds__(kBlock) void blur_axis_compact_kernel(const float *
 // vertex numbering, us per MVM with / without pairs: 94 / 99 at m = 4.0e5, 162 / 168 at m = 5.2e5 (N = 2e6), 286 / 286 at
 // m = 6.6e5 (N = 4e6), 124 / 116 at m = 7.9e5, 188 / 172 at m = 1.7e6).
 constexpr int kPairMaxVertices = 600000;
-int g_blur_fuse = 1;     // 0: one axis per launch; 1: axis pairs when order = 1, vd = 1 and m <= kPairMaxVertices; 2: whenever order = 1
 
 // slot = 3 * (b + 1) + (a + 1) without the centre (b = a = 0): 0..3 -> (b,a) = (-1,-1) (-1,0) (-1,+1) (0,-1); 4..7 -> (0,+1) (+1,-1) (+1,0) (+1,+1)
 __global__ __launch_bounds__(kBlock) void pair_nbr_kernel(const int *__restrict__ nbr, int m, int64_t mstride,
@@ -271,7 +270,6 @@ __global__ __launch_bounds__(kBlock) void blur_pair_v1_kernel(const float *__res
 // 2 x 2 of the single passes (they are near in id since the vertices are numbered along the Morton curve of the axis
 // coordinates).  Same operations in the same order as two blur_axis_narrow_kernel launches.  (Two items per thread,
 // kBlock apart, all loads first: 77 us against 59 us per launch at m = 1.73e6, vd = 12 -- occupancy, not latency.)
-int g_blur_fuse_vec = 1;   // 0: one axis per launch for vd > 1; 1: axis pairs when order = 1 and the row has 2..4 chunks
 
 template <int ROWLEN>
 __global__ __launch_bounds__(kBlock) void blur_pair_narrow_kernel(const float4 *__restrict__ old, float4 *__restrict__ out,

@@ -45,15 +45,6 @@
 
 namespace plx {
 
-int g_sort_points = 1;   // plx_tune("sort_points", 0) keeps the caller's point order (A/B only)
-int g_readback_spin = 1; // read_back: 1 = spin on the mailbox word, 0 = wait for the stream (A/B)
-int g_order_compact = 1; // 1: point-order keys over exactly the bits every coordinate's range needs (one small read-back per build); 0: a fixed 7 / 8 bits per coordinate
-int g_order_zcurve = 1;  // 1: points ordered along the Z-curve of their rounded lattice coordinates; 0: lexicographically; 2: Z-curve of the blur-axis coordinates
-int g_nbr_symmetric = 1;      // neighbour build looks up the positive taps only and mirrors the hits
-                              // (fine regime 7.2 -> 4.9 ms; an occupancy bitmap on top did not pay)
-int g_insert_dedupe = 2;      // hashed insert: 2 = every key of a wave probes once (in-wave match by hash ballots), 1 = runs of equal neighbouring lanes probe once, 0 = every lane probes
-int g_compact_nbr = 1;        // 0 never, 1 when under half of the neighbour slots exist, 2 always (A/B)
-
 // ----------------------------------------------------------------------------
 // small device helpers
 
@@ -871,8 +862,6 @@ static float taps_variance(const float *c, int R)
 // (1.275 ms).  With only the first corner of every vertex per 256-point block probing (a workgroup-level LDS
 // de-duplication would achieve that) the plane-major insert took 219 us, with only the 4e5 first-touch corners 67 us:
 // the duplicate lookups are what costs, and time locality removes most of that without the LDS stage.
-int g_insert_plane_fast = 1;
-int g_vertex_order = 1;      // 0: first touch; 1: Morton order where it pays (kMortonMinVertices <= m <= 0.9 corners); 2: always
 constexpr int kMortonMinVertices = 65536;
 
 // blur-axis coordinates a_c = (k_d - k_c) / (d+1), c < d, of a vertex (k_d = -sum k_c; exact: all coordinates of a lattice

@@ -43,10 +43,77 @@ struct DevBuf {
 struct ScaleArgs { float v[PLX_MAX_DIM]; };              // h:372-390 scale factors
 struct TapArgs { float c[2 * PLX_MAX_ORDER + 1]; };      // blur weights, h:546
 
+// Kernel-variant switches (plx_tune).  The process-wide defaults live in g_tune_defaults; every lattice takes a snapshot
+// when a build starts (plx_build / plx_build_local / plx_filter) and every entry point serves its lattice under that
+// snapshot (tl_tune), so a plx_tune call never changes what a built lattice does -- it takes effect at the next build.
+struct Tune {
+    int sort_points = 1;   // 0 keeps the caller's point order (A/B only)
+    int readback_spin = 1;   // read_back: 1 = spin on the mailbox word, 0 = wait for the stream
+    int order_compact = 1;   // 1: point-order keys over exactly the bits every coordinate's range needs; 0: a fixed 7 / 8 bits per coordinate
+    int order_zcurve = 1;   // 1: points along the Z-curve of their rounded lattice coordinates; 0: lexicographically; 2: Z-curve of the blur-axis coordinates
+    int nbr_symmetric = 1;   // neighbour build looks up the positive taps only and mirrors the hits (fine regime 7.2 -> 4.9 ms)
+    int insert_dedupe = 2;   // hashed insert: 2 = every key of a wave probes once, 1 = runs of equal neighbouring lanes probe once, 0 = every lane probes
+    int compact_nbr = 1;   // 0 never, 1 when under a quarter of the neighbour slots exist, 2 always
+    int insert_plane_fast = 1;   // the d+1 corner planes of a run of points are adjacent workgroups of the hashed insert / neighbour lookups
+    int vertex_order = 1;   // 0: first touch; 1: Morton order where it pays; 2: always
+    int blur_vpt = 4;   // vertices per thread in the vd = 1 blur (2 or 4)
+    int blur_small = 1;   // all blur passes in one workgroup when m <= 16384 (vd = 1)
+    int xcd_remap = 1;   // workgroup b works on tile (b % 8) * ceil(nb/8) + b / 8: every XCD owns one contiguous slice of the lattice
+    int splat_direct = 1;   // vd = 1 CSR splat gathers from d_src through caller-row indices: 0 never, 1 for <= 2e6 corners, 2 always
+    int blur_narrow = 1;   // vd 2..16 blur: row length compiled in, branch-free
+    int blur_multi = 1;   // vd > 1 blur: 4 items per thread on rows of >= 32 chunks
+    int splat_group = 1;   // vd 2..64: lane-group streaming splat
+    int splat_wide = 1;   // row-parallel splat for rows of 32..128 chunks
+    int blur_fuse = 1;   // two blur axes per launch (vd = 1): 0 never, 1 on cache-resident lattices, 2 always
+    int blur_fuse_vec = 1;   // two blur axes per launch for rows of 2..4 chunks
+    int block_path = 1;   // 0 never, 1 when the lattice qualifies (see build_blocks), 2 whenever representable
+    int scatter_store = 0;   // slice's row-scattered output stores: 0 plain, 1 non-temporal, 2 agent-scope
+    int unpermute_gather = 1;   // caller row order out of slice: 1 = lattice-ordered scratch + a gather pass, 0 = scatter from the slice kernel
+    int block_e = 0;   // corners per thread of the block kernels: 0 = per lattice (choose_block_e), 16 or 24
+    int block_dense_combine = 1;   // combine numbers the vertices by counting row ends when every vertex has block rows
+    // diagnostic ablations: the members always exist (one layout for both libraries), but only libplx_diag.so knows
+    // their names and compiles the branches behind them (PLX_DIAG_VALUE)
+    int splat_ablate = 0;   // libplx_diag.so only: 1 no value gather, 2 no stores, 4 no row-id loads
+    int blur_ablate = 0;   // libplx_diag.so only: 1 no neighbour gathers, 2 no neighbour-id loads either
+    int block_ablate = 0;   // libplx_diag.so only: 1 combine without the partial gathers, 2 without idx loads too, 4 without stores
+};
+extern Tune g_tune_defaults;
+extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this thread is serving (the defaults outside any entry point)
+
 }  // namespace plx
+
+// the names the kernel files use for the switches
+#define g_sort_points (plx::tl_tune->sort_points)
+#define g_readback_spin (plx::tl_tune->readback_spin)
+#define g_order_compact (plx::tl_tune->order_compact)
+#define g_order_zcurve (plx::tl_tune->order_zcurve)
+#define g_nbr_symmetric (plx::tl_tune->nbr_symmetric)
+#define g_insert_dedupe (plx::tl_tune->insert_dedupe)
+#define g_compact_nbr (plx::tl_tune->compact_nbr)
+#define g_insert_plane_fast (plx::tl_tune->insert_plane_fast)
+#define g_vertex_order (plx::tl_tune->vertex_order)
+#define g_blur_vpt (plx::tl_tune->blur_vpt)
+#define g_blur_small (plx::tl_tune->blur_small)
+#define g_xcd_remap (plx::tl_tune->xcd_remap)
+#define g_splat_direct (plx::tl_tune->splat_direct)
+#define g_blur_narrow (plx::tl_tune->blur_narrow)
+#define g_blur_multi (plx::tl_tune->blur_multi)
+#define g_splat_group (plx::tl_tune->splat_group)
+#define g_splat_wide (plx::tl_tune->splat_wide)
+#define g_blur_fuse (plx::tl_tune->blur_fuse)
+#define g_blur_fuse_vec (plx::tl_tune->blur_fuse_vec)
+#define g_block_path (plx::tl_tune->block_path)
+#define g_scatter_store (plx::tl_tune->scatter_store)
+#define g_unpermute_gather (plx::tl_tune->unpermute_gather)
+#define g_block_e (plx::tl_tune->block_e)
+#define g_block_dense_combine (plx::tl_tune->block_dense_combine)
+#define g_splat_ablate (plx::tl_tune->splat_ablate)
+#define g_blur_ablate (plx::tl_tune->blur_ablate)
+#define g_block_ablate (plx::tl_tune->block_ablate)
 
 struct plx_lattice {
     int device = 0;
+    plx::Tune tn;                // the switches this lattice was built under (snapshot of the process defaults)
     bool built = false;
     bool timing = false;
     bool partial_cover = false;  // built by plx_build_merge: this rank's points do not touch every vertex
@@ -229,9 +296,9 @@ inline void tmark(plx_lattice *L, hipStream_t stream)
         (void)hipEventRecord(L->tev[L->tev_n++], stream);
 }
 
-// kernel-variant switches for in-process A/B runs (plx_tune); defaults are the shipped choice
-struct Tunable { const char *name; int *value; };
-Tunable *tunables();
+// name -> member of Tune (plx_tune)
+struct Tunable { const char *name; int Tune::*member; };
+const Tunable *tunables();
 
 // value-row stride in floats: 1 for a single column, else the column count rounded up to 4 so
 // that every row is a whole number of 16-byte vectors

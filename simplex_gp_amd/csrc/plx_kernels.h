@@ -30,38 +30,11 @@ namespace plx {
 // compiled out.
 #ifdef PLX_DIAG
 #define PLX_DIAG_VALUE(x) (x)
-extern int g_splat_ablate;
-extern int g_blur_ablate;
-extern int g_block_ablate;
 #else
 #define PLX_DIAG_VALUE(x) 0
 #endif
 
 // kernel-variant switches (plx_tune); defined in plx_tune.hip and plx_build.hip
-extern int g_blur_vpt;
-extern int g_blur_small;
-extern int g_xcd_remap;
-extern int g_splat_direct;
-extern int g_blur_narrow;
-extern int g_blur_multi;
-extern int g_splat_group;
-extern int g_splat_wide;
-extern int g_sort_points;
-extern int g_order_zcurve;
-extern int g_order_compact;
-extern int g_readback_spin;
-extern int g_vertex_order;
-extern int g_insert_plane_fast;
-extern int g_compact_nbr;
-extern int g_insert_dedupe;
-extern int g_nbr_symmetric;
-extern int g_block_path;
-extern int g_block_e;
-extern int g_block_dense_combine;
-extern int g_blur_fuse;
-extern int g_blur_fuse_vec;
-extern int g_scatter_store;
-extern int g_unpermute_gather;
 
 // Tile index for workgroup blockIdx.x.  With remap the launch has 8 * ceil(ntiles / 8) workgroups and
 // workgroup b takes tile (b % 8) * per + b / 8: workgroups are dealt to the 8 XCDs round-robin

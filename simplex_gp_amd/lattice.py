@@ -222,6 +222,12 @@ class Lattice:
         nv.check(rc, "plx_prepare")
         return self
 
+    def tune(self, key, value):
+        """Switch a kernel variant for THIS lattice only, from its next call until its next build (plx_lattice_tune;
+        the process defaults -- plx_tune -- are what every build starts from)."""
+        nv.check(nv.lib().plx_lattice_tune(self._h, key.encode(), int(value)), "plx_lattice_tune")
+        return self
+
     @property
     def block_rows(self):
         """Rows of the block tables (0: not built yet -- see prepare() -- or the lattice uses the vertex-sorted CSR path)."""

@@ -487,9 +487,12 @@ def test_block_tables_equal_csr_path(plx, block_e):
             assert torch.equal(b.slice(blurred, vd=1), a.slice(blurred, vd=1))        # same arithmetic, same order
             assert torch.equal(b.apply(s), out_b)                                       # reproducible bits
             # the combine kernel that numbers vertices by counting row ends against the one that reads their ids
-            nv.check(lib.plx_tune(b"block_dense_combine", 0), "plx_tune")
+            b.tune("block_dense_combine", 0)
             assert torch.equal(b.splat(s), vb)
-            nv.check(lib.plx_tune(b"block_dense_combine", 1), "plx_tune")
+            b.tune("block_dense_combine", 1)
+            # the switches are per lattice: `a` was built under block_path = 0 and stays on the CSR path although the
+            # process default has been 2 since
+            assert torch.equal(a.apply(s), out_a) and a.block_rows == 0 and "block" not in a.stage_kernels()["splat"][0]
             # affine epilogue and lattice row order
             ss = torch.tensor([0.7, 0.3], device="cuda")
             assert rel_l2(b.apply_affine(s, ss).cpu().numpy(), (0.7 * out_b + 0.3 * s).cpu().numpy()) <= 1e-6
@@ -522,7 +525,6 @@ def test_block_tables_equal_csr_path(plx, block_e):
     finally:
         nv.check(lib.plx_tune(b"block_path", 1), "plx_tune")
         nv.check(lib.plx_tune(b"block_e", 0), "plx_tune")
-        nv.check(lib.plx_tune(b"block_dense_combine", 1), "plx_tune")
 
 
 def test_blur_axis_pairs_equal_single_axis_passes(plx):

@@ -181,6 +181,11 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.plx_create(0, None) == 1
     assert lib.plx_num_vertices(None) == -1
     assert lib.plx_tune(b"no_such_key", 1) == 1 and b"no_such_key" in lib.plx_last_error()
+    assert lib.plx_lattice_tune(None, b"xcd_remap", 1) == 1
+    # the diagnostic ablations are not part of the shipped library (libplx_diag.so only)
+    if not os.environ.get("PLX_LIBRARY"):
+        for key in (b"splat_ablate", b"blur_ablate", b"block_ablate"):
+            assert lib.plx_tune(key, 1) == 1, key
 
 
 def test_gp_compat_fallback_is_explicit():

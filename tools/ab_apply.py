@@ -17,8 +17,12 @@ from simplex_gp_amd import _native as nv  # noqa: E402
 RBF1 = np.array([0.34608543, 1.0, 0.34608543], np.float32)
 
 
-def tune(key, val):
+def tune(key, val, lat=None):
+    """Set the process default of a switch (what the next build starts from) and, with `lat`, the copy of that built
+    lattice as well (its MVMs from the next call on)."""
     nv.check(nv.lib().plx_tune(key.encode(), val), "plx_tune")
+    if lat is not None:
+        lat.tune(key, val)
 
 
 def timeit(fn, iters=20):

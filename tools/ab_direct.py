@@ -11,7 +11,7 @@ for (n, d, ell) in [(100000, 4, 1.0), (1000000, 8, 1.0), (1000000, 8, 0.6931), (
     out = torch.empty_like(v); vals = lat.new_values(1)
     for rep in range(2):
         for val in (0, 1):
-            tune("splat_direct", val)
+            tune("splat_direct", val, lat)
             ts = min(timeit(lambda: lat.splat(v, vals)) for _ in range(3))
             ta = min(timeit(lambda: lat.apply(v, out)) for _ in range(3))
             if val == 0: base = out.clone()

@@ -15,12 +15,12 @@ for ell in (1.0, 0.6931):
         vals = lat.new_values(vd)
         base = None
         for mode in (0, 1):
-            tune("splat_group", mode)
+            tune("splat_group", mode, lat)
             ts = min(timeit(lambda: lat.splat(v, vals), iters=5) for _ in range(3))
             res = lat.splat(v, vals).clone()
             base = res if base is None else base
             err = ((res - base).norm() / base.norm()).item()
             print(f"ell={ell} m={lat.m} vd={vd:3d} splat_group={mode}: splat {ts:8.1f} us   rel diff vs scan {err:.1e}", flush=True)
-        tune("splat_group", 1)
+        tune("splat_group", 1, lat)
         del v, vals
     lat.close()

@@ -14,7 +14,7 @@ for vd in (64, 198, 418):
         vals = lat.new_values(vd)
         base = None
         for mode in (0, 1, 0, 1):
-            tune("splat_wide", mode)
+            tune("splat_wide", mode, lat)
             ts = min(timeit(lambda: lat.splat(v, vals), iters=5) for _ in range(2))
             res = lat.splat(v, vals).clone(); base = res if base is None else base
             err = ((res - base).norm() / base.norm()).item()

@@ -13,7 +13,7 @@ for ell in (1.0, 0.6931):
     vals, scratch, out = lat.new_values(vd), lat.new_values(vd), torch.empty_like(v)
     base = None
     for rm in (0, 1, 0, 1):
-        tune("xcd_remap", rm)
+        tune("xcd_remap", rm, lat)
         lat.splat(v, vals)
         ts = min(timeit(lambda: lat.splat(v, vals)) for _ in range(3))
         tb = min(timeit(lambda: lat.blur(vals, scratch, vd=vd)) for _ in range(3))

@@ -16,9 +16,9 @@ for ell in (1.0, 0.6931, 0.25):
     vals, scratch = lat.new_values(vd), lat.new_values(vd)
     lat.splat(v, vals)
     for ab in ((0, 1, 3) if vd == 1 else (0, 1)):
-        tune("blur_ablate", ab)
+        tune("blur_ablate", ab, lat)
         ts = [timeit(lambda: lat.blur(vals, scratch, vd=vd)) for _ in range(3)]
         print(f"vd={vd} ell={ell} m={lat.m} blur_ablate={ab} (1=no gathers, 3=no gathers + no id loads): {min(ts):.2f} us per 9 launches = {min(ts)/9:.2f} us each", flush=True)
-    tune("blur_ablate", 0)
+    tune("blur_ablate", 0, lat)
     lat.close()
 tune("compact_nbr", 1)

@@ -17,7 +17,7 @@ for ell in (1.0, 0.6931, 0.25):
         vals.normal_()
         ref = None
         for multi in (0, 1):
-            tune("blur_narrow", multi)
+            tune("blur_narrow", multi, lat)
             vals.normal_()
             t = min(timeit(lambda: lat.blur(vals, scr, vd=vd), iters=5) for _ in range(3))
             res = lat.blur(vals, scr, vd=vd).clone()
@@ -25,5 +25,5 @@ for ell in (1.0, 0.6931, 0.25):
             gb = lat.m * lat.values_stride(vd) * 4 * 2 * 9 / 1e3
             print(f"ell={ell} m={lat.m} vd={vd} narrow={multi}: blur {t:8.1f} us  ({t/9:6.1f}/pass)  stream {gb/t/1e3:.2f} TB/s  "
                   f"max diff vs single {float((res - ref).abs().max()):.1e}", flush=True)
-        tune("blur_narrow", 1)
+        tune("blur_narrow", 1, lat)
     lat.close()

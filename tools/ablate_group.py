@@ -14,8 +14,8 @@ for ell in (1.0, 0.6931):
         v = torch.randn(n, vd, generator=g).cuda()
         vals = lat.new_values(vd)
         for ab in (0, 1, 2, 3):
-            tune("splat_ablate", ab)
+            tune("splat_ablate", ab, lat)
             ts = min(timeit(lambda: lat.splat(v, vals), iters=5) for _ in range(3))
             print(f"ell={ell} vd={vd} ablate={ab} (1: no gathers, 2: no stores): splat {ts:8.1f} us", flush=True)
-        tune("splat_ablate", 0)
+        tune("splat_ablate", 0, lat)
     lat.close()

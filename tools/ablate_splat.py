@@ -12,8 +12,8 @@ for ell in (1.0, 0.25):
     lat = plx.Lattice().build((x / ell).contiguous().cuda(), RBF1)
     vals = lat.new_values(1)
     for ab in (0, 1, 2, 4, 3, 6, 7):
-        tune("splat_ablate", ab)
+        tune("splat_ablate", ab, lat)
         ts = [timeit(lambda: lat.splat(v, vals)) for _ in range(3)]
         print(f"ell={ell} ablate={ab} (1=no gather 2=no stores 4=no rowid): {min(ts):.2f} us", flush=True)
-    tune("splat_ablate", 0)
+    tune("splat_ablate", 0, lat)
     lat.close()
