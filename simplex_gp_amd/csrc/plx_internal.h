@@ -259,14 +259,6 @@ int radix_sort_pairs64(void *temp, uint64_t *keys_a, uint64_t *keys_b, uint32_t 
 int radix_sort_pairs32(void *temp, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
                        int *in_second, hipStream_t stream);
 int selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, hipStream_t stream, int64_t *mismatches);
-// (rocPRIM radix sort of (vertex id, entry index) pairs: kept for the 64-bit sorts above 3e6 items)
-int sort_pairs_temp_bytes(int64_t n, int end_bit, size_t *bytes);
-int sort_pairs(void *temp, size_t temp_bytes, const uint32_t *keys_in, uint32_t *keys_out,
-               const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit,
-               hipStream_t stream);
-int sort_pairs64_temp_bytes(int64_t n, int end_bit, size_t *bytes);
-int sort_pairs64(void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
-                 const uint32_t *vals_in, uint32_t *vals_out, int64_t n, int end_bit, hipStream_t stream);
 // block tables built in LDS, one workgroup per block (256-thread blocks): sort by vertex + every per-corner record;
 // the block's vertex list lands in rows_tmp[b * cpb + row] and is compacted once the row offsets are scanned
 int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin, int n_own, int P, int d1, int cpb, int vbits,
