@@ -334,6 +334,57 @@ def test_side_stream_and_buffer_reuse_soak(plx):
     lat.close()
 
 
+def test_buffers_survive_the_stream_they_grew_on(plx):
+    """Device buffers grow stream-ordered on the stream of the call that needs them.  A lattice built on a stream its
+    owner then DESTROYS must still rebuild (bigger: every buffer is re-allocated) and serve MVMs on another stream, and
+    a lattice may change streams between calls as long as the caller orders them."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    raw = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(raw)) == 0
+    rng = np.random.default_rng(23)
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    lat = plx.Lattice()
+
+    def case(n, d, vd, stream):
+        ref = rng.standard_normal((n, d)).astype(np.float32)
+        src = rng.standard_normal((n, vd)).astype(np.float32)
+        ref_t, src_t = torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            lat.build(ref_t, taps)
+            out = lat.apply(src_t)
+        stream.synchronize()
+        oracle.set_exact_mode(False)
+        want = oracle.filter(src, ref, taps)
+        oracle.set_exact_mode(True)
+        assert rel_l2(out.cpu().numpy(), want) <= 5e-5, (n, d, vd)
+        return ref_t, src_t, out
+
+    ext = torch.cuda.ExternalStream(raw.value)
+    case(3000, 3, 1, ext)
+    case(2000, 5, 4, ext)
+    del ext
+    assert hip.hipStreamDestroy(raw) == 0                      # the owner of every buffer of `lat` is gone
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    ref_t, src_t, out_a = case(40000, 6, 1, a)                 # everything grows: the old owner cannot be waited for
+    # same lattice, another stream, ordered by the caller; a wider right-hand side grows the workspace on stream b
+    wide = torch.from_numpy(rng.standard_normal((40000, 7)).astype(np.float32)).cuda()
+    torch.cuda.synchronize()
+    b.wait_stream(a)
+    with torch.cuda.stream(b):
+        out_b = lat.apply(src_t)
+        out_w = lat.apply(wide)
+    b.synchronize()
+    assert torch.equal(out_a, out_b)
+    with torch.cuda.stream(a):
+        a.wait_stream(b)
+        first = lat.apply(wide[:, :1].contiguous())
+    a.synchronize()
+    assert rel_l2(first.cpu().numpy(), out_w[:, :1].cpu().numpy()) <= 1e-5      # (one-column and row kernels: two summation orders)
+    lat.close()
+
+
 def test_fused_cg_updates_match_torch(plx):
     from simplex_gp_amd import solvers
     g = torch.Generator().manual_seed(6)
