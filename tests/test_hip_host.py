@@ -385,6 +385,48 @@ def test_buffers_survive_the_stream_they_grew_on(plx):
     lat.close()
 
 
+def test_two_host_threads_two_lattices(plx):
+    """The library keeps no mutable process state besides the plx_tune defaults: two host threads, each with its own
+    lattice and stream, rebuild and apply concurrently (ctypes releases the GIL inside the calls) and reproduce, bit
+    for bit, what each computes alone."""
+    import threading
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    jobs = []
+    for seed, (n, d, vd) in enumerate([(60000, 4, 1), (30000, 8, 3)]):
+        rng = np.random.default_rng(100 + seed)
+        refs = [torch.from_numpy((rng.standard_normal((n + 1000 * k, d)) / (1.0 + 0.5 * k)).astype(np.float32)).cuda() for k in range(3)]
+        srcs = [torch.from_numpy(rng.standard_normal((r.shape[0], vd)).astype(np.float32)).cuda() for r in refs]
+        jobs.append((refs, srcs))
+    torch.cuda.synchronize()
+
+    def run(job, rounds, out):
+        refs, srcs = job
+        lat, stream = plx.Lattice(), torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            for it in range(rounds):
+                k = it % len(refs)
+                lat.build(refs[k], taps)
+                res = lat.apply(srcs[k])
+                res = lat.apply(srcs[k])
+                out.append(res.clone())
+        stream.synchronize()
+        lat.close()
+
+    alone = [[], []]
+    for j in range(2):
+        run(jobs[j], 3, alone[j])
+    together = [[], []]
+    threads = [threading.Thread(target=run, args=(jobs[j], 12, together[j])) for j in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for j in range(2):
+        assert len(together[j]) == 12
+        for it, res in enumerate(together[j]):
+            assert torch.equal(res, alone[j][it % 3]), (j, it)
+
+
 def test_fused_cg_updates_match_torch(plx):
     from simplex_gp_amd import solvers
     g = torch.Generator().manual_seed(6)
