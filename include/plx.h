@@ -18,14 +18,18 @@
  *   - every data pointer is DEVICE memory (fp32, row-major, contiguous) on the
  *     lattice's device unless the name starts with h_ (host);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
- *     work is enqueued on it.  plx_build() synchronises that stream (once to learn
- *     the vertex count m that sizes the lattice, once more for the neighbour count); plx_splat / plx_blur /
- *     plx_slice / plx_apply never synchronise and never allocate once their
- *     workspace has reached its high-water mark, so they are graph-capturable;
+ *     work is enqueued on it.  A build waits on the host for a few small counts (coordinate ranges, the vertex
+ *     count m that sizes the lattice, ...): each arrives through a pinned mailbox the host spins on, the stream
+ *     itself is not synchronised.  plx_splat / plx_blur / plx_slice / plx_apply never synchronise and never
+ *     allocate once the lattice's tables exist (plx_prepare, or the first MVM of that width) and their workspace
+ *     has reached its high-water mark, so they are graph-capturable from then on.  Buffers grow stream-ordered
+ *     (hipMallocAsync) on the stream of the call that needs them; a lattice may move between streams as long as
+ *     the caller orders the calls;
  *   - every function returns PLX_OK (0) or an error code; nothing calls exit()
  *     (reference: cuda/permutohedral_cuda_kernel.cu:24-32 does).
  *     plx_last_error() returns a thread-local detail string;
- *   - a plx_lattice is not safe for concurrent use from two threads.
+ *   - a plx_lattice is not safe for concurrent use from two threads; different lattices may be used from
+ *     different threads at the same time (the library keeps no other mutable state than the plx_tune defaults).
  */
 #ifndef PLX_H
 #define PLX_H
