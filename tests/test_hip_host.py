@@ -385,6 +385,41 @@ def test_buffers_survive_the_stream_they_grew_on(plx):
     lat.close()
 
 
+def test_mvm_is_graph_capturable(plx):
+    """Once a lattice's tables exist and its workspace has been sized, an MVM neither synchronises nor allocates inside
+    the library: it can be captured into a HIP graph (torch.cuda.CUDAGraph) and replayed on new right-hand sides."""
+    rng = np.random.default_rng(31)
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    n, d = 50000, 5
+    x = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda()
+    lat = plx.Lattice().build(x, taps)
+    for vd in (1, 4):
+        v = torch.from_numpy(rng.standard_normal((n, vd)).astype(np.float32)).cuda()
+        v2 = torch.from_numpy(rng.standard_normal((n, vd)).astype(np.float32)).cuda()
+        out = torch.empty_like(v)
+        lat.prepare(vd)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                lat.apply(v, out)                      # tables, workspace high-water mark
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            lat.apply(v, out)
+        want1, want2 = lat.apply(v).clone(), lat.apply(v2).clone()
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want1), vd
+        v.copy_(v2)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want2), vd
+    lat.close()
+
+
 def test_two_host_threads_two_lattices(plx):
     """The library keeps no mutable process state besides the plx_tune defaults: two host threads, each with its own
     lattice and stream, rebuild and apply concurrently (ctypes releases the GIL inside the calls) and reproduce, bit
