@@ -241,6 +241,65 @@ int plx_cg_update(float *d_x, float *d_r, const float *d_p, const float *d_ap, c
                   int64_t n, int vd, float *d_rs_new, float *d_work, void *stream);
 int plx_cg_direction(float *d_p, const float *d_r, const float *d_beta, int64_t n, int vd, void *stream);
 
+/*
+ * Preconditioned batched CG: the reference trains with gpytorch.settings.max_preconditioner_size(100)
+ * (experiments/train_simplexgp.py:36, configs/simplexgp.yml), i.e. every solve of (s K + sigma^2 I) is preconditioned by
+ * P = L L^T + sigma^2 I, L [n][k] the rank-k pivoted Cholesky factor of s K (GPyTorch builds and applies it with torch
+ * ops).  These entry points are that work as native passes.  The factor is handed over TRANSPOSED:
+ *   d_lt   float [kp][ld] row-major = L^T; kp = k rounded up to a multiple of 16 (the extra rows zero), ld = n rounded up
+ *          to a multiple of 64 (the tail of every row zero), 16-byte aligned; the n dimension in the same row order as
+ *          the CG vectors (solvers.py keeps everything in lattice row order, so nothing is permuted per iteration);
+ *   t      columns of the CG vectors, 1..16, row-major [n][t];
+ *   d_work plx_pcg_work_floats(n, kp, t) floats of scratch.
+ * One application Z = P^-1 R = (R - L C^-1 L^T R) / sigma^2, C = sigma^2 I + L^T L, is two streaming passes over L^T:
+ *   plx_pcg_project   T [kp][16] = C^-1 (L^T R): the products on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32
+ *                     products, fp32 accumulation), per-workgroup partial sums added in fp64 in a fixed order, then the
+ *                     kp x kp solve with d_cinv = C^-1 in fp64 [kp][kp] (symmetric; identity / sigma^2 on the padding);
+ *   plx_pcg_apply     Z = (d_scale[0] R - L T) d_scale[1] (k = columns of L actually used) and, unless NULL,
+ *                     d_rz[c] = <R[:, c], Z[:, c]> from the same registers.  d_scale: two floats in device memory.
+ *   plx_pcg_step_direction   beta = active ? rz_new / rz : 0; P = Z + beta P; active_out = active and
+ *                     sqrt(rr) / b_norm > tol (rr = |R|^2 as plx_cg_step_update returns it: the TRUE residual).
+ * plx_cg_step_update is used unchanged with rs := rz.  Deterministic (no atomics).
+ * factor_type: the factor's storage, PLX_FACTOR_F32 or PLX_FACTOR_F16 (IEEE half, same [kp][ld] layout; made from the fp32
+ * factor by plx_pcg_factor_to_half).  Both passes are bound by streaming the factor, so the half-width copy halves them.
+ * A preconditioner only has to be symmetric positive definite and the same matrix wherever it is used: a caller that
+ * stores L in fp16 must form C = sigma^2 I + L^T L, the log-determinant and its probe vectors from that SAME rounded L
+ * (solvers.LatticePreconditioner does); products and accumulation are fp32 either way.
+ */
+enum { PLX_FACTOR_F32 = 0, PLX_FACTOR_F16 = 1 };
+int64_t plx_pcg_work_floats(int64_t n, int kp, int t);
+int plx_pcg_project(const void *d_lt, int factor_type, int64_t ld, int kp, const float *d_r, int64_t n, int t,
+                    const double *d_cinv, float *d_t, float *d_work, void *stream);
+int plx_pcg_apply(const void *d_lt, int factor_type, int64_t ld, int kp, int k, const float *d_r, int64_t n, int t,
+                  const float *d_t, const float *d_scale, float *d_z, float *d_rz, float *d_work, void *stream);
+int plx_pcg_factor_to_half(const float *d_lt, int64_t ld, int kp, void *d_lt_half, void *stream);
+int plx_pcg_step_direction(float *d_p, const float *d_z, const float *d_rz_new, const float *d_rz, const float *d_rr,
+                           const float *d_active, const float *d_b_norm, float tol, int64_t n, int vd, float *d_beta,
+                           float *d_active_out, void *stream);
+/*
+ * The factor itself, built in batches of speculated pivots.  The sequential algorithm (GPyTorch's pivoted_cholesky, one
+ * kernel row = one single-column MVM per pivot) is reproduced exactly, but nb <= 16 pivots share ONE nb-column MVM:
+ *   plx_pchol_select        d_cand[0..nb) = the nb largest entries of the residual diagonal d_diag [n], ties by LOWER
+ *                           d_rank[i] (NULL: by lower i) -- pass the lattice's point permutation so that ties fall as
+ *                           torch.argmax breaks them on the caller-order vector; seeds the batch state in d_work;
+ *   plx_pchol_onehot        d_rhs [n][t] = the nb one-hot columns (t >= nb; the caller runs the MVM on it);
+ *   plx_pchol_factor_batch  d_rows [n][t] = K d_rhs.  Panel update against the m_done finished columns
+ *                           (d_scale[0] d_rows - L L[cand]^T, one pass over them), then the nb in-batch steps in pivot
+ *                           order: column m_done + b = row b / sqrt(pivot) (zero if the pivot is <= tol_abs), residual
+ *                           diagonal updated, and the argmax of the updated diagonal compared ON THE DEVICE with the
+ *                           next speculated pivot -- the first mismatch ends the batch.  *d_accepted (device int32) =
+ *                           columns written (>= 1: the first candidate is the argmax by construction); the caller reads
+ *                           it back once per batch and carries on from m_done + accepted.
+ * d_work: plx_pchol_work_bytes(ld, kp) bytes, the same buffer for the three calls of a batch.
+ */
+int64_t plx_pchol_work_bytes(int64_t ld, int kp);
+int plx_pchol_select(const float *d_diag, const uint32_t *d_rank, int64_t n, int nb, int64_t ld, int kp, int32_t *d_cand,
+                     void *d_work, void *stream);
+int plx_pchol_onehot(const int32_t *d_cand, int nb, int64_t n, int t, float *d_rhs, void *stream);
+int plx_pchol_factor_batch(float *d_lt, int64_t ld, int kp, int m_done, const float *d_rows, int t, const float *d_scale,
+                           const int32_t *d_cand, int nb, float *d_diag, const uint32_t *d_rank, int64_t n, float tol_abs,
+                           int32_t *d_accepted, void *d_work, void *stream);
+
 /* Copy one structure array to host memory (parity tests, debugging).
  * h_dst must hold `bytes` bytes, which must equal the array's size. */
 int plx_export(plx_lattice *lat, int which, void *h_dst, int64_t bytes, void *stream);

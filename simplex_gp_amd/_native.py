@@ -17,6 +17,7 @@ PLX_OK = 0
 ARRAY_KEYS, ARRAY_ENTRY_VERTEX, ARRAY_ENTRY_WEIGHT, ARRAY_NEIGHBORS = 0, 1, 2, 3
 ARRAY_ROW_PTR, ARRAY_CSR_POINT, ARRAY_CSR_WEIGHT, ARRAY_POINT_PERM = 4, 5, 6, 7
 MAX_DIM, MAX_ORDER = 32, 8
+FACTOR_F32, FACTOR_F16 = 0, 1
 
 
 class PlxError(RuntimeError):
@@ -65,6 +66,16 @@ _SIGNATURES = {
     "plx_cg_step_direction": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_direction": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "plx_pcg_work_floats": (_i64, [_i64, _i32, _i32]),
+    "plx_pcg_project": (_i32, [_vp, _i32, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "plx_pcg_apply": (_i32, [_vp, _i32, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "plx_pcg_factor_to_half": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "plx_pcg_step_direction": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp]),
+    "plx_pchol_work_bytes": (_i64, [_i64, _i32]),
+    "plx_pchol_select": (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "plx_pchol_onehot": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
+    "plx_pchol_factor_batch": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i64, ctypes.c_float,
+                                      _vp, _vp, _vp]),
     "plx_export": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "plx_export_bytes": (_i64, [_vp, _i32]),
     "plx_copy_point_perm": (_i32, [_vp, _vp, _vp]),

@@ -71,6 +71,8 @@ struct Tune {
     int unpermute_gather = 1;   // caller row order out of slice: 1 = lattice-ordered scratch + a gather pass, 0 = scatter from the slice kernel
     int block_e = 0;   // corners per thread of the block kernels: 0 = per lattice (choose_block_e), 16 or 24
     int block_dense_combine = 1;   // combine numbers the vertices by counting row ends when every vertex has block rows
+    int nbr_bitmap = 1;   // neighbour lookups test a slot-occupancy bitmap before they touch the hash table: 0 never, 1 when m >= 2^20, 2 always
+    int splat_first = 1;   // vd = 1 splat on lattices where almost every corner owns its vertex: first-touch corners store, the rest add (0 never, 1 when it qualifies)
     // diagnostic ablations: the members always exist (one layout for both libraries), but only libplx_diag.so knows
     // their names and compiles the branches behind them (PLX_DIAG_VALUE)
     int splat_ablate = 0;   // libplx_diag.so only: 1 no value gather, 2 no stores, 4 no row-id loads
@@ -107,6 +109,8 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_unpermute_gather (plx::tl_tune->unpermute_gather)
 #define g_block_e (plx::tl_tune->block_e)
 #define g_block_dense_combine (plx::tl_tune->block_dense_combine)
+#define g_nbr_bitmap (plx::tl_tune->nbr_bitmap)
+#define g_splat_first (plx::tl_tune->splat_first)
 #define g_splat_ablate (plx::tl_tune->splat_ablate)
 #define g_blur_ablate (plx::tl_tune->blur_ablate)
 #define g_block_ablate (plx::tl_tune->block_ablate)
@@ -152,7 +156,7 @@ struct plx_lattice {
     plx::DevBuf merge_slot, merge_flags;   // uint32 [sum of all ranks' local vertex counts] (sharded build)
     plx::DevBuf counters;   // int32  [8]            {m, error flag, ...}
     plx::DevBuf sort_keys_in, sort_vals_in, sort_vals_out, sort_temp;
-    plx::DevBuf sort_keys_out;   // build scratch (block tables: global-sort path)
+    plx::DevBuf slotmap;    // uint32 [capacity / 32] one bit per hash slot: occupied (neighbour lookups of large lattices)
 
     // structure
     plx::DevBuf vkeys;      // uint32 [m][DW]        packed vertex keys, in vertex id order

@@ -165,6 +165,231 @@ class PivotedCholeskyPreconditioner:
         return self.Lt.t() @ g1 + math.sqrt(self.noise) * g2
 
 
+def _vp(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class LatticePreconditioner:
+    """The same preconditioner, P = L L^T + sigma^2 I with L the rank-k pivoted Cholesky factor of s K, on the HIP path
+    (experiments/train_simplexgp.py:36: the reference trains with max_preconditioner_size(100)).
+
+    What differs from PivotedCholeskyPreconditioner (kept as the CPU / reference form) is where the work runs:
+      * everything lives in LATTICE row order (L^T is [kp][ld], its n dimension ordered like the lattice's points), so a
+        preconditioned CG iteration permutes nothing;
+      * the factor is built in batches of speculated pivots (plx_pchol_*): up to `batch` kernel rows per MVM instead of
+        one, each in-batch step checked on the device against the true argmax of the updated residual diagonal -- the
+        factor is the sequential algorithm's, pivot for pivot (ties broken by the caller's row number, like torch.argmax
+        on the caller-order diagonal), at one host read-back per batch;
+      * solve() = plx_pcg_project (L^T R on the matrix cores, C^-1 in fp64) + plx_pcg_apply;
+      * the finished factor is kept in fp16 (factor_dtype; fp32 on request): both passes of an application stream the
+        factor and nothing else of size, so its width is their time.  The factor is BUILT in fp32 and rounded once;
+        C, the log-determinant, solve() and sample() all use the rounded factor, i.e. P is exactly
+        L~ L~^T + sigma^2 I for the stored L~ -- a preconditioner has to be SPD and the same matrix everywhere it
+        appears in the estimator, nothing more.
+    """
+
+    def __init__(self, lat, outputscale, noise, rank, rel_tol=1e-6, batch=12, factor_dtype=torch.float16):
+        import ctypes
+        from . import _native as nv
+        lib = nv.lib()
+        s, noise = float(outputscale), float(noise)
+        dev = lat.device
+        n = lat.n_owned
+        if lat.n != n:
+            raise ValueError("LatticePreconditioner needs a single-shard lattice")
+        k = int(min(rank, n))
+        kp = max(16, (k + 15) // 16 * 16)
+        ld = (n + 63) // 64 * 64
+        self.lat, self.n, self.rank, self.kp, self.ld, self.noise, self.outputscale = lat, n, k, kp, ld, noise, s
+        self.Lt = torch.zeros(kp, ld, dtype=torch.float32, device=dev)
+        diag = torch.full((n,), s, dtype=torch.float32, device=dev)
+        row_rank = torch.empty(lat.n, dtype=torch.int32, device=dev)          # caller row of every lattice position (uint32 bits)
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            nv.check(lib.plx_copy_point_perm(lat._h, _vp(row_rank), stream), "plx_copy_point_perm")
+            work = torch.empty(int(lib.plx_pchol_work_bytes(ld, kp)), dtype=torch.uint8, device=dev)
+            cand = torch.empty(16, dtype=torch.int32, device=dev)
+            accepted = torch.zeros(1, dtype=torch.int32, device=dev)
+            scale = torch.tensor([s, 1.0], dtype=torch.float32, device=dev)
+            was_lattice = lat.lattice_rows
+            lat.set_lattice_row_order(True)
+            bufs = {}
+            m, B, self.batches = 0, max(1, min(int(batch), 16)), 0
+            try:
+                while m < k:
+                    nb = min(B, k - m, n)
+                    t = nb if nb == 1 else (nb + 3) // 4 * 4
+                    if t not in bufs:
+                        bufs[t] = (torch.empty(n, t, dtype=torch.float32, device=dev), torch.empty(n, t, dtype=torch.float32, device=dev))
+                    rhs, rows = bufs[t]
+                    nv.check(lib.plx_pchol_select(_vp(diag), _vp(row_rank), n, nb, ld, kp, _vp(cand), _vp(work), stream),
+                             "plx_pchol_select")
+                    nv.check(lib.plx_pchol_onehot(_vp(cand), nb, n, t, _vp(rhs), stream), "plx_pchol_onehot")
+                    lat.apply(rhs, rows)
+                    nv.check(lib.plx_pchol_factor_batch(_vp(self.Lt), ld, kp, m, _vp(rows), t, _vp(scale), _vp(cand), nb, _vp(diag),
+                                                        _vp(row_rank), n, float(rel_tol * s), _vp(accepted), _vp(work), stream),
+                             "plx_pchol_factor_batch")
+                    a = int(accepted.item())                   # the one host read-back of the batch
+                    assert 1 <= a <= nb, (a, nb)
+                    m += a
+                    self.batches += 1
+                    # speculation depth follows what the lattice accepts: dense kernels (few, strongly coupled points)
+                    # end a batch at the first or second pivot, sparse ones take every candidate
+                    B = min(int(batch), 16, 2 * a) if a < nb else min(int(batch), 16, max(B, 2 * a))
+            finally:
+                lat.set_lattice_row_order(was_lattice)
+        from . import _native as nvc
+        self.factor_type = nvc.FACTOR_F32
+        if factor_dtype == torch.float16 and 1e-7 < s < 1e9:          # entries of L are bounded by sqrt(s): inside fp16's range
+            half = torch.empty(kp, ld, dtype=torch.float16, device=dev)
+            with torch.cuda.device(dev):
+                nv.check(lib.plx_pcg_factor_to_half(_vp(self.Lt), ld, kp, _vp(half), stream), "plx_pcg_factor_to_half")
+            self.Lt.copy_(half)                                        # the rounded values, for C below
+            self._factor, self.factor_type = half, nvc.FACTOR_F16
+        else:
+            self._factor = self.Lt
+        # C = sigma^2 I + L^T L in fp64 (64 partial products over the n dimension, summed in fp64)
+        A = self.Lt[:k].reshape(k, 64, ld // 64).permute(1, 0, 2)
+        C = torch.bmm(A, A.transpose(1, 2)).double().sum(0) + noise * torch.eye(k, dtype=torch.float64, device=dev)
+        self._chol = torch.linalg.cholesky(C)
+        cinv = torch.eye(kp, dtype=torch.float64, device=dev) / noise
+        cinv[:k, :k] = torch.cholesky_inverse(self._chol)
+        self._cinv = cinv.contiguous()
+        self._scale_solve = torch.tensor([1.0, 1.0 / noise], dtype=torch.float32, device=dev)
+        self._scale_sample = torch.tensor([math.sqrt(noise), 1.0], dtype=torch.float32, device=dev)
+        self._T = torch.zeros(kp, 16, dtype=torch.float32, device=dev)
+        self._work = {}
+        if self._factor is not self.Lt:
+            del A
+            self.Lt = None                                             # only the fp16 copy stays resident
+
+    @property
+    def L(self):
+        """[n, k] in the caller's row order (tests; the solver never forms it)."""
+        return self.lat.from_lattice_order(self._factor[:self.rank, :self.n].float().t().contiguous())
+
+    def _workspace(self, t):
+        from . import _native as nv
+        w = self._work.get(t)
+        if w is None:
+            w = self._work[t] = torch.empty(int(nv.lib().plx_pcg_work_floats(self.n, self.kp, t)), dtype=torch.float32,
+                                            device=self._factor.device)
+        return w
+
+    def solve_lattice(self, R, out=None, rz=None):
+        """Z = P^-1 R for R [n, t] in lattice row order (t <= 16); rz (optional, [t]) receives <R, Z> per column."""
+        import ctypes
+        from . import _native as nv
+        lib = nv.lib()
+        assert R.is_cuda and R.dtype == torch.float32 and R.dim() == 2 and R.is_contiguous() and R.shape[0] == self.n
+        t = R.shape[1]
+        Z = torch.empty_like(R) if out is None else out
+        work = self._workspace(t)
+        dev = self._factor.device
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            nv.check(lib.plx_pcg_project(_vp(self._factor), self.factor_type, self.ld, self.kp, _vp(R), self.n, t, _vp(self._cinv),
+                                         _vp(self._T), _vp(work), stream), "plx_pcg_project")
+            nv.check(lib.plx_pcg_apply(_vp(self._factor), self.factor_type, self.ld, self.kp, self.rank, _vp(R), self.n, t,
+                                       _vp(self._T), _vp(self._scale_solve), _vp(Z), _vp(rz), _vp(work), stream), "plx_pcg_apply")
+        return Z
+
+    def _columns(self, fn, R):
+        """fn over column blocks of at most 16 (the native passes' tile), R in the caller's order."""
+        outs = []
+        for c0 in range(0, R.shape[1], 16):
+            blk = self.lat.to_lattice_order(R[:, c0:c0 + 16]).contiguous()
+            outs.append(self.lat.from_lattice_order(fn(blk)))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
+
+    def solve(self, R):
+        """P^-1 R, rows in the caller's order (any number of columns)."""
+        return self._columns(self.solve_lattice, R.contiguous())
+
+    def logdet(self):
+        return 2.0 * self._chol.diagonal().log().sum() + (self.n - self.rank) * math.log(self.noise)
+
+    def sample(self, t, generator=None):
+        """t columns drawn from N(0, P), rows in the caller's order: L g1 + sigma g2, the same draws in the same order
+        as PivotedCholeskyPreconditioner.sample."""
+        import ctypes
+        from . import _native as nv
+        lib = nv.lib()
+        dev = self._factor.device
+        g1 = torch.randn(self.rank, t, generator=generator, device=dev, dtype=torch.float32)
+        g2 = torch.randn(self.n, t, generator=generator, device=dev, dtype=torch.float32)
+
+        def draw(blk, c0=[0]):
+            tb = blk.shape[1]
+            T = torch.zeros(self.kp, 16, dtype=torch.float32, device=dev)
+            T[:self.rank, :tb] = -g1[:, c0[0]:c0[0] + tb]
+            c0[0] += tb
+            Z = torch.empty_like(blk)
+            with torch.cuda.device(dev):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                nv.check(lib.plx_pcg_apply(_vp(self._factor), self.factor_type, self.ld, self.kp, self.rank, _vp(blk), self.n, tb,
+                                           _vp(T), _vp(self._scale_sample), _vp(Z), None, _vp(self._workspace(tb)), stream),
+                         "plx_pcg_apply")
+            return Z
+        return self._columns(draw, g2)
+
+
+def _batched_pcg_native(matmul, B, precond, max_iter, tol, want_tridiag, check_every, matmul_dot=None, floor=0):
+    """Preconditioned batched CG on one GPU, rows in lattice order, scalars on the device: per iteration one MVM (with
+    its p^T A p), plx_cg_step_update (alpha = rz / pAp, X, R, |R|^2), the preconditioner (plx_pcg_project +
+    plx_pcg_apply: Z = P^-1 R and <R, Z>) and plx_pcg_step_direction (beta = rz' / rz, P = Z + beta P, active)."""
+    import ctypes
+    from . import _native as nv
+    lib = nv.lib()
+    n, t = B.shape
+    dev = B.device
+    X = torch.zeros_like(B)
+    R = B.clone().contiguous()
+    rz = torch.empty(t, dtype=torch.float32, device=dev)
+    rz_new = torch.empty_like(rz)
+    Z = precond.solve_lattice(R, rz=rz)
+    P = Z.clone()
+    rz0 = rz.clone()
+    rr = _colsum(R, R)
+    b_norm = rr.sqrt().clamp_min(1e-30)
+    rr = rr.clone()
+    active = torch.ones(t, dtype=torch.float32, device=dev)
+    active_next = torch.empty_like(active)
+    key = (dev.index, t)
+    work = _dot_work.get(key)
+    if work is None:
+        work = _dot_work[key] = torch.empty(int(lib.plx_coldot_work_floats(t)), dtype=torch.float32, device=dev)
+    alphas = torch.zeros(max_iter if want_tridiag else 1, t, dtype=torch.float32, device=dev)
+    betas = torch.zeros(max_iter if want_tridiag else 1, t, dtype=torch.float32, device=dev)
+    it = 0
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for it in range(1, max_iter + 1):
+            if matmul_dot is not None:
+                AP, pAp = matmul_dot(P)
+                pAp = pAp.contiguous()
+            else:
+                AP = matmul(P)
+                AP = AP if AP.is_contiguous() else AP.contiguous()
+                pAp = _colsum(P, AP)
+            row = it - 1 if want_tridiag else 0
+            nv.check(lib.plx_cg_step_update(_vp(X), _vp(R), _vp(P), _vp(AP), _vp(rz), _vp(pAp), _vp(active), n, t, _vp(rr),
+                                            _vp(alphas[row]), _vp(work), stream), "plx_cg_step_update")
+            precond.solve_lattice(R, out=Z, rz=rz_new)
+            step_tol = float(tol) if it >= floor else min(float(tol), _FROZEN_BELOW)
+            nv.check(lib.plx_pcg_step_direction(_vp(P), _vp(Z), _vp(rz_new), _vp(rz), _vp(rr), _vp(active), _vp(b_norm), step_tol,
+                                                n, t, _vp(betas[row]), _vp(active_next), stream), "plx_pcg_step_direction")
+            rz, rz_new = rz_new, rz
+            active, active_next = active_next, active
+            if tol > 0 and (it % check_every == 0 or it == max_iter) and not bool(active.any()):
+                break
+    info = {"iterations": it, "residual": (rr.sqrt() / b_norm), "rz0": rz0}
+    if want_tridiag:
+        info["tridiag"] = _tridiag_from_cg(list(alphas[:it]), list(betas[:it]), B)
+    return X, info
+
+
 _FROZEN_BELOW = 1e-10     # a column whose relative residual is below this never moves again (GPyTorch: stop_updating_after)
 
 
@@ -203,6 +428,8 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
     """
     floor = _iteration_floor(max_iter, want_tridiag, min_iter, min_tridiag_iter)
+    if isinstance(precond, LatticePreconditioner) and reduce is None and _native_ok(B) and B.shape[1] <= 16:
+        return _batched_pcg_native(matmul, B, precond, max_iter, tol, want_tridiag, check_every, matmul_dot, floor)
     if precond is not None:
         return _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every, floor)
     if reduce is None and _native_ok(B):
@@ -397,8 +624,10 @@ class LatticeGP(nn.Module):
             s, noise = self.outputscale, self.noise
             lat.set_lattice_row_order(True)
             try:
-                if cg_args.get("precond") is not None:
-                    # the factor's rows are in the caller's order: keep that order for the whole solve
+                pre = cg_args.get("precond")
+                native_pre = isinstance(pre, LatticePreconditioner) and pre.lat is lat
+                if pre is not None and not (native_pre and rhs.shape[1] <= 16):
+                    # a factor whose rows are in the caller's order: keep that order for the whole solve
                     lat.set_lattice_row_order(False)
                     return batched_cg(lambda V: lat.apply(V).mul_(s).addcmul_(V, noise), rhs, **cg_args)
                 ss = torch.stack([s.detach().reshape(()), noise.detach().reshape(())]).to(torch.float32).contiguous()
@@ -417,20 +646,50 @@ class LatticeGP(nn.Module):
                     info = dict(info, residual=info["residual"][:t])
                     if "tridiag" in info:
                         info["tridiag"] = info["tridiag"][:t]
+                    if "rz0" in info:
+                        info["rz0"] = info["rz0"][:t]
             finally:
                 lat.set_lattice_row_order(False)
             return lat.from_lattice_order(sol), info
 
-    def preconditioner(self, x, rank, K=None):
-        """Rank-`rank` pivoted-Cholesky preconditioner of (s K + sigma^2 I) (no gradients)."""
+    def preconditioner(self, x, rank, K=None, factor_dtype=torch.float16):
+        """Rank-`rank` pivoted-Cholesky preconditioner of (s K + sigma^2 I) (no gradients).  On the HIP path it is
+        built and applied natively, in the row order of the lattice the solve runs on (LatticePreconditioner)."""
+        from . import lattice_kernel as lk
         with torch.no_grad():
+            if lk.LatticeFilterGeneral.method is None and x.is_cuda and x.dtype == torch.float32:
+                ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
+                ref = ref if ref.is_contiguous() else ref.contiguous()
+                lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
+                return LatticePreconditioner(lat, self.outputscale, self.noise, rank, factor_dtype=factor_dtype)
             K = self.kernel(x, x) if K is None else K
             return PivotedCholeskyPreconditioner(K.matmul, x.shape[0], self.outputscale, self.noise, rank,
                                                  device=x.device, dtype=x.dtype)
 
 
+class _Phases:
+    """Wall time per phase of one marginal-likelihood evaluation (profile= of marginal_log_likelihood): every mark
+    synchronises the device, so it is a measuring mode, never the default."""
+
+    def __init__(self, sink, device):
+        import time
+        self.sink, self.device, self._clock = sink, device, time.perf_counter
+        self._t = self._now() if sink is not None else None
+
+    def _now(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return self._clock()
+
+    def mark(self, name):
+        if self.sink is not None:
+            t = self._now()
+            self.sink[name] = self.sink.get(name, 0.0) + (t - self._t) * 1e3
+            self._t = t
+
+
 def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, pre_size=0, reduce=None,
-                            n_total=None):
+                            n_total=None, profile=None):
     """Per-datapoint log marginal likelihood (the quantity GPyTorch's
     ExactMarginalLogLikelihood returns) of a LatticeGP, differentiable with
     respect to every hyper-parameter.
@@ -445,6 +704,9 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     preconditions the solve with P = pivoted-Cholesky(s K, pre_size) + sigma^2 I:
     probes are drawn from N(0, P), logdet = logdet P + SLQ of P^-1/2 (sK + sigma^2 I) P^-1/2,
     and the log-det gradient pairs w_i with P^-1 z_i  (E[P^-1 z z^T] = I).
+
+    profile: a dict that receives the wall time in ms of every phase (preconditioner, probes, solve, slq,
+    mvm_forward; the caller times backward()); each phase boundary synchronises the device.
     """
     if reduce is not None or n_total is not None:
         # kept in the signature for one release: the old row-sharded form evaluated a block-diagonal likelihood
@@ -454,6 +716,7 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     # distributed.ShardedLatticeMVM (whose vertex all-reduce couples the ranks); distributed.sharded_solve does the
     # solve that way, a sharded marginal likelihood with gradients is not implemented.
     n = n_local = y.shape[0]
+    ph = _Phases(profile, y.device)
     r = (y - model.mean).reshape(-1, 1)
     g = torch.Generator(device=y.device).manual_seed(seed)      # on the device: 1e7 CPU draws cost ~0.1 s per step
     K = model.kernel(x, x)
@@ -461,13 +724,16 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
     precond = None
     if pre_size > 0:
         precond = model.preconditioner(x, pre_size, K=K)
+    ph.mark("preconditioner")
     with torch.no_grad():
         if precond is None:
             Z = torch.randint(0, 2, (n_local, num_probes), generator=g, device=y.device).to(r.dtype) * 2 - 1
         else:
             Z = precond.sample(num_probes, generator=g)
         rhs = torch.cat([r.detach(), Z], 1)
+        ph.mark("probes")
         sol, info = model.khat_solve(x, rhs, K=K, max_iter=max_cg_iter, tol=cg_tol, want_tridiag=True, precond=precond)
+        ph.mark("solve")
         u, W = sol[:, :1], sol[:, 1:]
         quad = _colsum(r.detach(), u).sum()
         if precond is None:
@@ -476,11 +742,13 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
             logdet = precond.logdet() + slq_logdet(info["tridiag"][1:], n, weights=info["rz0"][1:])
             Z = precond.solve(Z)
         value = -0.5 * quad - 0.5 * logdet - 0.5 * n * math.log(2 * math.pi)
+    ph.mark("slq")
     KV = mm(torch.cat([u, Z], 1))                                # differentiable MVM
     s_quad = -(u * r).sum() + 0.5 * (u * KV[:, :1]).sum()
     s_logdet = -0.5 * (W * KV[:, 1:]).sum() / num_probes
     surrogate = s_quad + s_logdet
     out = (value.to(surrogate.dtype) + (surrogate - surrogate.detach())) / n
+    ph.mark("mvm_forward")
     out.cg_info = info
     return out
 
