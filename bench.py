@@ -420,10 +420,69 @@ def config3_leg(ctx, n=1_000_000, d=8, iters=50):
             res = float(info["residual"].max())
             m = list(plx.lattice_cache()._entries.values())[-1][0].m
     plx.lattice_cache().clear()
+    del x, y, Z, rhs
+    train = train_step_leg(ctx, n, d, lambda: plx.RBFLattice(order=1, ard_num_dims=d))
     return {"config3_cg_ms": round(best * 1e3, 2), "config3": {
         "workload": f"N={n}, d={d}, vd=11, lengthscale 0.6931, {iters} CG iterations incl. one lattice build",
         "ms_incl_build": round(best * 1e3, 2), "ms_cg_only": round(best_warm * 1e3, 2), "m_vertices": m,
-        "cg_iterations_per_s": round(iters / best_warm, 1), "final_rel_residual_max": res}}
+        "cg_iterations_per_s": round(iters / best_warm, 1), "final_rel_residual_max": res,
+        "train_step_ms": {k: v["step_ms"] for k, v in train.items() if k.startswith("pre_size")}, "train_step": train}}
+
+
+def train_step_leg(ctx, n, d, make_kernel, pre_sizes=(0, 100), steps=3, min_noise=1e-4, label=""):
+    """One marginal-likelihood training step as the reference's loop runs it (experiments/train_simplexgp.py:29-57:
+    10 probes, cg_tolerance(1.0), max_cg_iterations(500), max_preconditioner_size(pre_size); loss.backward(); Adam):
+    wall time of the whole step (forward + backward + optimiser, no synchronisation inside; best of `steps` after one
+    untimed step) and, from one more step run in the profiling mode of solvers.marginal_log_likelihood (a device
+    synchronisation at every phase boundary), where it goes."""
+    import torch
+    import simplex_gp_amd as plx
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(n, d, generator=g).to(ctx.dev)
+    y = (torch.sin(x[:, 0]) + 0.1 * torch.randn(n, generator=g).to(ctx.dev))
+    out = {}
+    for pre in pre_sizes:
+        model = solvers.LatticeGP(make_kernel(), min_noise=min_noise).to(ctx.dev)
+        opt = torch.optim.Adam(model.parameters(), lr=0.1)
+        start = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+        def step(seed, prof=None):
+            # every measured step starts from the same (GPyTorch default) hyper-parameters: the lattice of a step depends
+            # on the lengthscale, and Adam at lr 0.1 moves it by 10 % per step
+            model.load_state_dict(start)
+            opt.zero_grad()
+            ctx.sync()
+            t0 = time.perf_counter()
+            mll = solvers.marginal_log_likelihood(model, x, y, num_probes=10, cg_tol=1.0, max_cg_iter=500, seed=seed,
+                                                  pre_size=pre, profile=prof)
+            if prof is not None:
+                ctx.sync()
+            t1 = time.perf_counter()
+            (-mll).backward()
+            if prof is not None:
+                ctx.sync()
+                prof["backward"] = (time.perf_counter() - t1) * 1e3
+            t2 = time.perf_counter()
+            opt.step()
+            ctx.sync()
+            if prof is not None:
+                prof["optimizer"] = (time.perf_counter() - t2) * 1e3
+            return (time.perf_counter() - t0) * 1e3, mll
+        step(0)
+        step(0)                                   # two untimed steps: the lattice objects of forward and backward exist and are sized
+        best = min(step(1 + i)[0] for i in range(steps))
+        prof = {}
+        _, mll = step(99, prof)
+        lat = list(plx.lattice_cache()._entries.values())[-1][0]
+        out[f"pre_size_{pre}"] = {"step_ms": round(best, 2), "phases_ms": {k: round(v, 2) for k, v in prof.items()},
+                                  "cg_iterations": int(mll.cg_info["iterations"]), "m_vertices": lat.m}
+        plx.lattice_cache().clear()
+        del model, opt
+    out["workload"] = (f"{label}N={n}, d={d}: one Adam step on the CG/SLQ marginal likelihood (10 probes, cg_tol 1, max 500 CG "
+                       "iterations, GPyTorch's default initial hyper-parameters): forward (preconditioner, probes, solve, SLQ, "
+                       "differentiable MVM) + backward (one 2L(1+d)-column filter with the derivative taps) + optimiser")
+    return out
 
 
 def config5_leg(ctx, n=10623, d=18):
@@ -446,9 +505,28 @@ def config5_leg(ctx, n=10623, d=18):
     wall_cold = time_region(lambda i: (lat.build(x, taps), lat.apply(v, out)), 10, ctx.sync, lambda: None)
     m = lat.m
     lat.close()
+    # one epoch of the reference's recipe for this data set (configs/simplexgp.yml:11-45: pre_size 100, min_noise 0.1,
+    # Matern-1.5; order 3 per BASELINE.json): a training step, and the evaluation the loop runs beside it
+    # (train_simplexgp.py:123-165: predictive mean + variance on the validation and test splits, cg_eval_tol 1e-2)
+    train = train_step_leg(ctx, n, d, lambda: plx.MaternLattice(nu=1.5, order=3, ard_num_dims=d), pre_sizes=(100,), steps=3,
+                           min_noise=0.1, label="elevators stand-in, ")
+    from simplex_gp_amd import solvers, training
+    xs = torch.randn(2656 + 3320, d, generator=g).to(ctx.dev)                 # 16 % + 20 % of 16,599 rows
+    y = (torch.sin(x[:, 0]) + 0.1 * torch.randn(n, generator=g).to(ctx.dev))
+    model = solvers.LatticeGP(plx.MaternLattice(nu=1.5, order=3, ard_num_dims=d), min_noise=0.1).to(ctx.dev)
+    training.predict(model, x, y, xs, cg_tol=1e-2, lanc_iter=100, pre_size=100)
+    ctx.sync()
+    t0 = time.perf_counter()
+    training.predict(model, x, y, xs, cg_tol=1e-2, lanc_iter=100, pre_size=100)
+    ctx.sync()
+    eval_ms = (time.perf_counter() - t0) * 1e3
+    plx.lattice_cache().clear()
     return {"config5_mvm_us": round(wall / reps * 1e6, 1), "config5": {
         "workload": f"MaternLattice(nu=1.5, order=3) stand-in for elevators: N={n}, d={d}, vd=1, lengthscale 1",
-        "m_vertices": m, "warm_mvm_us": round(wall / reps * 1e6, 1), "cold_call_us": round(wall_cold / 10 * 1e6, 1)}}
+        "m_vertices": m, "warm_mvm_us": round(wall / reps * 1e6, 1), "cold_call_us": round(wall_cold / 10 * 1e6, 1),
+        "epoch_ms": train["pre_size_100"]["step_ms"], "train_step": train, "eval_ms": round(eval_ms, 2),
+        "eval_workload": "training.predict (CG mean at cg_eval_tol 1e-2 + 100-step Lanczos variance, pre_size 100) on "
+                         "5,976 held-out rows"}}
 
 
 def exchange_record(job, vd, stage_us):

@@ -691,8 +691,12 @@ int prepare_tables(plx_lattice *L, int vd, hipStream_t stream)
     bool sp = false, sl = false;
     PLX_TRY(choose_paths(L, vd, stream, &sp, &sl));
     if (L->nnz == 0) return PLX_OK;
-    if (sp) PLX_TRY(ensure_s2(L, stream));
-    else PLX_TRY(ensure_csr(L, stream));
+    if (sp) { PLX_TRY(ensure_s2(L, stream)); return PLX_OK; }
+    if (vd == 1) {
+        PLX_TRY(ensure_first(L, stream));
+        if (L->use_first) return PLX_OK;
+    }
+    PLX_TRY(ensure_csr(L, stream));
     return PLX_OK;
 }
 

@@ -637,7 +637,11 @@ __global__ __launch_bounds__(kBlock) void ids_kernel(const uint32_t *__restrict_
 // One bit per hash slot: occupied.  On large, sparse lattices most neighbour lookups are for vertices that do not
 // exist (88 % at l = 0.25, 43 % at l = 0.69: SURVEY 6.3), and an absent key ends its probe sequence at the first empty
 // slot: with the bit tested first that slot is never fetched -- a random 4-byte read of a 134 MB table becomes a read of
-// a 4 MB bitmap that the L2s / the Infinity Cache hold.  Same probe sequence, same result, bit for bit.
+// a 4 MB bitmap.  Same probe sequence, same result, bit for bit.  Measured (round 4, N = 1e6, d = 8, tools/ab_fine_r4.py):
+// neighbours 3.07 -> 2.92 ms at l = 0.25 (m = 8.9e6), 1.90 -> 1.92 at l = 0.4 (7.2e6), 0.38 -> 0.48 at l = 0.69 (1.7e6: the
+// pass that builds the bitmap reads the whole table) -- the lookups are bound by the RATE of random requests the
+// fabric serves (~40 G/s), which a bitmap that does not fit the 4 MB L2s next to the kernel's other streams does not
+// lower; it is used from m = 2^22 up, where it is at least not slower.
 __global__ __launch_bounds__(kBlock) void slotmap_kernel(const uint32_t *__restrict__ table, uint64_t cap,
                                                          unsigned long long *__restrict__ bits)
 {
@@ -1110,6 +1114,7 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
         L->ekeys.as<uint32_t>(), n, L->table.as<uint32_t>(), L->table_mask, L->eslot.as<uint32_t>(), g_insert_dedupe,
         plane_fast);
     mark();
+    L->flags_valid = !L->for_merge;      // the first-touch bits of this build's points stay in flagmask (plx_first.hip reads them)
     flag_kernel<D1><<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
                                                     L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
     scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
@@ -1320,7 +1325,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         dim3 ngrid(ceil_div(m, kBlock), D1);
         if (nplane_fast) ngrid = dim3(D1, ceil_div(m, kBlock));
         const uint32_t *slotmap = nullptr;
-        if (g_nbr_bitmap == 2 || (g_nbr_bitmap == 1 && m >= (1 << 20))) {
+        if (g_nbr_bitmap == 2 || (g_nbr_bitmap == 1 && m >= (1 << 22))) {
             const uint64_t cap = (uint64_t)L->table_mask + 1u;       // a power of two >= 1024
             PLX_TRY(ensure(L->slotmap, (size_t)cap / 8 + 8));
             slotmap_kernel<<<ceil_div(cap, kBlock), kBlock, 0, stream>>>(L->table.as<uint32_t>(), cap,
@@ -1378,6 +1383,8 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
     // splat / slice tables over the owned points (block tables, their vertex-sorted half, the vertex-sorted CSR): each is
     // built by its first user (plx_prepare, or the first MVM that needs it -- ensure_blocks / ensure_s2 / ensure_csr)
     L->csr_ready = false;
+    L->first_ready = false;
+    L->use_first = false;
     L->blocks_ready = false;
     L->s2_ready = false;
     L->inv_perm_ready = false;

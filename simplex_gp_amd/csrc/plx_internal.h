@@ -71,8 +71,8 @@ struct Tune {
     int unpermute_gather = 1;   // caller row order out of slice: 1 = lattice-ordered scratch + a gather pass, 0 = scatter from the slice kernel
     int block_e = 0;   // corners per thread of the block kernels: 0 = per lattice (choose_block_e), 16 or 24
     int block_dense_combine = 1;   // combine numbers the vertices by counting row ends when every vertex has block rows
-    int nbr_bitmap = 1;   // neighbour lookups test a slot-occupancy bitmap before they touch the hash table: 0 never, 1 when m >= 2^20, 2 always
-    int splat_first = 1;   // vd = 1 splat on lattices where almost every corner owns its vertex: first-touch corners store, the rest add (0 never, 1 when it qualifies)
+    int nbr_bitmap = 1;   // neighbour lookups test a slot-occupancy bitmap before they touch the hash table: 0 never, 1 when m >= 2^22, 2 always
+    int splat_first = 1;   // vd = 1 splat on lattices where almost every corner owns its vertex: first-touch corners store, the rest add (0 never, 1 when m >= 0.9 nnz, 2 whenever representable, 3 = 2 without the contiguous-range store)
     // diagnostic ablations: the members always exist (one layout for both libraries), but only libplx_diag.so knows
     // their names and compiles the branches behind them (PLX_DIAG_VALUE)
     int splat_ablate = 0;   // libplx_diag.so only: 1 no value gather, 2 no stores, 4 no row-id loads
@@ -211,6 +211,11 @@ struct plx_lattice {
     plx::DevBuf partial;    // float  [n_brows]      per-MVM block-row sums
     plx::DevBuf inv_perm;   // uint32 [n_own]        lattice-order position of every caller row of the shard
     bool inv_perm_ready = false;
+    // first-touch splat (plx_first.hip): vd = 1 on lattices where almost every corner owns its vertex
+    bool flags_valid = false;    // flagmask holds the first-touch bits of THIS build's points (plain single-process builds)
+    bool first_ready = false, use_first = false;
+    int64_t n_extra = 0;         // corners that are not the first touch of their vertex (nnz - m)
+    plx::DevBuf ex_vid, ex_pt, ex_w, ex_keys;   // int32 / int32 / float [n_extra] the extras sorted by vertex; sort scratch
 
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
@@ -253,6 +258,9 @@ int unpermute_rows(plx_lattice *L, const float *d_tmp, int vd, float *d_out, con
 int choose_paths(plx_lattice *L, int vd, hipStream_t stream, bool *splat_blocks, bool *slice_blocks);
 int prepare_tables(plx_lattice *L, int vd, hipStream_t stream);
 int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);
+// plx_first.hip
+int ensure_first(plx_lattice *L, hipStream_t stream);
+int splat_first_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);
 int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStream_t stream, const float *d_affine,
                      const float *d_src);
 // plx_sort.hip: plx::radix (plx_radix.h) behind plain functions -- stable LSD sort of bits [0, end_bit), ping-ponging between

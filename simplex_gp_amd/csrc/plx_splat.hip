@@ -549,6 +549,10 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     bool splat_blocks = false, slice_blocks = false;
     PLX_TRY(choose_paths(L, vd, stream, &splat_blocks, &slice_blocks));
     if (splat_blocks) return splat_block_impl(L, d_src, d_values, stream);
+    if (vd == 1) {
+        PLX_TRY(ensure_first(L, stream));
+        if (L->use_first) return splat_first_impl(L, d_src, d_values, stream);
+    }
     PLX_TRY(ensure_csr(L, stream));
     const bool all_rows_touched = (L->n_shards == 1 && !L->partial_cover);
     if (!all_rows_touched) PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)m * vdp * 4, stream));

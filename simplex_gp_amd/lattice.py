@@ -59,6 +59,7 @@ class Lattice:
         self._own_begin = 0
         self.lattice_rows = False
         self._dot_work = None
+        self.build_id = 0         # counts the builds of this object (holders of per-build data compare it)
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -86,6 +87,7 @@ class Lattice:
                                     taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), taps.size,
                                     index, count, _stream_ptr(self.device))
         nv.check(rc, "plx_build")
+        self.build_id += 1
         self._ref = ref
         self.taps = taps
         self._perm_cache = None
@@ -110,6 +112,7 @@ class Lattice:
                                      taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), taps.size,
                                      ctypes.c_void_p(out.data_ptr()), _stream_ptr(self.device))
         nv.check(rc, "plx_filter")
+        self.build_id += 1
         self._ref, self.taps, self._perm_cache, self._own_begin = ref, taps, None, 0
         return out
 
@@ -127,6 +130,7 @@ class Lattice:
                                    taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), taps.size,
                                    _stream_ptr(self.device))
         nv.check(rc, "plx_build_local")
+        self.build_id += 1
         self._ref, self.taps, self._perm_cache, self._own_begin = ref_local, taps, None, 0
         keys = torch.empty((int(L.plx_local_vertices(self._h)), int(L.plx_key_words(d))), dtype=torch.int32,
                            device=self.device)

@@ -202,6 +202,8 @@ class LatticePreconditioner:
         kp = max(16, (k + 15) // 16 * 16)
         ld = (n + 63) // 64 * 64
         self.lat, self.n, self.rank, self.kp, self.ld, self.noise, self.outputscale = lat, n, k, kp, ld, noise, s
+        self.build_id = lat.build_id        # a lattice object is recycled by the cache: the factor belongs to THIS build of it
+        self.ref = None
         self.Lt = torch.zeros(kp, ld, dtype=torch.float32, device=dev)
         diag = torch.full((n,), s, dtype=torch.float32, device=dev)
         row_rank = torch.empty(lat.n, dtype=torch.int32, device=dev)          # caller row of every lattice position (uint32 bits)
@@ -297,6 +299,9 @@ class LatticePreconditioner:
 
     def _columns(self, fn, R):
         """fn over column blocks of at most 16 (the native passes' tile), R in the caller's order."""
+        if self.lat.build_id != self.build_id:
+            raise RuntimeError("LatticePreconditioner: its lattice has been rebuilt for other positions (lattice-cache eviction); "
+                               "build the preconditioner again")
         outs = []
         for c0 in range(0, R.shape[1], 16):
             blk = self.lat.to_lattice_order(R[:, c0:c0 + 16]).contiguous()
@@ -405,7 +410,7 @@ def _iteration_floor(max_iter, want_tridiag, min_iter, min_tridiag_iter):
 
 
 def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=False, check_every=4, precond=None,
-               matmul_dot=None, min_iter=10, min_tridiag_iter=20):
+               matmul_dot=None, min_iter=10, min_tridiag_iter=20, lattice_rows=False):
     """Solve A X = B for all columns of B at once (A symmetric positive definite,
     known through `matmul`).  Stops when every column's residual norm is below
     `tol` x its right-hand-side norm, or after max_iter iterations.  The stopping
@@ -424,11 +429,15 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     `min_iter` / `min_tridiag_iter`: iteration floor as in GPyTorch's linear_cg (see _iteration_floor); before it only
     columns that have converged to rounding level (relative residual < 1e-10) are frozen.
 
+    `lattice_rows`: the rows of B (and what `matmul` takes and returns) are in the row order of precond.lat, a
+    LatticePreconditioner -- the native preconditioned iteration runs; any other combination goes through
+    precond.solve(), which takes rows in the caller's order.
+
     Returns (X, info); with want_tridiag, info["tridiag"] holds the per-column
     Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
     """
     floor = _iteration_floor(max_iter, want_tridiag, min_iter, min_tridiag_iter)
-    if isinstance(precond, LatticePreconditioner) and reduce is None and _native_ok(B) and B.shape[1] <= 16:
+    if lattice_rows and isinstance(precond, LatticePreconditioner) and reduce is None and _native_ok(B) and B.shape[1] <= 16:
         return _batched_pcg_native(matmul, B, precond, max_iter, tol, want_tridiag, check_every, matmul_dot, floor)
     if precond is not None:
         return _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every, floor)
@@ -620,12 +629,15 @@ class LatticeGP(nn.Module):
             # differentiable MVM that follows a solve reuses the lattice built here
             ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
             ref = ref if ref.is_contiguous() else ref.contiguous()
+            pre = cg_args.get("precond")
+            if isinstance(pre, LatticePreconditioner) and pre.ref is not None and pre.ref is not ref and pre.ref.shape == ref.shape \
+                    and torch.equal(pre.ref, ref):
+                ref = pre.ref          # the same positions as a fresh tensor (no K handed over): solve on the preconditioner's lattice
             lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
             s, noise = self.outputscale, self.noise
             lat.set_lattice_row_order(True)
             try:
-                pre = cg_args.get("precond")
-                native_pre = isinstance(pre, LatticePreconditioner) and pre.lat is lat
+                native_pre = isinstance(pre, LatticePreconditioner) and pre.lat is lat and pre.build_id == lat.build_id
                 if pre is not None and not (native_pre and rhs.shape[1] <= 16):
                     # a factor whose rows are in the caller's order: keep that order for the whole solve
                     lat.set_lattice_row_order(False)
@@ -640,7 +652,8 @@ class LatticeGP(nn.Module):
                 if pad:
                     rhs_l = torch.cat([rhs_l, rhs_l.new_zeros(rhs_l.shape[0], pad)], 1).contiguous()
                 fused_dot = (lambda V: lat.apply_affine(V, ss, want_dot=True)) if 2 <= rhs_l.shape[1] <= 256 else None
-                sol, info = batched_cg(lambda V: lat.apply_affine(V, ss), rhs_l, matmul_dot=fused_dot, **cg_args)
+                sol, info = batched_cg(lambda V: lat.apply_affine(V, ss), rhs_l, matmul_dot=fused_dot, lattice_rows=native_pre,
+                                       **cg_args)
                 if pad:
                     sol = sol[:, :t].contiguous()
                     info = dict(info, residual=info["residual"][:t])
@@ -661,7 +674,9 @@ class LatticeGP(nn.Module):
                 ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
                 ref = ref if ref.is_contiguous() else ref.contiguous()
                 lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
-                return LatticePreconditioner(lat, self.outputscale, self.noise, rank, factor_dtype=factor_dtype)
+                pre = LatticePreconditioner(lat, self.outputscale, self.noise, rank, factor_dtype=factor_dtype)
+                pre.ref = ref          # the positions its lattice was built on (kept alive: the lattice-cache key)
+                return pre
             K = self.kernel(x, x) if K is None else K
             return PivotedCholeskyPreconditioner(K.matmul, x.shape[0], self.outputscale, self.noise, rank,
                                                  device=x.device, dtype=x.dtype)

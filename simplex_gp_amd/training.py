@@ -48,17 +48,20 @@ def lanczos(matmul, v0, steps):
 
 
 @torch.no_grad()
-def predict(model, x, y, x_star, max_cg_iter=1000, cg_tol=1e-2, lanc_iter=100, variance=True, pre_size=0):
+def predict(model, x, y, x_star, max_cg_iter=1000, cg_tol=1e-2, lanc_iter=100, variance=True, pre_size=100):
     """Posterior mean and variance of the latent function at x_star.
 
     mean = mu + s K(x*, X) (s K + sigma^2 I)^-1 (y - mu)          one CG solve + one rectangular MVM
     var  = s k(x*, x*) - || L^-1 Q^T (s K(X, x*)) ||^2            K^-1 ~ Q T^-1 Q^T from `lanc_iter`
            Lanczos steps started at y - mu, T = L L^T; one rectangular MVM with lanc_iter columns
+    pre_size: rank of the pivoted-Cholesky preconditioner of the mean solve (the reference's test() default,
+    train_simplexgp.py:60: 100; 0 = plain CG)
     """
     assert isinstance(model, LatticeGP)
     r = (y - model.mean).reshape(-1, 1)
-    precond = model.preconditioner(x, pre_size) if pre_size > 0 else None
-    alpha, _ = model.khat_solve(x, r, max_iter=max_cg_iter, tol=cg_tol, precond=precond)
+    K = model.kernel(x, x)                                # one operator (one lattice) for the preconditioner and the solve
+    precond = model.preconditioner(x, pre_size, K=K) if pre_size > 0 else None
+    alpha, _ = model.khat_solve(x, r, K=K, max_iter=max_cg_iter, tol=cg_tol, precond=precond)
     K_star = model.kernel(x_star, x)                      # RectangularLazyLattice, [n*, n]
     s = model.outputscale
     mean = model.mean + s * K_star.matmul(alpha).squeeze(-1)
@@ -109,12 +112,13 @@ class EarlyStopper:
 
 
 def fit(model, train, val=None, test=None, epochs=100, lr=0.1, patience=200, log_every=1, num_probes=10,
-        cg_iter=1000, cg_tol=1.0, cg_eval_tol=1e-2, lanc_iter=100, pre_size=0, checkpoint=None, log=None):
+        cg_iter=1000, cg_tol=1.0, cg_eval_tol=1e-2, lanc_iter=100, pre_size=100, checkpoint=None, log=None):
     """Adam on -MLL; every `log_every` epochs evaluate on val/test, keep the state
     with the best validation RMSE, stop after `patience` evaluations without
     improvement; optionally torch.save the best state_dict to `checkpoint`.
-    `pre_size` is the rank of the pivoted-Cholesky preconditioner (train_simplexgp.py:36, the
-    reference's configs use 100; it costs pre_size extra single-column MVMs per solve)."""
+    Defaults are the reference's (train_simplexgp.py:87-90): `pre_size` = 100 is the rank of the pivoted-Cholesky
+    preconditioner (train_simplexgp.py:36; on the HIP path it is built and applied natively, solvers.LatticePreconditioner;
+    0 = plain CG)."""
     x, y = train
     opt = torch.optim.Adam(model.parameters(), lr=lr)
     stopper = EarlyStopper(patience=patience)

@@ -182,7 +182,8 @@ def test_config5_matern_order3_d18(plx):
     assert rel_l2(out, want) <= 1e-5
     lat.close()
     model = solvers.LatticeGP(k, min_noise=0.1).cuda()
-    history, _ = training.fit(model, (x.cuda(), y.cuda()), epochs=12, lr=0.1, num_probes=10, cg_iter=500, cg_tol=1.0)
+    history, _ = training.fit(model, (x.cuda(), y.cuda()), epochs=12, lr=0.1, num_probes=10, cg_iter=500, cg_tol=1.0,
+                              pre_size=100)          # the recipe of configs/simplexgp.yml
     mll = np.array([h["train/mll"] for h in history])
     print("config 5 stand-in: train/mll per epoch", np.round(mll, 4))
     assert len(mll) == 12 and np.isfinite(mll).all()

@@ -692,3 +692,62 @@ def test_tables_are_built_by_their_first_user(plx):
     assert rel_l2(once.cpu().numpy(), want11.cpu().numpy()) <= 1e-6
     assert rel_l2(plx.Lattice().filter_once(v1, x2, taps).cpu().numpy(), want1.cpu().numpy()) <= 1e-6
     lat.close(); fresh.close()
+
+
+def test_first_touch_splat_equals_sorted_corner_path(plx):
+    """vd = 1 on lattices where (almost) every corner owns its vertex -- plx_first.hip: the first-touch corner of every
+    vertex stores its product (as one contiguous run per workgroup under first-touch numbering, scattered otherwise), the
+    few remaining corners are added from a short list sorted by vertex -- against the vertex-sorted segmented scan and the
+    oracle: fine clouds, clouds with exact duplicates (extras), both row orders, and a heavy tail (hundreds of points on one
+    spot) that must send the lattice back to the sorted-corner path."""
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    rng = np.random.default_rng(123)
+    cases = []
+    for n, d, scale in [(30011, 8, 0.25), (5000, 3, 0.02), (20000, 18, 0.5), (257, 2, 0.001), (100003, 5, 0.1)]:
+        ref = (rng.standard_normal((n, d)) / scale).astype(np.float32)
+        cases.append(("fine", ref, True))
+        dup = ref.copy()
+        dup[n // 2: n // 2 + n // 50] = dup[: n // 50]                       # 2 % exact duplicates: every corner of them is an extra
+        cases.append(("duplicates", dup, True))
+    heavy = (rng.standard_normal((20000, 4)) / 0.01).astype(np.float32)
+    heavy[:300] = heavy[0]                                                    # 300 points on one spot: runs of 299 extras
+    cases.append(("heavy tail", heavy, False))
+    try:
+        for name, ref, expect_first in cases:
+            n, d = ref.shape
+            src = rng.standard_normal((n, 1)).astype(np.float32)
+            oracle.set_exact_mode(False)
+            want = oracle.filter(src, ref, taps)
+            oracle.set_exact_mode(True)
+            x, s = torch.from_numpy(ref).cuda(), torch.from_numpy(src).cuda()
+            outs = {}
+            for mode in (0, 1, 3):
+                nv.check(lib.plx_tune(b"splat_first", mode), "plx_tune")
+                lat = plx.Lattice().build(x, taps)
+                out = lat.apply(s).clone()
+                kern = lat.stage_kernels()["splat"]
+                used = any("splat_first" in k for k in kern)
+                assert used == (mode != 0 and expect_first), (name, n, d, mode, kern)
+                if mode == 1 and expect_first:
+                    assert "splat_first_seq_kernel" in kern          # first-touch numbering on these lattices: the contiguous store
+                assert rel_l2(out.cpu().numpy(), want) <= TOL_ORACLE, (name, n, d, mode)
+                assert torch.equal(lat.apply(s), out)                # reproducible bits
+                vals = lat.splat(s).clone()
+                lat.set_lattice_row_order(True)
+                assert torch.equal(lat.from_lattice_order(lat.apply(lat.to_lattice_order(s))), out)
+                assert torch.equal(lat.splat(lat.to_lattice_order(s)), vals)
+                lat.set_lattice_row_order(False)
+                # a multi-column MVM on the same lattice builds and uses the sorted corners next to it
+                s3 = torch.cat([s, 2 * s, -s], 1).contiguous()
+                o3 = lat.apply(s3)
+                assert rel_l2(o3[:, :1].cpu().numpy(), want) <= TOL_ORACLE
+                assert torch.equal(lat.apply(s), out)
+                outs[mode] = (out, vals, lat.m)
+                lat.close()
+            assert outs[0][2] == outs[1][2] == outs[3][2]
+            assert rel_l2(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy()) <= 2e-6      # two fixed summation orders
+            assert torch.equal(outs[1][1], outs[3][1])                                    # contiguous and scattered stores: same sums
+    finally:
+        nv.check(lib.plx_tune(b"splat_first", 1), "plx_tune")
