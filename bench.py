@@ -569,6 +569,117 @@ def sharded_leg(ctx, n_total, d, ell, vds, steps):
     return out
 
 
+def timed_collective(ctx, fn, reps=10):
+    """Mean wall time (us) of a collective issued alone, max over ranks."""
+    for _ in range(2):
+        fn()
+    wall = time_region(lambda i: fn(), reps, ctx.sync, ctx.barrier)
+    return round(ctx.max_over_ranks(wall) / reps * 1e6, 1)
+
+
+def config3_multi_leg(ctx, n=1_000_000, d=8, iters=50):
+    """BASELINE.json configs[2] on several GPUs, both ways of splitting ONE batched solve (N = 1e6, lengthscale 0.6931,
+    [y | 10 probes], 50 CG iterations incl. the lattice build):
+      points   rows sharded, one vertex all-reduce per MVM + the dot-product all-reduces (distributed.sharded_solve)
+      columns  every rank builds the whole lattice and solves its share of the 11 columns with the single-GPU solver
+               (lattice row order, fused kernels); no collective inside the iteration, one all-gather of the solution"""
+    import torch
+    import simplex_gp_amd as plx
+    from simplex_gp_amd import solvers
+    from simplex_gp_amd.distributed import (ShardedLatticeMVM, shard_bounds, sharded_solve, column_sharded_solve, column_bounds,
+                                            all_gather_columns, all_reduce_sum)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(n, d, generator=g)
+    y = torch.randn(n, generator=g)
+    Z = torch.randint(0, 2, (n, 10), generator=g).float() * 2 - 1
+    rhs = torch.cat([y[:, None], Z], 1)
+    t = rhs.shape[1]
+    ell, s, noise = 0.6931, 0.6931, 0.6932
+    transport = "RCCL" if ctx.backend == "nccl" else ctx.backend
+    out = {"workload": f"N={n}, d={d}, vd={t}, lengthscale {ell}, {iters} CG iterations incl. one lattice build, {ctx.world} rank(s)"}
+    # ---- rows sharded
+    lo, hi = shard_bounds(n, ctx.world, ctx.rank)
+    rhs_local = rhs[lo:hi].contiguous().to(ctx.dev)
+    op = ShardedLatticeMVM.from_local_rows((x[lo:hi] / ell).contiguous().to(ctx.dev), RBF1, n_total=n)
+    sharded_solve(op, rhs_local, s, noise, max_iter=3, tol=0.0)
+    best = float("inf")
+    for trial in range(3):
+        ref_local = (x[lo:hi] / (ell * (1 + 1e-5 * trial))).contiguous().to(ctx.dev)
+        ctx.barrier(); ctx.sync()
+        t0 = time.perf_counter()
+        op.rebuild(ref_local, RBF1)
+        _, info = sharded_solve(op, rhs_local, s, noise, max_iter=iters, tol=0.0)
+        ctx.sync()
+        best = min(best, ctx.max_over_ranks(time.perf_counter() - t0))
+    vals = op.lattice.new_values(t)
+    out["points"] = {"ms_incl_build": round(best * 1e3, 2), "m_vertices": op.m, "rows_per_rank": hi - lo,
+                     "final_rel_residual_max": float(info["residual"].max()),
+                     "exchange": {"kind": f"per MVM: all_reduce(sum) of values[m, {op.lattice.values_stride(t)}] (fp32); per iteration: "
+                                          f"2 all_reduce of {t} dot products; {transport}",
+                                  "bytes": op.exchange_bytes(t), "us": timed_collective(ctx, lambda: all_reduce_sum(vals, op.group))}}
+    op.lattice.close()
+    del op, vals, rhs_local
+    # ---- columns sharded
+    xd, rd = x.to(ctx.dev), rhs.to(ctx.dev)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).to(ctx.dev)
+    clo, chi = column_bounds(t, ctx.world, ctx.rank)
+    best = float("inf")
+    with torch.no_grad():
+        for trial in range(4):
+            model.kernel.lengthscale = ell * (1 + 1e-5 * trial)
+            ctx.barrier(); ctx.sync()
+            t0 = time.perf_counter()
+            X, info = column_sharded_solve(lambda B: model.khat_solve(xd, B, max_iter=iters, tol=0.0), rd)
+            ctx.sync()
+            dt = ctx.max_over_ranks(time.perf_counter() - t0)
+            if trial > 0:
+                best = min(best, dt)
+    blk = X[:, clo:chi].contiguous()
+    out["columns"] = {"ms_incl_build": round(best * 1e3, 2), "columns_on_rank0": [clo, chi], "max_columns_per_rank": -(-t // ctx.world),
+                      "final_rel_residual_max": float(info["residual"].max()),
+                      "exchange": {"kind": f"once per solve: all_gather of the solution's column blocks [n, {t}] (fp32); nothing inside "
+                                           f"the iteration; {transport}",
+                                   "bytes": n * t * 4, "us": timed_collective(ctx, lambda: all_gather_columns(blk, t))}}
+    plx.lattice_cache().clear()
+    return out
+
+
+CONFIG4_POINTS = int(os.environ.get("PLX_BENCH_CONFIG4_POINTS", "4000000"))      # (tests rehearse the multi-rank legs at a smaller size)
+
+
+def config4_grid_leg(ctx, steps, n=CONFIG4_POINTS, d=8, vd=11):
+    """BASELINE.json configs[3] at vd = 11 on the points x columns grid (distributed.SolveGrid): C column groups, each a
+    row-sharded operator over P = world / C ranks.  Every factorisation of the rank count is timed; the rate is 11-column
+    MVMs per second = 1 / (the slowest rank's time for its column block)."""
+    import torch
+    from simplex_gp_amd.distributed import ShardedLatticeMVM, SolveGrid
+    out = {"n_total": n, "vd": vd, "lengthscale": 1.0}
+    transport = "RCCL" if ctx.backend == "nccl" else ctx.backend
+    for C in [c for c in (1, 2, 4, 8, 16) if ctx.world % c == 0 and c <= min(ctx.world, vd)]:
+        grid = SolveGrid(C)
+        lo, hi = grid.rows(n)
+        clo, chi = grid.columns(vd)
+        x, v = synth(n, d, vd, lo=lo, hi=hi)
+        op = ShardedLatticeMVM.from_local_rows(x.contiguous().to(ctx.dev), RBF1, group=grid.point_group, n_total=n)
+        vb = v[:, clo:chi].contiguous().to(ctx.dev)
+        outb = torch.empty_like(vb)
+        for _ in range(3):
+            op.matmul(vb, outb)
+        wall = ctx.max_over_ranks(time_region(lambda i: op.matmul(vb, outb), steps, ctx.sync, ctx.barrier))
+        cols = chi - clo
+        out[f"C{C}xP{grid.P}"] = {"mvms_per_s": round(steps / wall, 1), "columns_per_rank_max": -(-vd // C), "rows_per_rank": hi - lo,
+                                  "m_vertices": op.m,
+                                  "exchange": {"kind": ("none (P = 1: every rank holds its column block of the whole operator)" if grid.P == 1 else
+                                                        f"per MVM: all_reduce(sum) of values[m, {op.lattice.values_stride(cols)}] inside the column "
+                                                        f"group's {grid.P} ranks; {transport}"),
+                                               "bytes": 0 if grid.P == 1 else op.exchange_bytes(cols)}}
+        op.lattice.close()
+        del op, vb, outb
+    best = max((k for k in out if k.startswith("C")), key=lambda k: out[k]["mvms_per_s"])
+    out["best"] = best
+    return out
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -659,12 +770,16 @@ def main():
             if args.scaling != "strong":
                 result["strong"] = sharded_leg(ctx, args.n, d, args.ell, [1], short)
             if args.scaling != "config4":
-                result["config4"] = sharded_leg(ctx, 4_000_000, d, 1.0, [1, 11], short)
+                result["config4"] = sharded_leg(ctx, CONFIG4_POINTS, d, 1.0, [1, 11], short)
             if args.scaling != "weak":
                 result["weak_1e6_per_gpu"] = sharded_leg(ctx, args.n * world, d, args.ell, [1], short)
             # weak scaling with 4e6 points per GPU: where the sharded splat / slice outweigh the replicated blur and the
             # all-reduce
-            result["weak_4e6_per_gpu"] = sharded_leg(ctx, 4_000_000 * world, d, 1.0, [1], short)
+            result["weak_4e6_per_gpu"] = sharded_leg(ctx, CONFIG4_POINTS * world, d, 1.0, [1], short)
+            # one batched solve split by rows or by columns, and config 4 at vd = 11 on the points x columns grid
+            result["config3_cg"] = config3_multi_leg(ctx, n=args.n)
+            cfg4 = result["config4"] if args.scaling != "config4" else result.setdefault("config4", {})
+            cfg4["grid_vd11"] = config4_grid_leg(ctx, short)
     else:
         # ---- warm / cold rates and per-stage times on the same lattice
         ref, v, out = job.ref, job.v, job.out

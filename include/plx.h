@@ -322,7 +322,8 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  *   range needs; 0 = a fixed 7 bits per coordinate), "readback_spin" (1 = counts come back through the mailbox; 0 = stream
  *   synchronisation), "vertex_order" (1: vertices numbered along the Morton curve of their blur-axis coordinates where
  *   that pays, 65536 <= m <= 0.9 n (d+1); 0: always by first touch; 2: always Morton -- vertex ids are internal, the
- *   PLX_ARRAY_* exports are in whichever numbering the build used), "insert_dedupe" (1), "insert_plane_fast" (1 = the
+ *   PLX_ARRAY_* exports are in whichever numbering the build used), "insert_dedupe" (2 = every key of a wave probes the table once: lanes with equal keys are grouped by hash ballots; 1 = runs of
+ *   equal NEIGHBOURING lanes probe once; 0 = every lane probes), "insert_plane_fast" (1 = the
  *   d+1 corner planes of a run of points are adjacent workgroups of the hashed insert / neighbour lookups; 0 =
  *   plane-major launch order), "nbr_symmetric" (1), "compact_nbr" (1 = when under a quarter of the neighbour slots exist;
  *   0 never, 2 always), "blur_vpt" (4; vertices per thread at vd = 1: 2 or 4, anything else selects the general kernel),
@@ -330,7 +331,11 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  *   for rows of 2..4 chunks; 0 = one), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1),
  *   "block_path" (1 = block tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable),
  *   "block_e" (0 = corners per thread of the block kernels chosen per lattice; 16 or 24: a block holds 256 * e corners),
- *   "block_dense_combine" (1), "scatter_store" (0), "unpermute_gather" (1).
+ *   "block_dense_combine" (1), "scatter_store" (0), "unpermute_gather" (1), "nbr_bitmap" (1 = neighbour lookups test a
+ *   slot-occupancy bitmap before the hash table when m >= 2^22; 0 never, 2 always), "splat_first" (1 = single-column splat by
+ *   first-touch stores + a short extras list when m >= 0.9 nnz; 0 never, 2 whenever representable, 3 = 2 with scattered
+ *   stores), "perm_rows" (1 = multi-column row permutations by 16-byte chunks / LDS-transposed whole-line stores; 0 = the
+ *   per-float forms).
  * The diagnostic ablations "splat_ablate" / "blur_ablate" / "block_ablate" exist only in libplx_diag.so (make diag).
  * Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);

@@ -26,27 +26,38 @@ static thread_local hipStream_t g_entry_stream = nullptr;
 struct EntryScope {
     hipStream_t prev;
     const Tune *prev_tune;
-    EntryScope(plx_lattice *L, void *s, bool new_build = false) : prev(g_entry_stream), prev_tune(tl_tune)
+    EntryScope(plx_lattice *L, void *s) : prev(g_entry_stream), prev_tune(tl_tune)
     {
         g_entry_stream = (hipStream_t)s;
-        if (L && new_build) L->tn = g_tune_defaults;
         tl_tune = L ? &L->tn : &g_tune_defaults;
     }
     ~EntryScope() { g_entry_stream = prev; tl_tune = prev_tune; }
 };
+
+int refuse_under_capture(hipStream_t stream, const char *what)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        set_error("%s has to be built or grown (an allocation, for tables also a host read-back) and the stream is being "
+                  "captured: call plx_prepare(lat, vd, stream) and run one MVM of this width before the capture", what);
+        return PLX_ERR_STATE;
+    }
+    return PLX_OK;
+}
 
 int ensure(DevBuf &b, size_t bytes)
 {
     if (bytes == 0) bytes = 4;
     if (b.cap >= bytes) return PLX_OK;
     const hipStream_t s = g_entry_stream;
+    // growing a buffer inside a capture would hand the lattice an address that belongs to the graph (a captured
+    // hipMallocAsync is a memory node: the memory exists while the graph runs, not afterwards)
+    PLX_TRY(refuse_under_capture(s, "a device buffer of this lattice"));
     if (b.p) {
-        // work queued on another stream may still read the old buffer: wait for that stream, not for the device
-        // (that stream may have been destroyed by its owner since: then wait for the device instead)
-        if (b.owner != s && hipStreamSynchronize(b.owner) != hipSuccess) {
-            (void)hipGetLastError();
-            PLX_HIP_TRY(hipDeviceSynchronize());
-        }
+        // work queued on another stream may still read the old buffer.  The stored handle is only COMPARED, never used:
+        // its owner may have destroyed that stream since (and the runtime may have recycled the handle), so the wait is
+        // for the device.  Growth across streams is rare -- a lattice normally lives on one stream.
+        if (b.owner != s) PLX_HIP_TRY(hipDeviceSynchronize());
         PLX_HIP_TRY(hipFreeAsync(b.p, s));
         b.p = nullptr;
         b.cap = 0;
@@ -151,7 +162,7 @@ void plx_destroy(plx_lattice *L)
 static int build_entry(plx_lattice *L, const float *d_ref, int64_t n, int d, const float *h_taps, int ntaps,
                        int shard_index, int n_shards, void *stream, bool single_use)
 {
-    EntryScope sc(L, stream, true);
+    EntryScope sc(L, stream);
     if (!L || !d_ref || !h_taps) { set_error("plx_build: NULL argument"); return PLX_ERR_INVALID; }
     if (n <= 0) { set_error("plx_build: n = %lld must be positive", (long long)n); return PLX_ERR_INVALID; }
     if (d < 1 || d > PLX_MAX_DIM) { set_error("plx_build: d = %d outside 1..%d", d, PLX_MAX_DIM); return PLX_ERR_DIM; }
@@ -167,6 +178,8 @@ static int build_entry(plx_lattice *L, const float *d_ref, int64_t n, int d, con
     }
     DeviceGuard g(L->device);
     if (!g.ok) { set_error("plx_build: cannot select device %d", L->device); return PLX_ERR_HIP; }
+    L->tn = g_tune_defaults;       // the snapshot of the process defaults this build (and every later call on it) runs under:
+                                   // taken only once the arguments are accepted -- a rejected call leaves a built lattice as it was
     L->built = false;
     L->local_ready = false;
     L->single_use = single_use;
@@ -191,7 +204,7 @@ int plx_build(plx_lattice *L, const float *d_ref, int64_t n, int d, const float 
 int plx_build_local(plx_lattice *L, const float *d_ref_local, int64_t n_local, int d, const float *h_taps, int ntaps,
                     void *stream)
 {
-    EntryScope sc(L, stream, true);
+    EntryScope sc(L, stream);
     if (!L || !d_ref_local || !h_taps) { set_error("plx_build_local: NULL argument"); return PLX_ERR_INVALID; }
     if (n_local <= 0) { set_error("plx_build_local: n_local = %lld must be positive", (long long)n_local); return PLX_ERR_INVALID; }
     if (d < 1 || d > PLX_MAX_DIM) { set_error("plx_build_local: d = %d outside 1..%d", d, PLX_MAX_DIM); return PLX_ERR_DIM; }
@@ -203,6 +216,7 @@ int plx_build_local(plx_lattice *L, const float *d_ref_local, int64_t n_local, i
     }
     DeviceGuard g(L->device);
     if (!g.ok) { set_error("plx_build_local: cannot select device %d", L->device); return PLX_ERR_HIP; }
+    L->tn = g_tune_defaults;
     L->built = false;
     L->local_ready = false;
     L->n = n_local; L->d = d; L->ntaps = ntaps; L->order = ntaps / 2;

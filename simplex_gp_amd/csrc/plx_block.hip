@@ -477,10 +477,57 @@ __global__ __launch_bounds__(kBlock) void unpermute_rows_kernel(const float4 *__
     }
 }
 
+// The same through LDS: a workgroup owns kBlock consecutive caller rows, i.e. ONE contiguous stretch of the output
+// (kBlock * vd floats, 16-byte aligned because kBlock is a multiple of 4).  Phase 1 gathers the rows' 16-byte chunks from
+// the lattice-ordered scratch into an LDS image of that stretch; phase 2 streams the image out as whole 16-byte vectors
+// (affine epilogue applied there, against the equally contiguous rows of src): every line of the output is written
+// whole, whatever vd -- the per-chunk form above writes a 44-byte row (vd = 11) as 11 four-byte stores.
+__global__ __launch_bounds__(kBlock) void unpermute_rows_lds_kernel(const float4 *__restrict__ tmp, const uint32_t *__restrict__ inv,
+                                                                    int n_own, int nch, int vd, float *__restrict__ out,
+                                                                    const float *__restrict__ affine, const float *__restrict__ src)
+{
+    extern __shared__ float img[];          // kBlock * vd floats
+    const int j0 = blockIdx.x * kBlock;
+    const int rows = min(kBlock, n_own - j0);
+    for (int item = threadIdx.x; item < rows * nch; item += kBlock) {
+        const int r = item / nch, ch = item - r * nch;
+        const float4 g = tmp[(size_t)inv[j0 + r] * nch + ch];
+        float *o = img + r * vd + 4 * ch;
+        const int left = vd - 4 * ch;
+        o[0] = g.x;
+        if (left > 1) o[1] = g.y;
+        if (left > 2) o[2] = g.z;
+        if (left > 3) o[3] = g.w;
+    }
+    __syncthreads();
+    const int total = rows * vd;
+    float *o = out + (size_t)j0 * vd;
+    const float *sp = src ? src + (size_t)j0 * vd : nullptr;
+    const float a = affine ? affine[0] : 1.f, b = affine ? affine[1] : 0.f;
+    const int quads = total >> 2;
+    for (int q = threadIdx.x; q < quads; q += kBlock) {
+        float4 v = *reinterpret_cast<const float4 *>(img + 4 * q);
+        if (affine) {
+            const float4 sv = *reinterpret_cast<const float4 *>(sp + 4 * q);
+            v.x = a * v.x + b * sv.x; v.y = a * v.y + b * sv.y; v.z = a * v.z + b * sv.z; v.w = a * v.w + b * sv.w;
+        }
+        *reinterpret_cast<float4 *>(o + 4 * q) = v;
+    }
+    for (int k = 4 * quads + threadIdx.x; k < total; k += kBlock) o[k] = affine ? a * img[k] + b * sp[k] : img[k];
+}
+
 int unpermute_rows(plx_lattice *L, const float *d_tmp, int vd, float *d_out, const float *d_affine, const float *d_src,
                    hipStream_t stream)
 {
     const int n_own = (int)(L->own_end - L->own_begin), nch = values_stride(vd) / 4;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_out) | (d_affine ? reinterpret_cast<uintptr_t>(d_src) : 0)) & 15) == 0;
+    if (g_perm_rows && vd <= 48 && aligned) {
+        unpermute_rows_lds_kernel<<<ceil_div(n_own, kBlock), kBlock, (size_t)kBlock * vd * 4, stream>>>(
+            reinterpret_cast<const float4 *>(d_tmp), L->inv_perm.as<uint32_t>(), n_own, nch, vd, d_out, d_affine, d_src);
+        L->kn_slice = "slice_vec_kernel+unpermute_rows_lds_kernel";
+        PLX_HIP_TRY(hipGetLastError());
+        return PLX_OK;
+    }
     unpermute_rows_kernel<<<ceil_div((int64_t)n_own * nch, kBlock), kBlock, 0, stream>>>(
         reinterpret_cast<const float4 *>(d_tmp), L->inv_perm.as<uint32_t>(), n_own, nch, vd, d_out, d_affine, d_src);
     PLX_HIP_TRY(hipGetLastError());
@@ -587,6 +634,7 @@ int ensure_inv_perm(plx_lattice *L, hipStream_t stream)
 int ensure_blocks(plx_lattice *L, hipStream_t stream)
 {
     if (L->blocks_ready) return PLX_OK;
+    PLX_TRY(refuse_under_capture(stream, "the block tables of this lattice"));
     return build_blocks(L, stream);
 }
 

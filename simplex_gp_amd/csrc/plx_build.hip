@@ -160,6 +160,15 @@ __global__ void mailbox_kernel(const int *__restrict__ src, int count, int *mail
 int read_back(plx_lattice *L, const int *d_src, int count, int *h_dst, hipStream_t stream)
 {
     if (count < 1 || count > 62) { set_error("read_back: %d values", count); return PLX_ERR_INVALID; }
+    // a capturing stream only records the mailbox kernel: the host would spin for a word that never arrives and then
+    // invalidate the capture by synchronising.  Everything that reads back (builds, the first MVM's tables) has to run
+    // before the capture starts: plx_prepare.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        set_error("this call has to build lattice tables (a host read-back) and the stream is being captured: call "
+                  "plx_prepare(lat, vd, stream) before the capture");
+        return PLX_ERR_STATE;
+    }
     const int seq = ++L->mail_seq;
     mailbox_kernel<<<1, 64, 0, stream>>>(d_src, count, L->h_mail, seq);
     PLX_HIP_TRY(hipGetLastError());
@@ -1275,6 +1284,7 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
 int ensure_csr(plx_lattice *L, hipStream_t stream)
 {
     if (L->csr_ready) return PLX_OK;
+    PLX_TRY(refuse_under_capture(stream, "the vertex-sorted corner table of this lattice"));
     const int n = (int)L->n, n_own = (int)(L->own_end - L->own_begin), m = (int)L->m, D1 = L->d + 1;
     PLX_TRY(ensure(L->csr_pt, (size_t)L->nnz * 4 + 64));   // slack: 16-byte loads at the tail
     PLX_TRY(ensure(L->csr_w, (size_t)L->nnz * 4 + 64));

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(kBlock) void splat_extras_kernel(const int *__restr
 int ensure_first(plx_lattice *L, hipStream_t stream)
 {
     if (L->first_ready) return PLX_OK;
+    PLX_TRY(refuse_under_capture(stream, "the first-touch splat list of this lattice"));
     L->first_ready = true;
     L->use_first = false;
     const int64_t nnz = L->nnz, m = L->m;

@@ -71,6 +71,7 @@ struct Tune {
     int unpermute_gather = 1;   // caller row order out of slice: 1 = lattice-ordered scratch + a gather pass, 0 = scatter from the slice kernel
     int block_e = 0;   // corners per thread of the block kernels: 0 = per lattice (choose_block_e), 16 or 24
     int block_dense_combine = 1;   // combine numbers the vertices by counting row ends when every vertex has block rows
+    int perm_rows = 1;   // multi-column row permutations: 1 = 16-byte chunks in, LDS-transposed whole-line stores out; 0 = the round-3 per-float / per-chunk kernels
     int nbr_bitmap = 1;   // neighbour lookups test a slot-occupancy bitmap before they touch the hash table: 0 never, 1 when m >= 2^22, 2 always
     int splat_first = 1;   // vd = 1 splat on lattices where almost every corner owns its vertex: first-touch corners store, the rest add (0 never, 1 when m >= 0.9 nnz, 2 whenever representable, 3 = 2 without the contiguous-range store)
     // diagnostic ablations: the members always exist (one layout for both libraries), but only libplx_diag.so knows
@@ -110,6 +111,7 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_block_e (plx::tl_tune->block_e)
 #define g_block_dense_combine (plx::tl_tune->block_dense_combine)
 #define g_nbr_bitmap (plx::tl_tune->nbr_bitmap)
+#define g_perm_rows (plx::tl_tune->perm_rows)
 #define g_splat_first (plx::tl_tune->splat_first)
 #define g_splat_ablate (plx::tl_tune->splat_ablate)
 #define g_blur_ablate (plx::tl_tune->blur_ablate)
@@ -239,6 +241,8 @@ namespace plx {
 
 int ensure(DevBuf &b, size_t bytes);
 void release(DevBuf &b);
+// PLX_ERR_STATE (with the plx_prepare hint) when `stream` is being captured into a graph: for the table builders
+int refuse_under_capture(hipStream_t stream, const char *what);
 
 // plx_build.hip
 int build_impl(plx_lattice *L, const float *d_ref, hipStream_t stream);

@@ -155,8 +155,14 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const K *__restrict__
             peers &= bit ? m : ~m;
         }
         const int rank = __popcll(peers & below);
-        const int old = run[d];                         // every peer reads the offset before the first of them advances it
-        if (live && rank == 0) run[d] = old + __popcll(peers);
+        // the running offsets pass between the lanes of this wave (and between its unrolled steps) through LDS: volatile
+        // accesses and a wave barrier on both sides, so that neither the compiler nor a future non-lockstep wave may
+        // serve a peer's read from a stale register or let the leader's store overtake it
+        volatile int *vrun = run;
+        const int old = vrun[d];                        // every peer reads the offset before the first of them advances it
+        __builtin_amdgcn_wave_barrier();
+        if (live && rank == 0) vrun[d] = old + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
         if (live) {
             keys_out[old + rank] = k[j];
             if (HAS_VALS) vals_out[old + rank] = v[j];

@@ -205,8 +205,8 @@ int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipS
         default: slice_vec_kernel<0><<<grid, kBlock, 0, stream>>>(evid, ew, perm, n, ob, n_own, L->d + 1, v4, nch, slice_vd, rden, slice_out, nt, g_xcd_remap, slice_affine, d_src, d_dot_partial); break;
         }
         if (two_step) {
-            PLX_TRY(unpermute_rows(L, slice_out, vd, d_out, d_affine, d_src, stream));
             L->kn_slice = "slice_vec_kernel+unpermute_rows_kernel";
+            PLX_TRY(unpermute_rows(L, slice_out, vd, d_out, d_affine, d_src, stream));      // (names the kernel it launched)
         }
     }
     tmark(L, stream);

@@ -80,21 +80,25 @@ static int selftest_typed(int64_t n, int end_bit, uint64_t seed, hipStream_t str
     void *tmp = nullptr;
     unsigned long long *bad = nullptr, h_bad = 0;
     const K mask = end_bit >= (int)sizeof(K) * 8 ? ~(K)0 : (((K)1 << end_bit) - 1);
-    PLX_HIP_TRY(hipMalloc(&ka, n * sizeof(K))); PLX_HIP_TRY(hipMalloc(&kb, n * sizeof(K)));
-    PLX_HIP_TRY(hipMalloc(&va, n * 4)); PLX_HIP_TRY(hipMalloc(&vb, n * 4));
-    PLX_HIP_TRY(hipMalloc(&tmp, radix_temp_bytes(n))); PLX_HIP_TRY(hipMalloc(&bad, 8));
-    PLX_HIP_TRY(hipMemsetAsync(bad, 0, 8, stream));
-    const int grid = (int)((n + 255) / 256);
-    selftest_fill_kernel<K><<<grid, 256, 0, stream>>>(ka, va, n, mask, seed);
-    int second = 0;
-    int rc = sizeof(K) == 8 ? radix_sort_pairs64(tmp, (uint64_t *)ka, (uint64_t *)kb, va, vb, n, end_bit, &second, stream)
-                            : radix_sort_pairs32(tmp, (uint32_t *)ka, (uint32_t *)kb, va, vb, n, end_bit, &second, stream);
-    if (rc == PLX_OK) {
+    // every exit path frees whatever was allocated (an early PLX_HIP_TRY return used to leak the earlier buffers)
+    auto body = [&]() -> int {
+        PLX_HIP_TRY(hipMalloc(&ka, n * sizeof(K))); PLX_HIP_TRY(hipMalloc(&kb, n * sizeof(K)));
+        PLX_HIP_TRY(hipMalloc(&va, n * 4)); PLX_HIP_TRY(hipMalloc(&vb, n * 4));
+        PLX_HIP_TRY(hipMalloc(&tmp, radix_temp_bytes(n))); PLX_HIP_TRY(hipMalloc(&bad, 8));
+        PLX_HIP_TRY(hipMemsetAsync(bad, 0, 8, stream));
+        const int grid = (int)((n + 255) / 256);
+        selftest_fill_kernel<K><<<grid, 256, 0, stream>>>(ka, va, n, mask, seed);
+        int second = 0;
+        PLX_TRY(sizeof(K) == 8 ? radix_sort_pairs64(tmp, (uint64_t *)ka, (uint64_t *)kb, va, vb, n, end_bit, &second, stream)
+                               : radix_sort_pairs32(tmp, (uint32_t *)ka, (uint32_t *)kb, va, vb, n, end_bit, &second, stream));
         selftest_check_kernel<K><<<grid, 256, 0, stream>>>(second ? kb : ka, second ? vb : va, n, mask, seed, bad);
         PLX_HIP_TRY(hipMemcpyAsync(&h_bad, bad, 8, hipMemcpyDeviceToHost, stream));
         PLX_HIP_TRY(hipStreamSynchronize(stream));
         *mismatches = (int64_t)h_bad;
-    }
+        return PLX_OK;
+    };
+    const int rc = body();
+    if (rc != PLX_OK) (void)hipStreamSynchronize(stream);
     (void)hipFree(ka); (void)hipFree(kb); (void)hipFree(va); (void)hipFree(vb); (void)hipFree(tmp); (void)hipFree(bad);
     return rc;
 }

@@ -19,6 +19,31 @@ __global__ __launch_bounds__(kBlock) void gather_in_kernel(const float *__restri
     ssrc[item] = (col < vd) ? src[(size_t)row * vd + col] : 0.f;
 }
 
+// the same, one thread per (row, 16-byte chunk): up to four 4-byte loads of the caller's row (its rows are vd floats: not
+// 16-byte aligned unless vd is a multiple of 4), one aligned 16-byte store -- a quarter of the store instructions and
+// of the index arithmetic of the per-float form (N = 4e6, vd = 11: 164 -> see DESIGN.md 4)
+__global__ __launch_bounds__(kBlock) void gather_in_rows_kernel(const float *__restrict__ src,
+                                                                const uint32_t *__restrict__ perm, int own_begin,
+                                                                int n_own, int vd, int nch, float4 *__restrict__ ssrc)
+{
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (item >= (int64_t)n_own * nch) return;
+    const int i = (int)(item / nch), ch = (int)(item - (int64_t)i * nch);
+    const int row = perm ? (int)perm[own_begin + i] - own_begin : i;
+    const float *sp = src + (size_t)row * vd + 4 * ch;
+    const int left = vd - 4 * ch;
+    float4 r;
+    if (left >= 4 && (vd & 3) == 0) {
+        r = *reinterpret_cast<const float4 *>(sp);
+    } else {
+        r.x = sp[0];
+        r.y = left > 1 ? sp[1] : 0.f;
+        r.z = left > 2 ? sp[2] : 0.f;
+        r.w = left > 3 ? sp[3] : 0.f;
+    }
+    ssrc[item] = r;
+}
+
 __global__ __launch_bounds__(kBlock) void gather_in_v1_kernel(const float *__restrict__ src,
                                                               const uint32_t *__restrict__ perm, int own_begin,
                                                               int n_own, float *__restrict__ ssrc)
@@ -578,8 +603,12 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
         ss = d_src;
     } else {
         gathered = true;
-        gather_in_kernel<<<ceil_div((int64_t)n_own * vdp, kBlock), kBlock, 0, stream>>>(
-            d_src, perm, (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());
+        if (g_perm_rows && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0)
+            gather_in_rows_kernel<<<ceil_div((int64_t)n_own * (vdp / 4), kBlock), kBlock, 0, stream>>>(
+                d_src, perm, (int)L->own_begin, n_own, vd, vdp / 4, reinterpret_cast<float4 *>(L->ssrc.as<float>()));
+        else
+            gather_in_kernel<<<ceil_div((int64_t)n_own * vdp, kBlock), kBlock, 0, stream>>>(
+                d_src, perm, (int)L->own_begin, n_own, vd, vdp, L->ssrc.as<float>());
     }
     const float *w = L->csr_w.as<float>();
     const int *vid = L->csr_vid.as<int>();   // sorted vertex id of every corner

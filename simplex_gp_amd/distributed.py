@@ -185,3 +185,147 @@ def sharded_solve(op, rhs_local, outputscale, noise, **cg_args):
     def mm(V):
         return op.matmul(V).mul_(s).add_(V, alpha=noise)
     return batched_cg(mm, rhs_local, reduce=lambda t: all_reduce_sum(t, op.group), **cg_args)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Column-sharded batched CG, and the points x columns grid.
+#
+# The columns of a batched solve -- [y | probe vectors] in the reference's training loop
+# (experiments/train_simplexgp.py:34-41: one mBCG call over 1 + num_trace_samples columns) -- never interact: batched CG
+# freezes every column on its own residual.  So the cheapest way to put several GPUs on ONE solve is to give each rank
+# the whole lattice (replicated build: every rank holds all positions) and a share of the COLUMNS.  There is then no
+# collective inside the iteration at all -- no vertex all-reduce, no dot-product all-reduce -- and one all-gather of the
+# solution (and the Lanczos coefficients) at the end.  Point sharding (ShardedLatticeMVM above) pays one all-reduce of
+# values[m, vd] per MVM and replicates the blur; it is the mode for operators too large for one GPU's time budget at
+# vd = 1.  The grid composes the two: C column groups x P point shards, the vertex all-reduce confined to the P ranks of
+# a column group.
+
+
+def column_bounds(t, parts, index):
+    """Contiguous near-equal column blocks (the first t % parts blocks get one extra column)."""
+    return shard_bounds(t, parts, index)
+
+
+def all_gather_columns(x_local, t, group=None):
+    """Every rank holds columns column_bounds(t, world, rank) of a [n, t] matrix (the same rows everywhere): returns the
+    whole matrix on every rank.  One collective; blocks are padded to the widest."""
+    if not _collective_needed(group):
+        return x_local
+    world = dist.get_world_size(group)
+    if world == 1 and not FORCE_COLLECTIVES:
+        return x_local
+    widest = -(-t // world)
+    n = x_local.shape[0]
+    pad = x_local.new_zeros(n, widest)
+    pad[:, : x_local.shape[1]] = x_local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad.contiguous(), group=group)
+    cols = []
+    for r, p in enumerate(parts):
+        lo, hi = column_bounds(t, world, r)
+        cols.append(p[:, : hi - lo])
+    return torch.cat(cols, 1)
+
+
+def column_sharded_solve(solve, rhs, group=None, gather=True):
+    """Batched solve with the right-hand-side columns split over the ranks of `group`.
+
+    solve(rhs_block) -> (x_block, info): the single-process solver over the WHOLE operator (every rank has built the
+    same lattice), e.g. `lambda B: model.khat_solve(x, B, K=K, max_iter=..., tol=...)`.  rhs: the full [n, t] matrix,
+    identical on every rank (only this rank's block of columns is read).  Returns (X, info): with gather=True the whole
+    [n, t] solution on every rank, info["residual"] / ["tridiag"] / ["rz0"] for all t columns and
+    info["iterations"] = the most any rank needed; with gather=False this rank's block and its own info (the caller
+    keeps working column-sharded, e.g. a training step that all-reduces hyper-parameter gradients only).
+    A rank with no column (world > t) solves nothing and contributes nothing."""
+    world = dist.get_world_size(group) if _collective_needed(group) else 1
+    rank = dist.get_rank(group) if _collective_needed(group) else 0
+    t = rhs.shape[1]
+    lo, hi = column_bounds(t, world, rank)
+    info = {"iterations": 0}
+    if hi > lo:
+        x_local, info = solve(rhs[:, lo:hi].contiguous())
+    else:
+        x_local = rhs.new_zeros(rhs.shape[0], 0)
+    info = dict(info, columns=(lo, hi), exchange_bytes=0)
+    if not gather or world == 1:
+        return x_local, info
+    X = all_gather_columns(x_local, t, group)
+    out = {"columns": (lo, hi), "exchange_bytes": int(rhs.shape[0]) * int(t) * rhs.element_size()}
+    it = torch.tensor([int(info["iterations"])], dtype=torch.int64, device=rhs.device)
+    dist.all_reduce(it, op=dist.ReduceOp.MAX, group=group)
+    out["iterations"] = int(it.item())
+    for key in ("residual", "rz0"):
+        if any_has(info, key, group, rhs.device):
+            v = info.get(key)
+            v = v.reshape(1, -1).to(rhs.dtype) if v is not None else rhs.new_zeros(1, 0)
+            out[key] = all_gather_columns(v, t, group).reshape(-1)
+    if any_has(info, "tridiag", group, rhs.device):
+        # [t_local, k, k] with k = this rank's iteration count: pad to the common k (identity rows, as
+        # solvers._tridiag_from_cg freezes converged columns), gather along the column axis
+        k = out["iterations"]
+        T = info.get("tridiag")
+        if T is None:
+            T = torch.zeros(0, k, k, dtype=torch.float64, device=rhs.device)
+        if T.shape[-1] < k:
+            big = torch.eye(k, dtype=T.dtype, device=T.device).repeat(T.shape[0], 1, 1)
+            big[:, : T.shape[-1], : T.shape[-1]] = T
+            T = big
+        flat = all_gather_columns(T.reshape(T.shape[0], k * k).t().contiguous(), t, group)     # [k*k, t]
+        out["tridiag"] = flat.t().reshape(t, k, k)
+    return X, out
+
+
+def any_has(info, key, group, device):
+    """True when any rank's info carries `key` (a rank without columns has an empty info)."""
+    flag = torch.tensor([1 if info.get(key) is not None else 0], dtype=torch.int64, device=device)
+    if _collective_needed(group):
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return bool(flag.item())
+
+
+class SolveGrid:
+    """C column groups x P point shards over world = C * P ranks: rank = c * P + p.
+
+    point_group   the P ranks that share a column block (same c): they run ONE row-sharded operator together
+                  (ShardedLatticeMVM over this group: vertex all-reduce and CG dot products stay inside it)
+    column_group  the C ranks that hold the same rows (same p): the final all-gather of columns runs over it
+    P = 1 is pure column sharding, C = 1 pure point sharding."""
+
+    def __init__(self, column_groups, world=None, rank=None):
+        self.world = dist.get_world_size() if world is None else world
+        self.rank = dist.get_rank() if rank is None else rank
+        if column_groups < 1 or self.world % column_groups:
+            raise ValueError(f"{column_groups} column groups do not divide {self.world} ranks")
+        self.C, self.P = column_groups, self.world // column_groups
+        self.c, self.p = self.rank // self.P, self.rank % self.P
+        self.point_group = self.column_group = None
+        if dist.is_available() and dist.is_initialized() and self.world > 1:
+            # every rank creates every group, in the same order (torch.distributed's rule)
+            for c in range(self.C):
+                g = dist.new_group([c * self.P + p for p in range(self.P)])
+                if c == self.c:
+                    self.point_group = g
+            for p in range(self.P):
+                g = dist.new_group([c * self.P + p for c in range(self.C)])
+                if p == self.p:
+                    self.column_group = g
+
+    def columns(self, t):
+        return column_bounds(t, self.C, self.c)
+
+    def rows(self, n):
+        return shard_bounds(n, self.P, self.p)
+
+    def solve(self, op, rhs_rows, outputscale, noise, gather=True, **cg_args):
+        """(s K + sigma^2 I)^-1 rhs on the grid.  op: a ShardedLatticeMVM over self.point_group; rhs_rows: this rank's
+        rows of ALL t columns.  Returns this rank's rows of the solution -- all t columns (gather=True: one all-gather over
+        the column group) or its own column block."""
+        t = rhs_rows.shape[1]
+        lo, hi = self.columns(t)
+        if hi > lo:
+            x_local, info = sharded_solve(op, rhs_rows[:, lo:hi].contiguous(), outputscale, noise, **cg_args)
+        else:
+            x_local, info = rhs_rows.new_zeros(rhs_rows.shape[0], 0), {"iterations": 0}
+        if not gather or self.C == 1:
+            return x_local, info
+        return all_gather_columns(x_local, t, self.column_group), info

@@ -195,3 +195,139 @@ def test_all_gather_rows_uneven(tmp_path):
     """The key exchange of the sharded lattice build: rank blocks of different length, rank order kept."""
     mp.spawn(_gather_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
     assert (tmp_path / "ok.npy").exists()
+
+
+# ---- column-sharded batched CG and the points x columns grid (distributed.column_sharded_solve, SolveGrid) ---------
+
+def _oracle_khat(x, s, noise):
+    from oracle import oracle
+
+    def mm(V):
+        oracle.set_exact_mode(False)
+        try:
+            kv = oracle.filter(np.ascontiguousarray(V.numpy()), x.numpy(), RBF1)
+        finally:
+            oracle.set_exact_mode(True)
+        return s * torch.from_numpy(kv) + noise * V
+    return mm
+
+
+def _column_worker(rank, world, port, n, d, t, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from simplex_gp_amd.distributed import column_sharded_solve, column_bounds
+    from simplex_gp_amd.solvers import batched_cg
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(21)
+        x = torch.randn(n, d, generator=g)
+        rhs = torch.randn(n, t, generator=g)
+        mm = _oracle_khat(x, 0.7, 0.3)                      # every rank holds the whole operator (replicated build)
+        solve = lambda B: batched_cg(mm, B, max_iter=40, tol=1e-5, want_tridiag=True, check_every=1)     # noqa: E731
+        X, info = column_sharded_solve(solve, rhs)
+        lo, hi = column_bounds(t, world, rank)
+        assert info["columns"] == (lo, hi) and X.shape == (n, t)
+        assert info["residual"].shape == (t,) and info["tridiag"].shape[0] == t
+        Xl, il = column_sharded_solve(solve, rhs, gather=False)
+        assert Xl.shape == (n, hi - lo) and torch.equal(Xl, X[:, lo:hi]) and il["exchange_bytes"] == 0
+        if rank == 0:
+            np.save(os.path.join(outdir, "X.npy"), X.numpy())
+            np.save(os.path.join(outdir, "res.npy"), info["residual"].numpy())
+            np.save(os.path.join(outdir, "T.npy"), info["tridiag"].numpy())
+            np.save(os.path.join(outdir, "it.npy"), np.array(info["iterations"]))
+            np.save(os.path.join(outdir, "bytes.npy"), np.array(info["exchange_bytes"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,t", [(2, 5), (3, 11), (3, 2)])
+def test_column_sharded_solve_equals_single_process(tmp_path, world, t):
+    """Columns of a batched CG solve split over the ranks (every rank holds the whole lattice): no collective inside the
+    iteration, one all-gather at the end.  Every column block of the gathered solution, its residuals and its Lanczos
+    tridiagonals are BIT-IDENTICAL to that block solved alone in one process (what a rank does; the plumbing adds
+    nothing), also when a rank has no column at all (3 ranks, 2 columns); against ONE batched solve of all t columns the
+    columns agree to the rounding of the dot products (torch picks the reduction order of `(a * b).sum(0)` by the
+    tensor's width, and the HIP kernels are picked by vd: bitwise identity across column splits is not a property of
+    either path -- independence of the columns is)."""
+    from simplex_gp_amd.solvers import batched_cg
+    from simplex_gp_amd.distributed import column_bounds
+    n, d = 400, 2
+    mp.spawn(_column_worker, args=(world, _free_port(), n, d, t, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, d, generator=g)
+    rhs = torch.randn(n, t, generator=g)
+    mm = _oracle_khat(x, 0.7, 0.3)
+    got, res, T = np.load(tmp_path / "X.npy"), np.load(tmp_path / "res.npy"), np.load(tmp_path / "T.npy")
+    k = int(np.load(tmp_path / "it.npy"))
+    its = []
+    for r in range(world):
+        lo, hi = column_bounds(t, world, r)
+        if hi == lo:
+            continue
+        want, info = batched_cg(mm, rhs[:, lo:hi].contiguous(), max_iter=40, tol=1e-5, want_tridiag=True, check_every=1)
+        its.append(info["iterations"])
+        assert np.array_equal(got[:, lo:hi], want.numpy())
+        assert np.array_equal(res[lo:hi], info["residual"].numpy())
+        kk = info["iterations"]
+        assert np.array_equal(T[lo:hi, :kk, :kk], info["tridiag"].numpy())
+        if kk < k:                                            # padded like a converged column: identity
+            assert np.array_equal(T[lo:hi, kk:, kk:], np.broadcast_to(np.eye(k - kk), (hi - lo, k - kk, k - kk)))
+    assert k == max(its)
+    assert int(np.load(tmp_path / "bytes.npy")) == n * t * 4
+    whole, info = batched_cg(mm, rhs, max_iter=40, tol=1e-5, want_tridiag=True, check_every=1)
+    assert np.linalg.norm(got - whole.numpy()) / np.linalg.norm(whole.numpy()) <= 1e-5
+    assert float(res.max()) <= 1e-3                           # 40 iterations at most
+
+
+def _grid_worker(rank, world, port, n, d, t, C, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tests.oracle_lattice_adapter import OracleLattice
+    from simplex_gp_amd.distributed import SolveGrid
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(22)
+        x = torch.randn(n, d, generator=g)
+        rhs = torch.randn(n, t, generator=g)
+        grid = SolveGrid(C)
+        assert (grid.C, grid.P) == (C, world // C) and grid.rank == grid.c * grid.P + grid.p
+        lo, hi = grid.rows(n)
+        op = ShardedLatticeMVM.from_local_rows(x[lo:hi].contiguous(), RBF1, group=grid.point_group, lattice=OracleLattice(),
+                                               n_total=n)
+        assert (op.lo, op.hi) == (lo, hi)
+        X_rows, info = grid.solve(op, rhs[lo:hi].contiguous(), 0.7, 0.3, max_iter=200, tol=1e-6)
+        assert X_rows.shape == (hi - lo, t)
+        np.save(os.path.join(outdir, f"X{rank}.npy"), X_rows.numpy())
+        np.save(os.path.join(outdir, f"rows{rank}.npy"), np.array([lo, hi]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,C", [(4, 2), (3, 3), (2, 1)])
+def test_solve_grid_points_by_columns(tmp_path, world, C):
+    """C column groups x P point shards (4 ranks as 2 x 2; 3 ranks as pure column sharding; 2 ranks as pure point
+    sharding): every rank ends up with its rows of ALL columns, and the assembled solution satisfies the single-process
+    operator equation."""
+    from oracle import oracle
+    n, d, t = 601, 3, 5
+    mp.spawn(_grid_worker, args=(world, _free_port(), n, d, t, C, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(n, d, generator=g)
+    rhs = torch.randn(n, t, generator=g)
+    P = world // C
+    sol = np.zeros((n, t), np.float32)
+    for rank in range(world):
+        lo, hi = np.load(tmp_path / f"rows{rank}.npy")
+        block = np.load(tmp_path / f"X{rank}.npy")
+        if rank < P:
+            sol[lo:hi] = block
+        else:                                   # the other column groups hold the same rows: identical copies
+            assert np.array_equal(sol[lo:hi], block)
+    oracle.set_exact_mode(False)
+    try:
+        back = 0.7 * oracle.filter(sol, x.numpy(), RBF1) + 0.3 * sol
+    finally:
+        oracle.set_exact_mode(True)
+    assert np.linalg.norm(back - rhs.numpy()) / np.linalg.norm(rhs.numpy()) <= 1e-4

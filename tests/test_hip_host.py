@@ -418,6 +418,47 @@ def test_mvm_is_graph_capturable(plx):
         torch.cuda.synchronize()
         assert torch.equal(out, want2), vd
     lat.close()
+    # a capture that would have to BUILD tables (allocation + a host read-back the capture would only record) is refused
+    # with the remedy in the message, nothing is launched, and the lattice works eagerly afterwards
+    from simplex_gp_amd._native import PlxError
+    lat2 = plx.Lattice().build(x, taps)
+    v = torch.from_numpy(rng.standard_normal((n, 1)).astype(np.float32)).cuda()
+    out = torch.empty_like(v)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(PlxError, match="plx_prepare"):
+        with torch.cuda.graph(graph):
+            lat2.apply(v, out)
+    torch.cuda.synchronize()
+    want = lat2.apply(v).clone()
+    lat3 = plx.Lattice().build(x, taps)
+    assert torch.equal(lat3.apply(v), want)
+    lat2.close()
+    lat3.close()
+
+
+def test_rejected_build_leaves_a_built_lattice_alone(plx):
+    """A build call that fails validation must not touch the lattice: it stays built, with the switch snapshot it was built
+    under (plx.h: 'a plx_tune call changes nothing for lattices that are already built')."""
+    from simplex_gp_amd import _native as nv
+    from simplex_gp_amd._native import PlxError
+    rng = np.random.default_rng(5)
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    x = torch.from_numpy(rng.standard_normal((20000, 4)).astype(np.float32)).cuda()
+    v = torch.from_numpy(rng.standard_normal((20000, 1)).astype(np.float32)).cuda()
+    lat = plx.Lattice().build(x, taps)
+    want = lat.apply(v).clone()
+    kern = lat.stage_kernels()
+    try:
+        nv.check(nv.lib().plx_tune(b"block_path", 0), "plx_tune")          # new process default: never the block tables
+        with pytest.raises((PlxError, ValueError)):
+            lat.build(x, np.array([0.5, 0.5], np.float32))                  # even tap count: rejected
+        with pytest.raises(PlxError):
+            lat.build(x[:0], taps)                                          # n = 0: rejected inside the library
+        assert lat.m > 0 and torch.equal(lat.apply(v), want) and lat.stage_kernels() == kern
+    finally:
+        nv.check(nv.lib().plx_tune(b"block_path", 1), "plx_tune")
+    lat.close()
 
 
 def test_two_host_threads_two_lattices(plx):

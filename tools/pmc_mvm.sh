@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: wave-state / L1 / L2 / TLB counters of the kernels of tools/prof_mvm.py, one counter group per pass.
-#   EXTRA="--n 4000000 --vd 11 --tune block_multi=2" FILTER="multi|slice_vec" tools/pmc_mvm.sh
+#   EXTRA="--n 4000000 --vd 11 --tune perm_rows=0" FILTER="gather_in|slice_vec" tools/pmc_mvm.sh
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 i=0
