@@ -529,6 +529,46 @@ def config5_leg(ctx, n=10623, d=18):
                          "5,976 held-out rows"}}
 
 
+# The only MVM timings the reference publishes (notebooks/viz_compute.ipynb:102-106: `simplex_mvm_t`, seconds per MVM of its
+# CUDA path on the UCI sets; GPU not stated).  The data sets are not redistributable: the shapes are run on synthetic
+# standardised clouds.
+PUBLISHED_SHAPES = [("houseelectric", 2_049_280, 11, 1.756), ("precipitation", 628_474, 3, 0.082), ("keggdirected", 48_827, 20, 0.134),
+                    ("elevators", 16_599, 17, 0.083), ("protein", 45_730, 9, 0.034)]
+
+
+def published_shapes_leg(ctx, ell=0.6931):
+    """One K.v MVM (vd = 1, RBF order 1, lengthscale softplus(0) = GPyTorch's initial value) at the (n, d) of the reference's
+    published timing table, on x ~ N(0, I) seed 1234: warm (lattice built) and cold (plx_filter: build + apply, what the
+    reference's filter() does on every call) seconds, beside the published CUDA seconds -- different data, unstated GPU:
+    an order-of-magnitude placement, not a like-for-like ratio."""
+    import torch
+    import simplex_gp_amd as plx
+    rows = []
+    for name, n, d, pub in PUBLISHED_SHAPES:
+        g = torch.Generator().manual_seed(1234)
+        ref = (torch.randn(n, d, generator=g) / ell).contiguous().to(ctx.dev)
+        v = torch.randn(n, 1, generator=g).to(ctx.dev)
+        out = torch.empty_like(v)
+        lat = plx.Lattice(ctx.dev)
+        lat.build(ref, RBF1)
+        lat.prepare(1)
+        for _ in range(3):
+            lat.apply(v, out)
+        reps = 20
+        warm = time_region(lambda i: lat.apply(v, out), reps, ctx.sync, lambda: None) / reps
+        lat.filter_once(v, ref, RBF1, out)
+        ncold = 5
+        cold = time_region(lambda i: lat.filter_once(v, ref, RBF1, out), ncold, ctx.sync, lambda: None) / ncold
+        rows.append({"shape_of": name, "n": n, "d": d, "m_vertices": lat.m, "warm_mvm_s": round(warm, 7), "cold_mvm_s": round(cold, 6),
+                     "published_cuda_mvm_s": pub, "published_over_cold": round(pub / cold, 1)})
+        lat.close()
+        del ref, v, out
+    return {"published_shapes": rows,
+            "published_shapes_note": "reference: notebooks/viz_compute.ipynb:102-106 (its CUDA path, one filter() = build + apply "
+                                     "per MVM, real UCI data, GPU not stated); here: synthetic N(0, I) clouds of the same (n, d), "
+                                     "lengthscale 0.6931, vd = 1 -- different data, so a placement, not a like-for-like ratio"}
+
+
 def exchange_record(job, vd, stage_us):
     """The one exchange step of a sharded MVM: what moves, how many bytes per rank, and its device time."""
     transport = "RCCL" if job.ctx.backend == "nccl" else job.ctx.backend
@@ -832,6 +872,8 @@ def main():
             # ---- fine regime: same points, lengthscale 0.25 -> m ~ 8.9e6, blur streams from HBM
             ref_f = (x_cpu / 0.25).contiguous().to(ctx.dev)
             lat_f = plx.Lattice(ctx.dev)
+            lat_f.build(ref_f, RBF1)                   # (sizes the object's buffers: a first build pays the allocations)
+            lat_f.prepare(vd)
             lat_f.set_timing(True)
             lat_f.build(ref_f, RBF1)
             fine_build = lat_f.build_times_ms()
@@ -872,6 +914,7 @@ def main():
             result.update(config3_leg(ctx))
             result["config4"] = sharded_leg(ctx, 4_000_000, d, 1.0, [1, 11], 20)
             result.update(config5_leg(ctx))
+            result.update(published_shapes_leg(ctx))
 
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(x_cpu[:n_local], v_cpu[:n_local], args.ell)

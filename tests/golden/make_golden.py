@@ -80,6 +80,47 @@ def synth(n, d, vd, ell, seed=1234, dist="randn"):
     return v, (x / ell).contiguous()
 
 
+def large_record(large, name, n, d, vd, ell, v, r, taps_t, ref, dbg):
+    out = ref.filter(v, r, taps_t).numpy()
+    m = capture_m(dbg, v, r, taps_t)
+    stride = max(1, n // 4096)
+    large[f"{name}/shape"] = np.array([n, d, vd], np.int64)
+    large[f"{name}/ell"] = np.float64(ell)
+    large[f"{name}/seed"] = np.int64(1234)
+    large[f"{name}/taps"] = taps_t.numpy()
+    large[f"{name}/m"] = np.int64(m)
+    large[f"{name}/ref_head"] = r[:8].numpy()
+    large[f"{name}/src_head"] = v[:8].numpy()
+    large[f"{name}/out_head"] = out[:512]
+    large[f"{name}/out_strided"] = out[::stride]
+    large[f"{name}/stride"] = np.int64(stride)
+    large[f"{name}/out_l2"] = np.float64(np.linalg.norm(out.astype(np.float64)))
+    large[f"{name}/out_sum"] = np.float64(out.astype(np.float64).sum())
+    large[f"{name}/out_abs_sum"] = np.float64(np.abs(out.astype(np.float64)).sum())
+    print(name, "m =", m)
+
+
+def config_probes():
+    """`make_golden.py --config-probes` (round 4): reference probes for BASELINE.json configs[3] and configs[4], ADDED to the
+    existing filter_large.npz (the other records are carried over byte for byte):
+      config5_n10623_d18_matern3   x, v = synth(10623, 18, 1, 1.0); Matern-1.5 order-3 taps (the stand-in for elevators)
+      config4_n4e6_d8_ell1.0       bench.synth(4_000_000, 8, 11): rows in blocks of 1e6, block b from seed 1234 + b
+                                   (what every rank of the sharded job generates); column 0 of v"""
+    build_ref.build()
+    ref = build_ref.load("cpu_lattice_ref")
+    dbg = build_ref.load("cpu_lattice_ref_dbg")
+    path = os.path.join(HERE, "filter_large.npz")
+    old = np.load(path)
+    large = {k: old[k] for k in old.files}
+    v, r = synth(10623, 18, 1, 1.0)
+    large_record(large, "config5_n10623_d18_matern3", 10623, 18, 1, 1.0, v, r, torch.tensor(MAT3, dtype=torch.float32), ref, dbg)
+    import bench
+    x, v11 = bench.synth(4_000_000, 8, 11)
+    large_record(large, "config4_n4e6_d8_ell1.0", 4_000_000, 8, 1, 1.0, v11[:, :1].contiguous(), x.contiguous(),
+                 torch.tensor(RBF1, dtype=torch.float32), ref, dbg)
+    np.savez_compressed(path, **large)
+
+
 def main():
     build_ref.build()
     ref = build_ref.load("cpu_lattice_ref")
@@ -297,6 +338,10 @@ def dataset_fixture():
     np.savez_compressed(os.path.join(HERE, "dataset_split.npz"), **ds)
     print("dataset_split.npz:", sorted(ds))
 
+
+if __name__ == "__main__" and "--config-probes" in sys.argv:
+    config_probes()
+    sys.exit(0)
 
 if __name__ == "__main__":
     # `python tests/golden/make_golden.py dataset` regenerates dataset_split.npz only

@@ -89,7 +89,7 @@ def test_variance_and_scale():
     np.testing.assert_allclose(sf, want, rtol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["n1e5_d4_ell1.0", "n1e5_d4_ell0.25", "n1e5_d4_vd11_ell1.0"])
+@pytest.mark.parametrize("name", ["n1e5_d4_ell1.0", "n1e5_d4_ell0.25", "n1e5_d4_vd11_ell1.0", "config5_n10623_d18_matern3"])
 def test_large_probes(golden_dir, name):
     """BASELINE.json config-2 shape: inputs re-generated from the seed, output
     compared with the stored probes of the reference output."""

@@ -45,5 +45,6 @@ for pre in args.pre:
                "peak_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}
         if prof is not None:
             row["phases_ms"] = {k: round(v, 2) for k, v in prof.items()}
+        row["lattices_m"] = [lat.m for lat, _ in plx.lattice_cache()._entries.values()][-2:]      # forward taps, derivative taps
         print(json.dumps(row), flush=True)
     plx.lattice_cache().clear()
