@@ -60,6 +60,8 @@ def table(rows, m_fwd, m_bwd, steps, top=34):
 
 r0, rows0 = last_row(log0)
 r100, rows100 = last_row(log100)
+prof0 = [x for x in rows0 if "phases_ms" not in x]          # the steps that ran under the profiler (the phase runs are appended to the log)
+prof100 = [x for x in rows100 if "phases_ms" not in x]
 md = f"""# rocprofv3 of the training step ({tag})
 
 `rocprofv3 --kernel-trace --stats -- python3 tools/train_step_r4.py --pre P --steps S --no-profile`: N = 1e6, d = 8, RBFLattice
@@ -70,22 +72,22 @@ taps, py:113-123, on its own lattice) + Adam.  Adam moves the lengthscale by 10 
 different lattices; the table is the mean over the run's steps.  Fractions: SURVEY 8(d) algorithmic bytes / mean launch
 time / 8 TB/s.
 
-## pre_size 0 (steps: {len(rows0)}; last step {r0['step_ms']} ms wall; lattices of the last step m = {r0.get('lattices_m')})
+## pre_size 0 ({len(prof0)} steps under the profiler; lattices of the last step m = {r0.get('lattices_m')}: forward taps, derivative taps)
 
 ```
-{table(stats(dir0), *(r0.get('lattices_m') or [0, 0])[:2], len(rows0))}
+{table(stats(dir0), *(r0.get('lattices_m') or [0, 0])[:2], len(prof0))}
 ```
 
-## pre_size 100 (steps: {len(rows100)}; last step {r100['step_ms']} ms wall; m = {r100.get('lattices_m')})
+## pre_size 100 ({len(prof100)} steps under the profiler; m = {r100.get('lattices_m')})
 
 ```
-{table(stats(dir100), *(r100.get('lattices_m') or [0, 0])[:2], len(rows100))}
+{table(stats(dir100), *(r100.get('lattices_m') or [0, 0])[:2], len(prof100))}
 ```
 
 Wall time per step (no profiler; phases from `--steps 3` with the phase synchronisation on):
 
 ```
-{chr(10).join(json.dumps(x) for x in rows0[-2:] + rows100[-2:])}
+{chr(10).join(json.dumps(x) for x in [y for y in rows0 if 'phases_ms' in y][-2:] + [y for y in rows100 if 'phases_ms' in y][-2:])}
 ```
 """
 open(os.path.join(root, "profiles", f"{tag}_train.md"), "w").write(md)
