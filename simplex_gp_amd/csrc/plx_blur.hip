@@ -510,10 +510,16 @@ __global__ __launch_bounds__(kBlock) void blur_axis_multi_kernel(const float4 *_
     float4 c[IPT], g[IPT][2 * ORDER];
 #pragma unroll
     for (int k = 0; k < IPT; ++k) c[k] = old[live[k] ? item[k] : 0u];
+    // a gather no lane of the wave needs is not issued at all (wave-uniform branch): on sparse lattices -- the elevators
+    // stand-in has every corner on a vertex of its own -- almost every neighbour is absent, and re-reading the centre in its
+    // place (what keeps the dense case branch-free) made the pass six L1 reads per element instead of one
 #pragma unroll
     for (int k = 0; k < IPT; ++k)
 #pragma unroll
-        for (int s = 0; s < 2 * ORDER; ++s) g[k][s] = old[src[k][s]];
+        for (int s = 0; s < 2 * ORDER; ++s) {
+            g[k][s] = f4_zero();
+            if (__ballot(have[k][s]) != 0ull) g[k][s] = old[src[k][s]];
+        }
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         float4 acc = f4_zero();

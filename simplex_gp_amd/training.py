@@ -17,34 +17,56 @@ import torch
 from .solvers import LatticeGP, marginal_log_likelihood
 
 
-def lanczos(matmul, v0, steps):
+def lanczos(matmul, v0, steps, check_every=8):
     """`steps` Lanczos iterations with full re-orthogonalisation.
-    Returns Q [n, t] (orthonormal) and the tridiagonal T [t, t] with Q^T A Q = T."""
-    q = v0 / v0.norm()
-    Q, alphas, betas = [q], [], []
-    beta, q_prev = None, None
+    Returns Q [n, t] (orthonormal) and the tridiagonal T [t, t] with Q^T A Q = T.
+
+    The basis lives in one preallocated [steps, n] buffer (stacking the vectors anew in every step copied O(steps^2 n) bytes)
+    and the breakdown test -- beta below 1e-6 |alpha_0|: the Krylov space is exhausted -- reads the device every
+    `check_every` steps instead of twice per step (a step is one MVM of ~80 us at the elevators size: the two host
+    synchronisations cost more than the step); vectors produced after a breakdown are discarded when it is found."""
+    n = v0.shape[0]
+    Qb = torch.zeros(steps, n, dtype=v0.dtype, device=v0.device)
+    alphas = torch.zeros(steps, dtype=v0.dtype, device=v0.device)
+    betas = torch.zeros(steps, dtype=v0.dtype, device=v0.device)
+    Qb[0] = v0 / v0.norm()
+    t = steps
+
+    def first_breakdown(upto):
+        small = betas[:upto] < 1e-6 * alphas[0].abs()
+        return int(torch.nonzero(small)[0]) + 1 if bool(small.any()) else None
+
     for i in range(steps):
-        w = matmul(Q[-1].unsqueeze(-1)).squeeze(-1)
-        if q_prev is not None:
-            w = w - beta * q_prev
-        alpha = torch.dot(w, Q[-1])
-        w = w - alpha * Q[-1]
-        Qm = torch.stack(Q, 1)
-        w = w - Qm @ (Qm.t() @ w)                 # full re-orthogonalisation
-        alphas.append(alpha)
-        beta = w.norm()
-        if i + 1 == steps or float(beta) < 1e-6 * float(alphas[0].abs()):
+        w = matmul(Qb[i].unsqueeze(-1)).squeeze(-1)
+        if i > 0:
+            w = w - betas[i - 1] * Qb[i - 1]
+        alpha = torch.dot(w, Qb[i])
+        w = w - alpha * Qb[i]
+        Qi = Qb[:i + 1]
+        w = w - Qi.t() @ (Qi @ w)                 # full re-orthogonalisation
+        alphas[i] = alpha
+        if i + 1 == steps:
             break
-        betas.append(beta)
-        q_prev = Q[-1]
-        Q.append(w / beta)
-    t = len(alphas)
-    T = torch.zeros(t, t, dtype=v0.dtype, device=v0.device)
-    for i in range(t):
-        T[i, i] = alphas[i]
-        if i + 1 < t:
-            T[i, i + 1] = T[i + 1, i] = betas[i]
-    return torch.stack(Q[:t], 1), T
+        beta = w.norm()
+        betas[i] = beta
+        Qb[i + 1] = w / beta.clamp_min(1e-30)
+        if (i + 1) % check_every == 0:
+            cut = first_breakdown(i + 1)
+            if cut is not None:
+                t = cut
+                break
+    else:
+        pass
+    if t == steps and steps > 1:
+        cut = first_breakdown(steps - 1)
+        if cut is not None:
+            t = cut
+    T = torch.diag(alphas[:t])
+    if t > 1:
+        idx = torch.arange(t - 1, device=v0.device)
+        T[idx, idx + 1] = betas[:t - 1]
+        T[idx + 1, idx] = betas[:t - 1]
+    return Qb[:t].t(), T
 
 
 @torch.no_grad()
