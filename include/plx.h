@@ -286,10 +286,12 @@ int plx_pcg_step_direction(float *d_p, const float *d_z, const float *d_rz_new, 
  *   plx_pchol_factor_batch  d_rows [n][t] = K d_rhs.  Panel update against the m_done finished columns
  *                           (d_scale[0] d_rows - L L[cand]^T, one pass over them), then the nb in-batch steps in pivot
  *                           order: column m_done + b = row b / sqrt(pivot) (zero if the pivot is <= tol_abs), residual
- *                           diagonal updated, and the argmax of the updated diagonal compared ON THE DEVICE with the
- *                           next speculated pivot -- the first mismatch ends the batch.  *d_accepted (device int32) =
- *                           columns written (>= 1: the first candidate is the argmax by construction); the caller reads
- *                           it back once per batch and carries on from m_done + accepted.
+ *                           diagonal updated, and the argmax of the updated diagonal looked up ON THE DEVICE among the
+ *                           batch's unused candidates (the sequential algorithm may take them in another order than
+ *                           their values at the start of the batch suggest) -- the batch ends when the argmax is an entry
+ *                           whose kernel row is not in it.  *d_accepted (device int32) = columns written (>= 1: the first
+ *                           candidate is the argmax by construction); the caller reads it back once per batch and carries
+ *                           on from m_done + accepted.
  * d_work: plx_pchol_work_bytes(ld, kp) bytes, the same buffer for the three calls of a batch.
  */
 int64_t plx_pchol_work_bytes(int64_t ld, int kp);

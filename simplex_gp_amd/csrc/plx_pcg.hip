@@ -417,7 +417,12 @@ __global__ __launch_bounds__(kBlock) void pchol_top_partial_kernel(const float *
 }
 
 // Batch state (device): stf[0] = residual diagonal at the pivot of the next in-batch step, stf[1 + b'] = L[pivot][m + b']
-// of the in-batch columns already written; sti[0] = stop (a speculated pivot was not the argmax), sti[1] = accepted.
+// of the in-batch columns already written; sti[0] = stop (the argmax is not among the batch's unused candidates),
+// sti[1] = accepted, sti[2] = bit mask of the candidates used so far, sti[4 + b] = the candidate (batch column) step b uses.
+// The candidates are the nb largest diagonal entries when the batch starts, but the ORDER in which the sequential
+// algorithm takes them is only known step by step (an entry touched by an earlier pivot's column falls behind untouched
+// ones): every step looks its true argmax up among the unused candidates, so a batch only ends when the argmax is an
+// entry whose kernel row was not computed.
 __global__ __launch_bounds__(1024) void pchol_top_final_kernel(const uint64_t *__restrict__ pkey, const int *__restrict__ pidx,
                                                                int count, int nb, int *__restrict__ cand,
                                                                float *__restrict__ stf, int *__restrict__ sti)
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(1024) void pchol_top_final_kernel(const uint64_t *_
         block_argmax(best, bi, skey, sidx);
         if (threadIdx.x == 0) {
             cand[r] = bi;
-            if (r == 0) { stf[0] = __uint_as_float((uint32_t)(best >> 32)); sti[0] = 0; sti[1] = 0; }
+            if (r == 0) { stf[0] = __uint_as_float((uint32_t)(best >> 32)); sti[0] = 0; sti[1] = 0; sti[2] = 1; sti[4] = 0; }
             s_last = best;
         }
         __syncthreads();
@@ -476,14 +481,15 @@ __global__ __launch_bounds__(kBlock) void pchol_step_kernel(float *__restrict__ 
     const float dmax = stf[0];
     const bool ok = dmax > tol_abs;
     const float root = sqrtf(fmaxf(dmax, 1e-30f));
-    const int piv = cand[b];
+    const int col_b = sti[4 + b];               // the batch column (candidate) this step uses
+    const int piv = cand[col_b];
     float w[kPcholMaxBatch];
 #pragma unroll
     for (int q = 0; q < kPcholMaxBatch; ++q) w[q] = q < b ? stf[1 + q] : 0.f;
     uint64_t best = 0;
     int bi = -1;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        float v = rowsT[(int64_t)b * ld + i];
+        float v = rowsT[(int64_t)col_b * ld + i];
 #pragma unroll
         for (int q = 0; q < kPcholMaxBatch; ++q)
             if (q < b) v -= lt[(int64_t)(m + q) * ld + i] * w[q];
@@ -515,17 +521,29 @@ __global__ __launch_bounds__(1024) void pchol_step_final_kernel(const uint64_t *
         if (key > best) { best = key; bi = pidx[x]; }
     }
     block_argmax(best, bi, skey, sidx);
+    __shared__ int s_bi;
     if (threadIdx.x == 0) {
+        s_bi = bi;
         sti[1] = b + 1;
         int go = 0;
         if (b + 1 < nb) {
-            if (bi != cand[b + 1]) sti[0] = 1;
-            else { stf[0] = __uint_as_float((uint32_t)(best >> 32)); go = 1; }
+            // the sequential algorithm's next pivot is the argmax `bi`: is its kernel row in this batch, still unused?
+            const int used = sti[2];
+            int j = -1;
+            for (int q = 0; q < nb; ++q)
+                if (!((used >> q) & 1) && cand[q] == bi) { j = q; break; }
+            if (j < 0) sti[0] = 1;
+            else {
+                sti[2] = used | (1 << j);
+                sti[4 + b + 1] = j;
+                stf[0] = __uint_as_float((uint32_t)(best >> 32));
+                go = 1;
+            }
         }
         s_go = go;
     }
     __syncthreads();
-    if (s_go && (int)threadIdx.x <= b) stf[1 + threadIdx.x] = lt[(int64_t)(m + threadIdx.x) * ld + cand[b + 1]];
+    if (s_go && (int)threadIdx.x <= b) stf[1 + threadIdx.x] = lt[(int64_t)(m + threadIdx.x) * ld + s_bi];
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
