@@ -681,6 +681,34 @@ def config3_multi_leg(ctx, n=1_000_000, d=8, iters=50):
                                            f"the iteration; {transport}",
                                    "bytes": n * t * 4, "us": timed_collective(ctx, lambda: all_gather_columns(blk, t))}}
     plx.lattice_cache().clear()
+    # ---- the training step, column-sharded (distributed.column_sharded_mll): same recipe as the one-GPU `config3.train_step`
+    from simplex_gp_amd.distributed import column_sharded_mll, all_reduce_gradients
+    yv = (torch.sin(xd[:, 0]) + 0.1 * torch.randn(n, generator=torch.Generator().manual_seed(99)).to(ctx.dev))
+    steps_out = {}
+    for pre in (0, 100):
+        m2 = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).to(ctx.dev)
+        opt = torch.optim.Adam(m2.parameters(), lr=0.1)
+        start = {k: v.detach().clone() for k, v in m2.state_dict().items()}
+
+        def step(seed):
+            m2.load_state_dict(start)
+            opt.zero_grad()
+            ctx.barrier(); ctx.sync()
+            t0 = time.perf_counter()
+            val = column_sharded_mll(m2, xd, yv, num_probes=10, cg_tol=1.0, max_cg_iter=500, seed=seed, pre_size=pre)
+            (-val).backward()
+            all_reduce_gradients(m2)
+            opt.step()
+            ctx.sync()
+            return ctx.max_over_ranks(time.perf_counter() - t0), float(val.detach())
+        step(0); step(0)
+        best, val = min(step(1 + i) for i in range(3))
+        steps_out[f"pre_size_{pre}"] = {"step_ms": round(best * 1e3, 2), "mll": round(val, 5)}
+        plx.lattice_cache().clear()
+    out["train_step_columns"] = dict(steps_out, exchange={"kind": f"per step: all_reduce of 2 scalars (value) + all_reduce of the {d + 3} "
+                                                                     f"hyper-parameter gradients; {transport}", "bytes": 8 * 2 + 4 * (d + 3)},
+                                     workload="one Adam step on the CG/SLQ marginal likelihood, [y | 10 probes] columns sharded over the "
+                                              "ranks, replicated lattice build and preconditioner")
     return out
 
 

@@ -329,3 +329,90 @@ class SolveGrid:
         if not gather or self.C == 1:
             return x_local, info
         return all_gather_columns(x_local, t, self.column_group), info
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# A column-sharded TRAINING STEP: the marginal likelihood of solvers.marginal_log_likelihood with its [y | probes] columns
+# split over the ranks.  Every rank holds all positions, builds the same lattice (and, with pre_size > 0, the same
+# preconditioner) and draws the same probe vectors from the same seed; it solves its own columns, forms its own share of
+# the value (the quadratic term lives with the rank that has column 0, the stochastic log-determinant is a mean over the
+# probe columns) and of the surrogate whose gradient is the gradient of the likelihood, and runs its own backward pass --
+# ONE all-reduce of two scalars for the value, one all-reduce of the hyper-parameter gradients (d + 3 numbers) per step, no
+# collective inside the solve or the backward filter.
+
+
+def column_sharded_mll(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4, seed=0, pre_size=0, group=None):
+    """Per-datapoint log marginal likelihood (as solvers.marginal_log_likelihood) with the columns of its batched solve
+    sharded over `group`.  The returned scalar has the same VALUE on every rank; its backward() leaves THIS RANK'S SHARE
+    of the gradient in the parameters' .grad -- call all_reduce_gradients(model, group) before the optimiser step."""
+    import math
+    from . import solvers
+    world = dist.get_world_size(group) if _collective_needed(group) else 1
+    rank = dist.get_rank(group) if _collective_needed(group) else 0
+    n = y.shape[0]
+    r = (y - model.mean).reshape(-1, 1)
+    gen = torch.Generator(device=y.device).manual_seed(seed)          # the same probes on every rank
+    K = model.kernel(x, x)
+    mm = model.khat_matmul(x, K)
+    precond = model.preconditioner(x, pre_size, K=K) if pre_size > 0 else None
+    t = 1 + num_probes
+    lo, hi = column_bounds(t, world, rank)
+    stats = torch.zeros(2, dtype=torch.float64, device=y.device)      # [r^T u, sum over local probes of weight_i * quadrature_i]
+    surrogate = None
+    info = {"iterations": 0}
+    with torch.no_grad():
+        if precond is None:
+            Z = torch.randint(0, 2, (n, num_probes), generator=gen, device=y.device).to(r.dtype) * 2 - 1
+        else:
+            Z = precond.sample(num_probes, generator=gen)
+        rhs = torch.cat([r.detach(), Z], 1)
+    if hi > lo:
+        with torch.no_grad():
+            sol, info = model.khat_solve(x, rhs[:, lo:hi].contiguous(), K=K, max_iter=max_cg_iter, tol=cg_tol, want_tridiag=True,
+                                         precond=precond)
+            has_y = lo == 0
+            p0 = 1 if has_y else 0                                    # first probe column inside the local block
+            W = sol[:, p0:]
+            terms = solvers.slq_terms(info["tridiag"][p0:])
+            if terms.numel():
+                weights = torch.full_like(terms, float(n)) if precond is None else info["rz0"][p0:].double()
+                stats[1] = (weights * terms).sum()
+            Zl = Z[:, lo + p0 - 1: hi - 1]                            # the probes this rank solved for
+            if precond is not None and Zl.shape[1]:
+                Zl = precond.solve(Zl)
+            if has_y:
+                u = sol[:, :1]
+                stats[0] = (r.detach() * u).sum().double()
+        cols = ([u] if has_y else []) + ([Zl] if Zl.shape[1] else [])
+        KV = mm(torch.cat(cols, 1))                                   # differentiable MVM over the local columns
+        surrogate = torch.zeros((), dtype=KV.dtype, device=KV.device)
+        if has_y:
+            surrogate = surrogate - (u * r).sum() + 0.5 * (u * KV[:, :1]).sum()
+        if Zl.shape[1]:
+            surrogate = surrogate - 0.5 * (W * KV[:, p0:]).sum() / num_probes
+    all_reduce_sum(stats, group)
+    logdet = stats[1] / num_probes + (precond.logdet() if precond is not None else 0.0)
+    value = -0.5 * stats[0] - 0.5 * logdet - 0.5 * n * math.log(2 * math.pi)
+    if surrogate is None:                                             # a rank without columns: value only, no gradient share
+        surrogate = (model.mean * 0.0).sum()
+    out = (value.to(surrogate.dtype) + (surrogate - surrogate.detach())) / n
+    out.cg_info = info
+    return out
+
+
+def all_reduce_gradients(model, group=None):
+    """Sum the hyper-parameter gradients over the ranks (after column_sharded_mll(...).backward()): one collective over a
+    flat buffer of all gradients."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    if not _collective_needed(group):
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for p in params:
+        k = p.grad.numel()
+        p.grad.copy_(flat[off:off + k].reshape(p.grad.shape))
+        off += k

@@ -576,6 +576,12 @@ def _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_
     return X, info
 
 
+def slq_terms(tridiag):
+    """e1^T log(T_i) e1 per column of a [t, k, k] stack of Lanczos tridiagonals (the quadrature of slq_logdet)."""
+    evals, evecs = torch.linalg.eigh(tridiag)
+    return ((evecs[:, 0, :] ** 2) * evals.clamp_min(1e-30).log()).sum(-1)
+
+
 def slq_logdet(tridiag, n, weights=None):
     """Stochastic Lanczos quadrature: logdet(A) ~ mean_i |z_i|^2 e1^T log(T_i) e1; Rademacher
     probes have |z|^2 = n, preconditioned probes pass their own weights (b^T P^-1 b)."""

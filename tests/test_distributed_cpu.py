@@ -331,3 +331,61 @@ def test_solve_grid_points_by_columns(tmp_path, world, C):
     finally:
         oracle.set_exact_mode(True)
     assert np.linalg.norm(back - rhs.numpy()) / np.linalg.norm(rhs.numpy()) <= 1e-4
+
+
+def _mll_worker(rank, world, port, n, pre_size, outdir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import simplex_gp_amd as plx
+    from simplex_gp_amd import solvers
+    from simplex_gp_amd.distributed import column_sharded_mll, all_reduce_gradients
+    from oracle import oracle
+
+    def oracle_filter(src, ref, coeffs):
+        return torch.from_numpy(oracle.filter(src.detach().numpy(), ref.detach().numpy(), coeffs.detach().numpy()))
+    plx.LatticeFilterGeneral.method = staticmethod(oracle_filter)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        x = torch.rand(n, 2) * 3
+        y = torch.sin(2 * x[:, 0]) * torch.cos(x[:, 1]) + 0.1 * torch.randn(n)
+        model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=2), min_noise=1e-2)
+        out = column_sharded_mll(model, x, y, num_probes=7, cg_tol=1e-6, max_cg_iter=300, seed=5, pre_size=pre_size)
+        (-out).backward()
+        all_reduce_gradients(model)
+        if rank == 0:
+            np.save(os.path.join(outdir, "value.npy"), np.array(float(out.detach())))
+            np.save(os.path.join(outdir, "grads.npy"), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy())
+    finally:
+        dist.destroy_process_group()
+        plx.LatticeFilterGeneral.method = None
+
+
+@pytest.mark.parametrize("world,pre_size", [(2, 0), (3, 0), (2, 10)])
+def test_column_sharded_training_step_equals_single_process(tmp_path, world, pre_size):
+    """One marginal-likelihood evaluation + backward with the [y | probes] columns sharded over the ranks (replicated lattice,
+    same probes from the same seed, one all-reduce of two scalars for the value and one of the hyper-parameter gradients):
+    the value and every gradient equal the single-process solvers.marginal_log_likelihood."""
+    import simplex_gp_amd as plx
+    from simplex_gp_amd import solvers
+    from oracle import oracle
+    n = 300
+    mp.spawn(_mll_worker, args=(world, _free_port(), n, pre_size, str(tmp_path)), nprocs=world, join=True)
+
+    def oracle_filter(src, ref, coeffs):
+        return torch.from_numpy(oracle.filter(src.detach().numpy(), ref.detach().numpy(), coeffs.detach().numpy()))
+    plx.LatticeFilterGeneral.method = staticmethod(oracle_filter)
+    try:
+        torch.manual_seed(3)
+        x = torch.rand(n, 2) * 3
+        y = torch.sin(2 * x[:, 0]) * torch.cos(x[:, 1]) + 0.1 * torch.randn(n)
+        model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=2), min_noise=1e-2)
+        want = solvers.marginal_log_likelihood(model, x, y, num_probes=7, cg_tol=1e-6, max_cg_iter=300, seed=5, pre_size=pre_size)
+        (-want).backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
+    finally:
+        plx.LatticeFilterGeneral.method = None
+    assert abs(float(np.load(tmp_path / "value.npy")) - float(want.detach())) <= 1e-5 * (1 + abs(float(want.detach())))
+    got = np.load(tmp_path / "grads.npy")
+    assert np.allclose(got, grads, rtol=2e-4, atol=1e-6), (got, grads)
