@@ -160,6 +160,12 @@ int64_t plx_device_bytes(const plx_lattice *lat);
  */
 int plx_splat(plx_lattice *lat, const float *d_src, int vd, float *d_values, void *stream);
 
+/* plx_splat of nb one-hot columns without streaming the corners: column b (< nb <= vd) of d_values is S^T e_p for
+ * p = d_points[b], a point index in LATTICE order (device int32; PLX_ARRAY_POINT_PERM maps it to the caller's row); the
+ * other columns and rows are zero.  What a pivoted Cholesky of the operator asks for: rows of K = slice(blur(this)).
+ * Single-shard lattices. */
+int plx_splat_onehot(plx_lattice *lat, const int32_t *d_points, int nb, int vd, float *d_values, void *stream);
+
 /*
  * Stage 2 -- blur (h:513-572): d+1 Jacobi passes over the neighbour table,
  * ping-ponging between d_values and d_scratch (both [m][stride]).  On return

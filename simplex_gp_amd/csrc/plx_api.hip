@@ -312,6 +312,16 @@ int plx_splat(plx_lattice *L, const float *d_src, int vd, float *d_values, void 
     return splat_impl(L, d_src, vd, d_values, (hipStream_t)stream);
 }
 
+int plx_splat_onehot(plx_lattice *L, const int32_t *d_points, int nb, int vd, float *d_values, void *stream)
+{
+    EntryScope sc(L, stream);
+    PLX_TRY(check_apply(L, d_points, d_values, vd, "plx_splat_onehot"));
+    if (nb < 1 || nb > vd) { set_error("plx_splat_onehot: %d one-hot columns in %d", nb, vd); return PLX_ERR_INVALID; }
+    if (L->n_shards != 1 || L->partial_cover) { set_error("plx_splat_onehot: single-shard lattices only"); return PLX_ERR_STATE; }
+    DeviceGuard g(L->device);
+    return splat_onehot_impl(L, d_points, nb, vd, d_values, (hipStream_t)stream);
+}
+
 int plx_blur(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch, void *stream)
 {
     EntryScope sc(L, stream);

@@ -283,6 +283,7 @@ int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin,
 int compact_block_rows(const int *rows_tmp, const int *brow_ptr, int cpb, int64_t nblocks, int *brow_vid, hipStream_t stream);
 // plx_splat.hip / plx_blur.hip / plx_slice.hip
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream);
+int splat_onehot_impl(plx_lattice *L, const int *d_cand, int nb, int vd, float *d_values, hipStream_t stream);
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
 int build_blur_pairs(plx_lattice *L, hipStream_t stream);   // composite neighbour tables of the two-axes-per-launch blur

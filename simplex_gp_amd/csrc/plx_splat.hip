@@ -560,6 +560,31 @@ __global__ __launch_bounds__(kBlock) void splat_fixup_kernel(const int *__restri
     values[(size_t)csr_vid[k1 - 1] * vdp + col] = total;
 }
 
+// splat of nb ONE-HOT columns (column b = the unit vector of point cand[b]): the d + 1 corners of every such point put their
+// barycentric weight into column b of their vertex row, everything else is zero -- the general splat of such a right-hand
+// side streams all nnz corners to add up nb (d + 1) numbers (the rows of K a pivoted Cholesky asks for, plx_pcg.hip)
+__global__ void splat_onehot_kernel(const int *__restrict__ evid, const float *__restrict__ ew, const int *__restrict__ cand,
+                                    int nb, int d1, int n, int vdp, float *__restrict__ values)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nb * d1) return;
+    const int b = x / d1, r = x - b * d1;
+    const int p = cand[b];
+    if (p < 0 || p >= n) return;
+    values[(size_t)evid[(size_t)r * n + p] * vdp + b] = ew[(size_t)r * n + p];     // the corners of one point are distinct vertices
+}
+
+int splat_onehot_impl(plx_lattice *L, const int *d_cand, int nb, int vd, float *d_values, hipStream_t stream)
+{
+    const int vdp = values_stride(vd), d1 = L->d + 1;
+    PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)L->m * vdp * 4, stream));
+    splat_onehot_kernel<<<ceil_div((int64_t)nb * d1, 64), 64, 0, stream>>>(L->evid.as<int>(), L->ew.as<float>(), d_cand, nb, d1, (int)L->n,
+                                                                           vdp, d_values);
+    L->kn_splat = "splat_onehot_kernel";
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream)
 {
     const int64_t m = L->m;

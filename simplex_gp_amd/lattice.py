@@ -275,6 +275,16 @@ class Lattice:
         nv.check(rc, "plx_splat")
         return values
 
+    def splat_onehot(self, points, nb, values, vd=None):
+        """values[:, b] = S^T e_p for p = points[b] (device int32, lattice-order point indices), b < nb; zero elsewhere."""
+        vd = values.shape[1] if vd is None else vd
+        assert values.shape[1] == self.values_stride(vd) and values.is_contiguous() and points.dtype == torch.int32
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_splat_onehot(self._h, ctypes.c_void_p(points.data_ptr()), int(nb), vd,
+                                           ctypes.c_void_p(values.data_ptr()), _stream_ptr(self.device))
+        nv.check(rc, "plx_splat_onehot")
+        return values
+
     def blur(self, values, scratch=None, vd=None):
         """Returns the tensor holding the blurred values (either `values` or `scratch`).
         `values` is [m, values_stride(vd)]; vd defaults to its width."""

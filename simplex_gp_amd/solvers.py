@@ -223,12 +223,14 @@ class LatticePreconditioner:
                     nb = min(B, k - m, n)
                     t = nb if nb == 1 else (nb + 3) // 4 * 4
                     if t not in bufs:
-                        bufs[t] = (torch.empty(n, t, dtype=torch.float32, device=dev), torch.empty(n, t, dtype=torch.float32, device=dev))
-                    rhs, rows = bufs[t]
+                        bufs[t] = (torch.empty(n, t, dtype=torch.float32, device=dev), lat.new_values(t), lat.new_values(t))
+                    rows, vals, scratch = bufs[t]
                     nv.check(lib.plx_pchol_select(_vp(diag), _vp(row_rank), n, nb, ld, kp, _vp(cand), _vp(work), stream),
                              "plx_pchol_select")
-                    nv.check(lib.plx_pchol_onehot(_vp(cand), nb, n, t, _vp(rhs), stream), "plx_pchol_onehot")
-                    lat.apply(rhs, rows)
+                    # K e_p for the nb candidates: the splat of one-hot columns is d + 1 numbers per column (plx_splat_onehot),
+                    # then the usual blur and slice
+                    lat.splat_onehot(cand, nb, vals, vd=t)
+                    lat.slice(lat.blur(vals, scratch, vd=t), rows, vd=t)
                     nv.check(lib.plx_pchol_factor_batch(_vp(self.Lt), ld, kp, m, _vp(rows), t, _vp(scale), _vp(cand), nb, _vp(diag),
                                                         _vp(row_rank), n, float(rel_tol * s), _vp(accepted), _vp(work), stream),
                              "plx_pchol_factor_batch")
