@@ -227,3 +227,35 @@ def test_config3_full_size_preconditioned_cg(plx):
     assert np.abs(true_rel - reported).max() <= 1e-4
     assert reported.max() < 0.5          # 20 iterations at cg_tol = 1 (the reference's training setting): a loose solve by design
     cache.clear()
+
+
+def test_onehot_splat_and_recycled_lattice_guard(plx):
+    """plx_splat_onehot (the factor build's kernel rows: d + 1 numbers per column instead of a pass over all corners)
+    equals the general splat of the same one-hot right-hand side; and a LatticePreconditioner whose lattice object has
+    been rebuilt for other positions (lattice-cache eviction) refuses to be applied instead of permuting rows wrongly."""
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(9)
+    n, d = 20000, 4
+    x = torch.randn(n, d, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    lat = plx.Lattice().build(x, taps)
+    lat.set_lattice_row_order(True)
+    for t, nb in ((1, 1), (4, 3), (12, 12), (16, 13)):
+        pts = torch.randperm(n, generator=g)[:nb].to(torch.int32).cuda()
+        rhs = torch.zeros(n, t, device="cuda")
+        rhs[pts.long(), torch.arange(nb, device="cuda")] = 1.0
+        want = lat.splat(rhs)
+        got = lat.splat_onehot(pts, nb, lat.new_values(t), vd=t)
+        assert torch.equal(got, want), (t, nb)
+    lat.set_lattice_row_order(False)
+    lat.close()
+    model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).cuda()
+    with torch.no_grad():
+        pre = model.preconditioner(x, 20)
+        R = torch.randn(n, 2, generator=g).cuda()
+        z = pre.solve(R)
+        assert torch.isfinite(z).all()
+        pre.lat.build((x * 1.7).contiguous(), taps)                      # what an eviction from the lattice cache does to the object
+        with pytest.raises(RuntimeError, match="rebuilt"):
+            pre.solve(R)
+    plx.lattice_cache().clear()
