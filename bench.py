@@ -41,7 +41,11 @@ rate of one operator, MVMs/s -- never scaled by the problem size:
   --scaling weak    1e6 points PER GPU: the operator grows with the rank count
 Whatever the mode, a multi-GPU line also carries the other legs (`strong`, `config4`
 with vd 1 and 11, `weak_1e6_per_gpu`, `weak_4e6_per_gpu`), each with per-stage us per
-rank and `exchange: {kind, bytes, us}`, so that one 1/2/4/8 sweep yields every curve.
+rank and `exchange: {kind, bytes, us}`, so that one 1/2/4/8 sweep yields every curve;
+`columns_mode` (every rank applies the whole operator to its own right-hand-side column:
+the batched solve's columns sharded, no collective), `config3_cg` (one batched solve split
+by rows / by columns, and a column-sharded training step) and `config4.grid_vd11` (the
+points x columns grid) report the modes of distributed.py that shard columns.
 PLX_BENCH_SINGLE_RANK_RCCL=1 makes a one-GPU run open a world-size-1 "nccl" group and
 take the multi-rank code path (RCCL calls included) -- a rehearsal switch, not a mode.
 """
@@ -715,6 +719,39 @@ def config3_multi_leg(ctx, n=1_000_000, d=8, iters=50):
 CONFIG4_POINTS = int(os.environ.get("PLX_BENCH_CONFIG4_POINTS", "4000000"))      # (tests rehearse the multi-rank legs at a smaller size)
 
 
+def columns_leg(ctx, n, d, ell, steps):
+    """The metric's operator (N = 1e6, d = 8, vd = 1) in COLUMNS mode: every rank builds the whole lattice and applies it to its
+    own right-hand-side column -- the way the columns of a batched solve are sharded (distributed.column_sharded_solve): no
+    collective on the data path at all.  Rate = single-column K.v MVMs per second over ALL ranks (every one of them a whole
+    N-point MVM); per-GPU work is fixed as the rank count grows, i.e. this is weak scaling in the number of right-hand sides,
+    reported beside `value` (one MVM's rows sharded over the ranks), never instead of it."""
+    import torch
+    import simplex_gp_amd as plx
+    x, v = synth(n, d, 1, seed=1234 + 17 * ctx.rank)                 # (the same positions matter, not the same vectors)
+    x0, _ = synth(n, d, 1)
+    ref = (x0 / ell).contiguous().to(ctx.dev)
+    vv = v.contiguous().to(ctx.dev)
+    out = torch.empty_like(vv)
+    lat = plx.Lattice(ctx.dev)
+    lat.build(ref, RBF1)
+    lat.prepare(1)
+    for _ in range(20):
+        lat.apply(vv, out)
+
+    def step(i):
+        if i % 20 == 0:
+            lat.build(ref, RBF1)
+        lat.apply(vv, out)
+    step(0)
+    wall_warm = ctx.max_over_ranks(time_region(lambda i: lat.apply(vv, out), steps, ctx.sync, ctx.barrier))
+    wall_cad = ctx.max_over_ranks(time_region(step, steps, ctx.sync, ctx.barrier))
+    lat.close()
+    return {"mvms_per_s_all_ranks_warm": round(ctx.world * steps / wall_warm, 1),
+            "mvms_per_s_all_ranks_one_build_per_20": round(ctx.world * steps / wall_cad, 1), "ranks": ctx.world,
+            "scaling": "weak (one right-hand-side column per rank; every MVM is a whole N-point K.v on one GPU)",
+            "exchange": {"kind": "none", "bytes": 0, "us": 0.0}}
+
+
 def config4_grid_leg(ctx, steps, n=CONFIG4_POINTS, d=8, vd=11):
     """BASELINE.json configs[3] at vd = 11 on the points x columns grid (distributed.SolveGrid): C column groups, each a
     row-sharded operator over P = world / C ranks.  Every factorisation of the rank count is timed; the rate is 11-column
@@ -844,6 +881,7 @@ def main():
             # weak scaling with 4e6 points per GPU: where the sharded splat / slice outweigh the replicated blur and the
             # all-reduce
             result["weak_4e6_per_gpu"] = sharded_leg(ctx, CONFIG4_POINTS * world, d, 1.0, [1], short)
+            result["columns_mode"] = columns_leg(ctx, args.n, d, args.ell, max(20, args.steps))
             # one batched solve split by rows or by columns, and config 4 at vd = 11 on the points x columns grid
             result["config3_cg"] = config3_multi_leg(ctx, n=args.n)
             cfg4 = result["config4"] if args.scaling != "config4" else result.setdefault("config4", {})
