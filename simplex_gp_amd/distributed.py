@@ -255,11 +255,11 @@ def column_sharded_solve(solve, rhs, group=None, gather=True):
     dist.all_reduce(it, op=dist.ReduceOp.MAX, group=group)
     out["iterations"] = int(it.item())
     for key in ("residual", "rz0"):
-        if any_has(info, key, group, rhs.device):
+        if _any_has(info, key, group, rhs.device):
             v = info.get(key)
             v = v.reshape(1, -1).to(rhs.dtype) if v is not None else rhs.new_zeros(1, 0)
             out[key] = all_gather_columns(v, t, group).reshape(-1)
-    if any_has(info, "tridiag", group, rhs.device):
+    if _any_has(info, "tridiag", group, rhs.device):
         # [t_local, k, k] with k = this rank's iteration count: pad to the common k (identity rows, as
         # solvers._tridiag_from_cg freezes converged columns), gather along the column axis
         k = out["iterations"]
@@ -275,7 +275,7 @@ def column_sharded_solve(solve, rhs, group=None, gather=True):
     return X, out
 
 
-def any_has(info, key, group, device):
+def _any_has(info, key, group, device):
     """True when any rank's info carries `key` (a rank without columns has an empty info)."""
     flag = torch.tensor([1 if info.get(key) is not None else 0], dtype=torch.int64, device=device)
     if _collective_needed(group):

@@ -326,20 +326,23 @@ class LatticePreconditioner:
         dev = self._factor.device
         g1 = torch.randn(self.rank, t, generator=generator, device=dev, dtype=torch.float32)
         g2 = torch.randn(self.n, t, generator=generator, device=dev, dtype=torch.float32)
-
-        def draw(blk, c0=[0]):
+        if self.lat.build_id != self.build_id:
+            raise RuntimeError("LatticePreconditioner: its lattice has been rebuilt for other positions (lattice-cache eviction); "
+                               "build the preconditioner again")
+        outs = []
+        for c0 in range(0, t, 16):                                       # the native pass works on column tiles of at most 16
+            blk = self.lat.to_lattice_order(g2[:, c0:c0 + 16]).contiguous()
             tb = blk.shape[1]
             T = torch.zeros(self.kp, 16, dtype=torch.float32, device=dev)
-            T[:self.rank, :tb] = -g1[:, c0[0]:c0[0] + tb]
-            c0[0] += tb
+            T[:self.rank, :tb] = -g1[:, c0:c0 + tb]                      # Z = sigma g2 - L (-g1)
             Z = torch.empty_like(blk)
             with torch.cuda.device(dev):
                 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 nv.check(lib.plx_pcg_apply(_vp(self._factor), self.factor_type, self.ld, self.kp, self.rank, _vp(blk), self.n, tb,
                                            _vp(T), _vp(self._scale_sample), _vp(Z), None, _vp(self._workspace(tb)), stream),
                          "plx_pcg_apply")
-            return Z
-        return self._columns(draw, g2)
+            outs.append(self.lat.from_lattice_order(Z))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 1)
 
 
 def _batched_pcg_native(matmul, B, precond, max_iter, tol, want_tridiag, check_every, matmul_dot=None, floor=0):

@@ -247,6 +247,12 @@ def test_onehot_splat_and_recycled_lattice_guard(plx):
         want = lat.splat(rhs)
         got = lat.splat_onehot(pts, nb, lat.new_values(t), vd=t)
         assert torch.equal(got, want), (t, nb)
+        # plx_pchol_onehot writes the same right-hand side (for callers that only have plx_apply)
+        from simplex_gp_amd import _native as nv
+        rhs2 = torch.full((n, t), 7.0, device="cuda")
+        nv.check(nv.lib().plx_pchol_onehot(_vp(pts), nb, n, t, _vp(rhs2), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                 "plx_pchol_onehot")
+        assert torch.equal(rhs2, rhs)
     lat.set_lattice_row_order(False)
     lat.close()
     model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).cuda()
