@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--nu", type=float, default=None, help="Matern smoothness (1.5 / 2.5); default RBF")
     ap.add_argument("--min-noise", type=float, default=1e-4)
-    ap.add_argument("--pre-size", type=int, default=0, help="rank of the pivoted-Cholesky preconditioner (the reference's configs use 100)")
+    ap.add_argument("--pre-size", type=int, default=100, help="rank of the pivoted-Cholesky preconditioner (train_simplexgp.py:88 default; 0 = plain CG)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="model.pt")
     args = ap.parse_args()
