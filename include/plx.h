@@ -339,7 +339,9 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  *   for rows of 2..4 chunks; 0 = one), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1),
  *   "block_path" (1 = block tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable),
  *   "block_e" (0 = corners per thread of the block kernels chosen per lattice; 16 or 24: a block holds 256 * e corners),
- *   "block_dense_combine" (1), "scatter_store" (0), "unpermute_gather" (1), "nbr_bitmap" (1 = neighbour lookups test a
+ *   "block_dense_combine" (1), "scatter_store" (0), "unpermute_gather" (1), "nbr_window" (512: on Morton-numbered lattices a neighbour lookup first binary-searches this
+ *   many sorted vertex codes next to the vertex -- found, or proven absent, without touching the hash table when the window
+ *   brackets the target; 0 = hash table only), "nbr_bitmap" (1 = neighbour lookups test a
  *   slot-occupancy bitmap before the hash table when m >= 2^22; 0 never, 2 always), "splat_first" (1 = single-column splat by
  *   first-touch stores + a short extras list when m >= 0.9 nnz; 0 never, 2 whenever representable, 3 = 2 with scattered
  *   stores), "perm_rows" (1 = multi-column row permutations by 16-byte chunks / LDS-transposed whole-line stores; 0 = the

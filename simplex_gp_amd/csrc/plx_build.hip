@@ -660,12 +660,26 @@ __global__ __launch_bounds__(kBlock) void slotmap_kernel(const uint32_t *__restr
     if ((threadIdx.x & 63) == 0 && h < cap) bits[h >> 6] = b;
 }
 
+// Under the Morton numbering (renumber_vertices) vertex i's id IS its rank among the sorted codes of the blur-axis
+// coordinates (a_0 .. a_{d-1}), and a blur step along axis j < d changes a_j alone (by -nid: see vertex_axis_coords).  The
+// neighbour's code is therefore vertex i's code with the bits of coordinate j replaced, it lies on the SAME side of i for
+// every vertex, and -- the codes being sorted and, when no coordinate had to drop bits, unique -- a binary search in a
+// window of the code array next to i decides the lookup whenever the window brackets the target: present (the id is the
+// position: no key compare, no table) or PROVEN absent.  Only targets outside the window (and axis d, which moves every
+// coordinate) go to the hash table.  Where the bits of (coordinate c, bit b) sit in a code, and each coordinate's
+// measured range, come from the layout the renumbering used.
+struct NbrCode {
+    int nbits[kMaxOrderCoords], lo[kMaxOrderCoords], hi[kMaxOrderCoords];
+    unsigned char pos[kMaxOrderCoords][16];
+};
+
 template <int D, bool SYMMETRIC>
 __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__restrict__ vkeys, int m,
                                                           int64_t mstride, int order,
                                                           const uint32_t *__restrict__ table,
                                                           uint32_t mask, int *__restrict__ nbr, int plane_fast,
-                                                          const uint32_t *__restrict__ slotmap)
+                                                          const uint32_t *__restrict__ slotmap,
+                                                          const unsigned long long *__restrict__ vcode, NbrCode nc, int window)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
@@ -677,10 +691,54 @@ __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__rest
     int key[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) key[c] = (int)(int16_t)((kw[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu);
+    const bool windowed = vcode != nullptr && axis < D && axis < kMaxOrderCoords;
+    unsigned long long ci = 0;
+    int aj = 0;
+    if (windowed) {
+        ci = vcode[i];
+        int kd = 0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) kd -= key[c];
+        int ka = 0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) ka = (c == axis) ? key[c] : ka;
+        aj = (kd - ka) / D1;
+    }
 
     int *plane = nbr + (size_t)axis * 2 * order * mstride;
     for (int s = SYMMETRIC ? order : 0; s < 2 * order; ++s) {
         const int nid = (s < order) ? (s - order) : (s - order + 1);
+        if (windowed) {
+            const int ajn = aj - nid;
+            int found_w = -1;
+            bool resolved = false;
+            if (ajn < nc.lo[axis] || ajn > nc.hi[axis]) {
+                resolved = true;                                   // no vertex has that coordinate value
+            } else {
+                unsigned long long T = ci;
+                const int q = ajn - nc.lo[axis];
+                for (int b = 0; b < nc.nbits[axis]; ++b) {
+                    const int pb = nc.pos[axis][b];
+                    T = (T & ~(1ull << pb)) | ((unsigned long long)((q >> b) & 1) << pb);
+                }
+                const int lo_i = T < ci ? max(0, i - window) : i + 1;
+                const int hi_i = T < ci ? i : min(m, i + 1 + window);
+                if (lo_i < hi_i && vcode[lo_i] <= T && T <= vcode[hi_i - 1]) {
+                    int a = lo_i, e = hi_i;
+                    while (a < e) {
+                        const int mid = (a + e) >> 1;
+                        if (vcode[mid] < T) a = mid + 1; else e = mid;
+                    }
+                    found_w = (a < hi_i && vcode[a] == T) ? a : -1;
+                    resolved = true;
+                }
+            }
+            if (resolved) {
+                plane[(size_t)s * mstride + i] = found_w;
+                if (SYMMETRIC && found_w >= 0) plane[(size_t)(order - nid) * mstride + found_w] = i;
+                continue;
+            }
+        }
         uint32_t nk[DW];
 #pragma unroll
         for (int j = 0; j < DW; ++j) nk[j] = 0;
@@ -996,6 +1054,7 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
     constexpr int DW = (D + 1) / 2;
     const int m = (int)L->m;
     L->vertex_order = 0;
+    L->vcode = nullptr;
     if (g_vertex_order == 0 || m < 2) return PLX_OK;
     if (g_vertex_order == 1 && (L->single_use || m < kMortonMinVertices || 10 * (int64_t)m > 9 * corners)) return PLX_OK;
     L->vertex_order = 1;
@@ -1023,6 +1082,22 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
     PLX_TRY(radix_sort_pairs64(L->sort_temp.p, L->sortkey_in.as<uint64_t>(), L->sortkey_out.as<uint64_t>(),
                                L->iota.as<uint32_t>(), L->vorder.as<uint32_t>(), m, key_bits, &second, stream));
     if (!second) std::swap(L->iota, L->vorder);
+    // the sorted codes stay where the sort left them until this build's neighbour lookups have used them (the window search
+    // of neighbor_kernel); exact = every coordinate kept all its bits, so codes are unique and ids are ranks
+    L->vcode = second ? L->sortkey_out.as<unsigned long long>() : L->sortkey_in.as<unsigned long long>();
+    L->vcode_exact = D <= kMaxOrderCoords;
+    for (int c = 0; c < ca.ncoord; ++c) L->vcode_exact = L->vcode_exact && ca.drop[c] == 0;
+    {
+        int at = key_bits;                                        // bits are appended from the top: the first one is the MSB
+        for (int b = ca.maxbits - 1; b >= 0; --b)
+            for (int c = 0; c < ca.ncoord; ++c)
+                if (ca.bits[c] > b) L->vcode_pos[c][b] = (unsigned char)(--at);
+        for (int c = 0; c < ca.ncoord; ++c) {
+            L->vcode_bits[c] = ca.bits[c];
+            L->vcode_lo[c] = ca.lo[c];
+            L->vcode_hi[c] = h_range[2 * c];
+        }
+    }
     vertex_permute_kernel<D><<<nb, kBlock, 0, stream>>>(L->vorder.as<uint32_t>(), m, L->vkeys.as<uint32_t>(),
                                                         L->vslot.as<uint32_t>(), L->vkeys_alt.as<uint32_t>(),
                                                         L->vslot_alt.as<uint32_t>(), L->table.as<uint32_t>());
@@ -1342,16 +1417,28 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
                                                                          L->slotmap.as<unsigned long long>());
             slotmap = L->slotmap.as<uint32_t>();
         }
+        // Morton-numbered lattices: most lookups are decided by a binary search in a window of the sorted codes
+        NbrCode nc;
+        memset(&nc, 0, sizeof(nc));
+        const unsigned long long *vcode = nullptr;
+        if (g_nbr_window > 0 && L->vertex_order == 1 && L->vcode && L->vcode_exact) {
+            vcode = L->vcode;
+            for (int c = 0; c < kMaxOrderCoords; ++c) {
+                nc.nbits[c] = L->vcode_bits[c]; nc.lo[c] = L->vcode_lo[c]; nc.hi[c] = L->vcode_hi[c];
+                memcpy(nc.pos[c], L->vcode_pos[c], 16);
+            }
+        }
         if (g_nbr_symmetric) {
             PLX_HIP_TRY(hipMemsetAsync(L->nbr.p, 0xFF, (size_t)D1 * 2 * order * L->mstride * 4, stream));
             neighbor_kernel<D, true><<<ngrid, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, L->mstride, order,
                                                                     L->table.as<uint32_t>(), L->table_mask,
-                                                                    L->nbr.as<int>(), nplane_fast, slotmap);
+                                                                    L->nbr.as<int>(), nplane_fast, slotmap, vcode, nc, g_nbr_window);
         } else {
             neighbor_kernel<D, false><<<ngrid, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, L->mstride, order,
                                                                      L->table.as<uint32_t>(), L->table_mask,
-                                                                     L->nbr.as<int>(), nplane_fast, slotmap);
+                                                                     L->nbr.as<int>(), nplane_fast, slotmap, vcode, nc, g_nbr_window);
         }
+        L->vcode = nullptr;                                       // (the sort buffers are free for their next user)
     }
     PLX_TRY(build_blur_pairs(L, stream));      // composite neighbours for the two-axes-per-launch blur (coarse lattices)
     // compacted copy for sparse lattices (used by the vd = 1 blur when under a quarter of the neighbours exist)

@@ -72,6 +72,7 @@ struct Tune {
     int block_e = 0;   // corners per thread of the block kernels: 0 = per lattice (choose_block_e), 16 or 24
     int block_dense_combine = 1;   // combine numbers the vertices by counting row ends when every vertex has block rows
     int perm_rows = 1;   // multi-column row permutations: 1 = 16-byte chunks in, LDS-transposed whole-line stores out; 0 = the round-3 per-float / per-chunk kernels
+    int nbr_window = 512;   // Morton-numbered lattices: neighbour lookups first search this many sorted codes next to the vertex (0 = hash only)
     int nbr_bitmap = 1;   // neighbour lookups test a slot-occupancy bitmap before they touch the hash table: 0 never, 1 when m >= 2^22, 2 always
     int splat_first = 1;   // vd = 1 splat on lattices where almost every corner owns its vertex: first-touch corners store, the rest add (0 never, 1 when m >= 0.9 nnz, 2 whenever representable, 3 = 2 without the contiguous-range store)
     // diagnostic ablations: the members always exist (one layout for both libraries), but only libplx_diag.so knows
@@ -111,6 +112,7 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_block_e (plx::tl_tune->block_e)
 #define g_block_dense_combine (plx::tl_tune->block_dense_combine)
 #define g_nbr_bitmap (plx::tl_tune->nbr_bitmap)
+#define g_nbr_window (plx::tl_tune->nbr_window)
 #define g_perm_rows (plx::tl_tune->perm_rows)
 #define g_splat_first (plx::tl_tune->splat_first)
 #define g_splat_ablate (plx::tl_tune->splat_ablate)
@@ -125,6 +127,11 @@ struct plx_lattice {
     bool partial_cover = false;  // built by plx_build_merge: this rank's points do not touch every vertex
     bool local_ready = false;    // plx_build_local done, waiting for plx_build_merge
     int vertex_order = 0;        // 0 first touch, 1 Morton order of the blur-axis coordinates (this build)
+    // the sorted Morton codes of this build's vertices and their bit layout, between the renumbering and the neighbour lookups
+    const unsigned long long *vcode = nullptr;
+    bool vcode_exact = false;
+    int vcode_bits[16] = {}, vcode_lo[16] = {}, vcode_hi[16] = {};
+    unsigned char vcode_pos[16][16] = {};
     int64_t merge_total_points = 0;   // plx_build_merge: points of all ranks (<= 0: unknown)
     bool single_use = false;     // built by plx_filter for one MVM: no vertex renumbering, no axis-pair tables
     bool for_merge = false;      // the local stage of a sharded build is running (vertex renumbering waits for the merge)
