@@ -118,7 +118,8 @@ const char *plx_strerror(int code)
 
 const char *plx_last_error(void) { return g_err; }
 
-const char *plx_version(void) { return "libplx 0.1.0 gfx950"; }
+/* minor = the round that last extended the C ABI */
+const char *plx_version(void) { return "libplx 0.4.0 gfx950"; }
 
 int plx_create(int device, plx_lattice **out)
 {
