@@ -256,10 +256,12 @@ class LatticePreconditioner:
         # C = sigma^2 I + L^T L in fp64 (64 partial products over the n dimension, summed in fp64)
         A = self.Lt[:k].reshape(k, 64, ld // 64).permute(1, 0, 2)
         C = torch.bmm(A, A.transpose(1, 2)).double().sum(0) + noise * torch.eye(k, dtype=torch.float64, device=dev)
-        self._chol = torch.linalg.cholesky(C)
-        cinv = torch.eye(kp, dtype=torch.float64, device=dev) / noise
+        # the k x k factorisation and inverse on the host: 80 KB each way, against a dozen ~100 us launches of the device solver
+        self._chol = torch.linalg.cholesky(C.cpu())
+        cinv = torch.eye(kp, dtype=torch.float64) / noise
         cinv[:k, :k] = torch.cholesky_inverse(self._chol)
-        self._cinv = cinv.contiguous()
+        self._cinv = cinv.contiguous().to(dev)
+        self._logdet = float(2.0 * self._chol.diagonal().log().sum()) + (n - k) * math.log(noise)
         self._scale_solve = torch.tensor([1.0, 1.0 / noise], dtype=torch.float32, device=dev)
         self._scale_sample = torch.tensor([math.sqrt(noise), 1.0], dtype=torch.float32, device=dev)
         self._T = torch.zeros(kp, 16, dtype=torch.float32, device=dev)
@@ -315,7 +317,7 @@ class LatticePreconditioner:
         return self._columns(self.solve_lattice, R.contiguous())
 
     def logdet(self):
-        return 2.0 * self._chol.diagonal().log().sum() + (self.n - self.rank) * math.log(self.noise)
+        return self._logdet
 
     def sample(self, t, generator=None):
         """t columns drawn from N(0, P), rows in the caller's order: L g1 + sigma g2, the same draws in the same order
@@ -529,21 +531,22 @@ def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matm
 
 
 def _tridiag_from_cg(alphas, betas, B):
+    """[t, k, k] Lanczos tridiagonals from the CG coefficients of k iterations (mBCG): T[i, i] = 1 / a_i + b_{i-1} / a_{i-1},
+    T[i, i+1] = sqrt(b_i) / a_i; a column that converged early has alpha = 0 afterwards and its tridiagonal is frozen there
+    (identity rows).  Whole-array expressions: a loop over the k iterations was 4 k small launches (0.4 ms at k = 20)."""
     k = len(alphas)
     a = torch.stack(alphas, 0).double()           # [k, t]
     b = torch.stack(betas, 0).double()
-    # a column that converged early has alpha = 0 afterwards: freeze its tridiagonal there
     valid = a > 0
     inv_a = torch.where(valid, 1.0 / a.clamp_min(1e-300), torch.zeros_like(a))
     t = B.shape[1]
-    T = torch.zeros(t, k, k, dtype=torch.float64, device=B.device)
-    for i in range(k):
-        diag = inv_a[i] + (b[i - 1] * inv_a[i - 1] if i > 0 else 0.0)
-        T[:, i, i] = torch.where(valid[i], diag, torch.ones_like(diag))
-        if i + 1 < k:
-            off = torch.where(valid[i + 1], b[i].clamp_min(0).sqrt() * inv_a[i], torch.zeros_like(diag))
-            T[:, i, i + 1] = off
-            T[:, i + 1, i] = off
+    diag = inv_a.clone()
+    diag[1:] += b[:-1] * inv_a[:-1]
+    diag = torch.where(valid, diag, torch.ones_like(diag))
+    T = torch.diag_embed(diag.t())                # [t, k, k]
+    if k > 1:
+        off = torch.where(valid[1:], b[:-1].clamp_min(0).sqrt() * inv_a[:-1], torch.zeros_like(inv_a[:-1]))      # [k - 1, t]
+        T = T + torch.diag_embed(off.t(), offset=1) + torch.diag_embed(off.t(), offset=-1)
     return T
 
 
@@ -582,17 +585,20 @@ def _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_
 
 
 def slq_terms(tridiag):
-    """e1^T log(T_i) e1 per column of a [t, k, k] stack of Lanczos tridiagonals (the quadrature of slq_logdet)."""
-    evals, evecs = torch.linalg.eigh(tridiag)
-    return ((evecs[:, 0, :] ** 2) * evals.clamp_min(1e-30).log()).sum(-1)
+    """e1^T log(T_i) e1 per column of a [t, k, k] stack of Lanczos tridiagonals (the quadrature of slq_logdet).  The
+    eigen-decompositions of a few dozen k x k matrices run on the HOST (the device solver takes ~1 ms in a dozen small
+    launches for eleven 20 x 20 problems; the copy is a few KB and the solve has just synchronised anyway)."""
+    dev = tridiag.device
+    small = dev.type == "cuda" and tridiag.shape[0] * tridiag.shape[-1] ** 2 <= 1 << 18
+    evals, evecs = torch.linalg.eigh(tridiag.cpu() if small else tridiag)
+    terms = ((evecs[:, 0, :] ** 2) * evals.clamp_min(1e-30).log()).sum(-1)
+    return terms.to(dev) if small else terms
 
 
 def slq_logdet(tridiag, n, weights=None):
     """Stochastic Lanczos quadrature: logdet(A) ~ mean_i |z_i|^2 e1^T log(T_i) e1; Rademacher
     probes have |z|^2 = n, preconditioned probes pass their own weights (b^T P^-1 b)."""
-    evals, evecs = torch.linalg.eigh(tridiag)
-    w = evecs[:, 0, :] ** 2
-    quad = (w * evals.clamp_min(1e-30).log()).sum(-1)
+    quad = slq_terms(tridiag)
     if weights is None:
         return float(n) * quad.mean()
     return (weights.double() * quad).mean()
