@@ -61,6 +61,71 @@ __device__ __forceinline__ uint32_t mix_hash(const uint32_t *k, int dw)
     return (uint32_t)h;
 }
 
+// ---- hash_v = 2 (round 5): a hash that is LINEAR in the key coordinates before one multiplicative mix.
+//   s(key) = sum_c key[c] * kHashMul[c]  (mod 2^32);   slot bits = top 3 bits of s, then the top bits of (s ^ (s >> 15)) * kHashMix
+// A blur neighbour's key is the vertex's own plus a constant vector (h:541-542), so its s is the vertex's s plus a constant
+// per (axis, tap): one add instead of re-hashing 16 bytes -- which is what lets every XCD look at every lookup and serve
+// only those whose slot falls into its own eighth of the table (neighbor_sliced_kernel): the owning eighth is (s + delta) >> 29.
+// Fingerprint: the top byte of a second product of the same s ^ (s >> 15).  Which slot a key lands in is internal: vertex ids
+// come from first touch (h:73-79), so the structure is the same bit for bit under either hash
+// (tests/test_hip_parity.py::test_structure_bit_exact_round5_build_paths).
+#define PLX_HASH_MULS                                                                                          \
+    0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u,    \
+    0x7FEB352Du, 0x846CA68Bu, 0x2C1B3C6Du, 0x297A2D39u, 0x9C06FAF5u, 0xCC9E2D51u, 0x1B873593u, 0xE6546B65u,    \
+    0x63D83595u, 0x4CF5AD43u, 0xA54FF53Bu, 0x510E527Fu, 0x9B05688Du, 0x1F83D9ABu, 0x5BE0CD19u, 0xBB67AE85u,    \
+    0x3C6EF373u, 0xCBBB9D5Du, 0x629A292Bu, 0x9159015Bu, 0x152FECD9u, 0x67332667u, 0x8EB44A87u, 0xDB0C2E0Du
+__device__ constexpr uint32_t kHashMul[PLX_MAX_DIM] = {PLX_HASH_MULS};
+static const uint32_t kHashMulHost[PLX_MAX_DIM] = {PLX_HASH_MULS};      // the host's copy (neighbour deltas)
+static_assert(PLX_MAX_DIM == 32, "one odd multiplier per key coordinate");
+constexpr uint32_t kHashMix = 0x2545F491u, kHashFp = 0x9E3779B9u;
+
+__device__ __forceinline__ uint32_t lin_mix(uint32_t s) { return (s ^ (s >> 15)) * kHashMix; }
+__device__ __forceinline__ uint32_t lin_fp(uint32_t s) { return ((s ^ (s >> 15)) * kHashFp) >> 24; }
+// the value whose top log2(cap) bits are the slot: the top 3 bits -- the eighth of the table, i.e. the XCD that serves the
+// lookup -- are those of s itself (one add and one shift decide whose lookup it is), the bits below them come from the
+// mix.  (s alone as the slot was measured on the CPU: same probe lengths as a random hash at l = 0.25, 16 % more probes per
+// insert at l = 0.5 -- the arithmetic progressions of a linear hash cluster a little; tools/slot_locality_study.py.)
+__device__ __forceinline__ uint32_t lin_slotbits(uint32_t s) { return (s & 0xE0000000u) | (lin_mix(s) >> 3); }
+// map nibble of an occupied slot: 1 + (fingerprint byte scaled to 0..14)
+__device__ __forceinline__ uint32_t fp_nibble(uint32_t fp8) { return 1u + ((fp8 * 15u) >> 8); }
+
+template <int D>
+__device__ __forceinline__ uint32_t lin_hash_coords(const int (&key)[D])
+{
+    uint32_t s = 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s += (uint32_t)key[c] * kHashMul[c];
+    return s;
+}
+
+template <int D>
+__device__ __forceinline__ uint32_t lin_hash_packed(const uint32_t (&kw)[(D + 1) / 2])
+{
+    uint32_t s = 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s += (uint32_t)(int)(int16_t)((kw[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu) * kHashMul[c];
+    return s;
+}
+
+// what the table kernels need to know about the hash in force: slot = hv2 ? x >> shift : x & mask
+struct HashSel { int v2; uint32_t mask; int shift; };
+
+template <int D>
+__device__ __forceinline__ uint32_t key_hash(const uint32_t (&kw)[(D + 1) / 2], const HashSel &hs)
+{
+    return hs.v2 ? lin_slotbits(lin_hash_packed<D>(kw)) : mix_hash(kw, (D + 1) / 2);
+}
+__device__ __forceinline__ uint32_t hash_slot(uint32_t x, const HashSel &hs) { return hs.v2 ? (x >> hs.shift) : (x & hs.mask); }
+
+// table word of a numbered vertex: the id, and (fp_on: hash_v = 2, m < 2^24 - 1) eight fingerprint bits of the key above it.
+// An id field of all ones never occurs, so kEmpty stays distinguishable.
+constexpr int kFpShift = 24;
+template <int D>
+__device__ __forceinline__ uint32_t table_word(uint32_t id, const uint32_t (&kw)[(D + 1) / 2], int fp_on)
+{
+    return fp_on ? (id | (lin_fp(lin_hash_packed<D>(kw)) << kFpShift)) : id;
+}
+
 template <int DW>
 __device__ __forceinline__ void load_key(const uint32_t *__restrict__ base, size_t idx, uint32_t (&k)[DW])
 {
@@ -352,10 +417,12 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__ x,
                                                        const uint32_t *__restrict__ perm, int n, ScaleArgs sf,
                                                        uint32_t *__restrict__ ekeys,
-                                                       float *__restrict__ ew, int *__restrict__ counters)
+                                                       float *__restrict__ ew, int *__restrict__ counters,
+                                                       uint32_t *__restrict__ prank)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
+    constexpr int WR = (D1 + 3) / 4;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
 
@@ -439,6 +506,18 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__
 
     if (bad) atomicOr(&counters[1], 1);
 
+    // the final ranks, one byte per coordinate: corner r-1 is the +1 blur neighbour of corner r along the coordinate
+    // whose rank is d-r+1 (seed_neighbors_kernel)
+    if (prank) {
+        uint32_t rw[WR];
+#pragma unroll
+        for (int j = 0; j < WR; ++j) rw[j] = 0;
+#pragma unroll
+        for (int i = 0; i < D1; ++i) rw[i >> 2] |= ((uint32_t)rk[i] & 0xFFu) << ((i & 3) * 8);
+#pragma unroll
+        for (int j = 0; j < WR; ++j) prank[(size_t)p * WR + j] = rw[j];
+    }
+
     // h:468-471: corner r has key greedy + canonical[r][rank]
 #pragma unroll
     for (int r = 0; r < D1; ++r) {
@@ -470,8 +549,9 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restrict__ ekeys, int n,
-                                                        uint32_t *__restrict__ table, uint32_t mask,
-                                                        uint32_t *__restrict__ eslot, int dedupe, int plane_fast)
+                                                        uint32_t *__restrict__ table, HashSel hs,
+                                                        uint32_t *__restrict__ eslot, int dedupe, int plane_fast,
+                                                        uint32_t *__restrict__ disp)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
@@ -493,7 +573,8 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restri
     // key hash (one ballot per bit), confirmed by comparing the key itself with that lane's -- and only those leaders
     // probe the table; a leader has the smallest entry index of its group.  A lane whose candidate turns out to hold
     // another key (a hash collision inside the wave, < 1 %) simply probes for itself.
-    const uint32_t hk = mix_hash(k, DW);
+    const uint32_t mask = hs.mask;
+    const uint32_t hk = key_hash<D>(k, hs);
     int leader = lane;
     if (dedupe == 2) {
         unsigned long long peers = __ballot(valid);
@@ -521,28 +602,44 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restri
         leader = below ? 63 - __clzll(below) : lane;
     }
 
+    // disp != nullptr (flag_own): the slot's value only ever decreases, and every value that is replaced is replaced by
+    // exactly one atomicMin, whose return value names it.  "own" = this corner put its index into the slot (claimed it
+    // empty, or lowered it); "displaced" = a later atomicMin replaced it.  The first touch of a vertex is the one corner
+    // that owns and was never displaced: own & ~displaced, without reading the table again (flag_own_kernel).
     uint32_t h = 0;
+    bool own = false;
     if (valid && leader == lane) {
-        h = hk & mask;
+        h = hash_slot(hk, hs);
         for (;;) {
             uint32_t o = table[h];
             if (o == kEmpty) {
                 o = atomicCAS(&table[h], kEmpty, e);
-                if (o == kEmpty) break;   // claimed an empty slot
+                if (o == kEmpty) { own = true; break; }   // claimed an empty slot
             }
             if (o == e) break;
             uint32_t ko[DW];
             const uint32_t po = o / D1, ro = o - po * D1;
             load_key<DW>(ekeys, (size_t)ro * n + po, ko);
             if (key_equal<DW>(k, ko)) {
-                if (e < o) atomicMin(&table[h], e);
+                if (e < o) {
+                    if (disp) {
+                        const uint32_t old = atomicMin(&table[h], e);
+                        if (old > e) {
+                            own = true;
+                            const uint32_t pd = old / D1, rd = old - pd * D1;
+                            atomicOr(&disp[2 * (size_t)pd + (rd >> 5)], 1u << (rd & 31));
+                        }
+                    } else {
+                        atomicMin(&table[h], e);
+                    }
+                }
                 break;
             }
             h = (h + 1) & mask;
         }
     }
     if (dedupe) h = __shfl(h, leader);
-    if (valid) eslot[idx] = h;
+    if (valid) eslot[idx] = (disp && own) ? (h | 0x80000000u) : h;
 }
 
 // ----------------------------------------------------------------------------
@@ -578,6 +675,33 @@ __global__ __launch_bounds__(kBlock) void flag_kernel(const uint32_t *__restrict
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
 
+// flag_own: the same flags from the insert's own marks (bit 31 of eslot = the corner put its index into the slot; disp =
+// corners whose index was replaced later): no table gathers.  disp and flagmask may be the same array.
+template <int D1>
+__global__ __launch_bounds__(kBlock) void flag_own_kernel(const uint32_t *__restrict__ eslot, const uint32_t *disp, int n,
+                                                          uint32_t *flagmask, int *__restrict__ blockcnt)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t bits = 0, bits_hi = 0;
+    if (p < n) {
+        uint32_t slot[D1];
+#pragma unroll
+        for (int r = 0; r < D1; ++r) slot[r] = eslot[(size_t)r * n + p];
+#pragma unroll
+        for (int r = 0; r < D1; ++r) {
+            if (r < 32) bits |= (slot[r] >> 31) << r;
+            else bits_hi |= (slot[r] >> 31) << (r - 32);
+        }
+        bits &= ~disp[2 * (size_t)p];
+        bits_hi &= ~disp[2 * (size_t)p + 1];
+        flagmask[2 * (size_t)p] = bits;
+        flagmask[2 * (size_t)p + 1] = bits_hi;
+    }
+    int total;
+    block_exclusive_scan(__popc(bits) + __popc(bits_hi), &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+
 // ... scanned by one workgroup (nblocks <= ~16k for n = 4e6) ...
 __global__ __launch_bounds__(kBlock) void scan_blocks_kernel(int *__restrict__ blockcnt, int nblocks,
                                                              int *__restrict__ counters)
@@ -601,7 +725,9 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ eslot,
                                                         const uint32_t *__restrict__ ekeys, int n,
                                                         uint32_t *__restrict__ table,
-                                                        uint32_t *__restrict__ vkeys, uint32_t *__restrict__ vslot)
+                                                        uint32_t *__restrict__ vkeys, uint32_t *__restrict__ vslot, int fp_on,
+                                                        int *__restrict__ evid, uint32_t *__restrict__ vs0,
+                                                        uint32_t *__restrict__ vowner)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
@@ -616,12 +742,15 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
         bool first = (r < 32) ? ((bits >> r) & 1u) : ((bits_hi >> (r - 32)) & 1u);
         if (first) {
             const size_t idx = (size_t)r * n + p;
-            const uint32_t slot = eslot[idx];
-            table[slot] = (uint32_t)id;
-            vslot[id] = slot;
+            const uint32_t slot = eslot[idx] & 0x7FFFFFFFu;
             uint32_t k[DW];
             load_key<DW>(ekeys, idx, k);
+            table[slot] = table_word<D>((uint32_t)id, k, fp_on);
+            vslot[id] = slot;
             store_key<DW>(vkeys, (size_t)id, k);
+            if (evid) evid[idx] = id;            // the numbering is final (no renumbering follows): assign_evid
+            if (vs0) vs0[id] = lin_hash_packed<D>(k);
+            if (vowner) vowner[id] = (uint32_t)p * D1 + r;
             ++id;
         }
     }
@@ -629,12 +758,86 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
 
 __global__ __launch_bounds__(kBlock) void ids_kernel(const uint32_t *__restrict__ eslot,
                                                      const uint32_t *__restrict__ table, int n,
-                                                     int *__restrict__ evid)
+                                                     int *__restrict__ evid, uint32_t idmask)
 {
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= n) return;
     const size_t idx = (size_t)blockIdx.y * n + p;
-    evid[idx] = (int)table[eslot[idx]];
+    evid[idx] = (int)(table[eslot[idx] & 0x7FFFFFFFu] & idmask);
+}
+
+// assign_evid: the first-touch corners already have their ids (assign_kernel); the others look theirs up.  On the lattices
+// that keep first-touch numbering (m >= 0.9 nnz) that is 1 % of the corners instead of 9e6 random reads of the table.
+__global__ __launch_bounds__(kBlock) void ids_rest_kernel(const uint32_t *__restrict__ eslot, const uint32_t *__restrict__ flagmask,
+                                                          const uint32_t *__restrict__ table, int n, int d1,
+                                                          int *__restrict__ evid, uint32_t idmask)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t lo = flagmask[2 * (size_t)p], hi = flagmask[2 * (size_t)p + 1];
+    for (int r = 0; r < d1; ++r) {
+        const bool first = (r < 32) ? ((lo >> r) & 1u) : ((hi >> (r - 32)) & 1u);
+        if (!first) {
+            const size_t idx = (size_t)r * n + p;
+            evid[idx] = (int)(table[eslot[idx] & 0x7FFFFFFFu] & idmask);
+        }
+    }
+}
+
+// Neighbours known from the embedding.  The corners of one point's simplex are consecutive blur neighbours: going from
+// corner r to corner r+1 (mod d+1) adds 1 to every key coordinate except the one whose rank is d-r, which loses d
+// (h:364-369) -- which is the blur step nid = -1 along that coordinate (h:541-542).  So a vertex that is corner r of point
+// p has corner r-1 as its +1 neighbour along the coordinate of rank d-r+1 (rank 0 for r = 0) and corner r+1 as its -1
+// neighbour along the coordinate of rank d-r.  Every vertex has exactly one first-touch corner (vowner); one thread per
+// vertex writes the vertex's WHOLE row of the table -- these two ids, -1 everywhere else -- as coalesced full-line stores,
+// and records the +1 axis in vaxis[v] (bits 0-5; 0xFF: none), which tells the sliced lookups not to search it.  On the lattices where almost every
+// corner owns its vertex these are nearly ALL the neighbours that exist (11 % of the slots at l = 0.25), i.e. nearly all the
+// lookups that would have to touch the table and a key; what is left to the hash table are proofs of absence.  (First
+// version: a memset of the table, then one thread per POINT scattering the two ids of each first-touch corner: 27 M 4-byte
+// stores that each became a 32-byte write, 699 MB for 81 MB of payload, 420 us on top of the 100 us memset.)
+template <int D>
+__global__ __launch_bounds__(kBlock) void nbr_rows_init_kernel(const uint32_t *__restrict__ vowner, const int *__restrict__ evid,
+                                                               const uint32_t *__restrict__ prank, int n, int m, int64_t mstride,
+                                                               int order, int *__restrict__ nbr, uint8_t *__restrict__ vaxis)
+{
+    constexpr int D1 = D + 1;
+    constexpr int WR = (D1 + 3) / 4;
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (v >= mstride) return;
+    int axis_plus = 255, axis_minus = 255, u_plus = -1, u_minus = -1;
+    if (v < m) {
+        const uint32_t e = vowner[v];
+        const uint32_t p = e / D1;
+        const int r = (int)(e - p * D1);
+        uint32_t rw[WR];
+#pragma unroll
+        for (int j = 0; j < WR; ++j) rw[j] = prank[(size_t)p * WR + j];
+        const int want_plus = (r == 0) ? 0 : D - r + 1, want_minus = D - r;
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+            const int rk = (int)((rw[i >> 2] >> ((i & 3) * 8)) & 0xFFu);
+            axis_plus = (rk == want_plus) ? i : axis_plus;
+            axis_minus = (rk == want_minus) ? i : axis_minus;
+        }
+        u_plus = evid[(size_t)(r == 0 ? D : r - 1) * n + p];
+        u_minus = evid[(size_t)(r == D ? 0 : r + 1) * n + p];
+        // The mirror of the +1 entry -- "v is u_plus's -1 neighbour along this axis" -- is what u_plus's own thread writes
+        // when u_plus has its first touch in this same simplex.  Otherwise bit 7 asks the lookup kernel to store it (it
+        // skips this lookup, so nobody else would).  The mirror of the -1 entry needs nothing: if u_minus has its first
+        // touch elsewhere, its +1 lookup along this axis is not skipped and finds v through the table.
+        const bool mirror = vowner[u_plus] / D1 != p;
+        vaxis[v] = (uint8_t)(axis_plus | (mirror ? 0x80 : 0));
+    }
+#pragma unroll
+    for (int axis = 0; axis < D1; ++axis) {
+        int *plane = nbr + (size_t)axis * 2 * order * mstride + v;
+        for (int sidx = 0; sidx < 2 * order; ++sidx) {
+            int val = -1;
+            if (sidx == order && axis == axis_plus) val = u_plus;            // tap nid = +1
+            if (sidx == order - 1 && axis == axis_minus) val = u_minus;      // tap nid = -1
+            plane[(size_t)sidx * mstride] = val;
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -677,10 +880,11 @@ template <int D, bool SYMMETRIC>
 __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__restrict__ vkeys, int m,
                                                           int64_t mstride, int order,
                                                           const uint32_t *__restrict__ table,
-                                                          uint32_t mask, int *__restrict__ nbr, int plane_fast,
+                                                          HashSel hs, uint32_t idmask, int *__restrict__ nbr, int plane_fast,
                                                           const uint32_t *__restrict__ slotmap,
                                                           const unsigned long long *__restrict__ vcode, NbrCode nc, int window)
 {
+    const uint32_t mask = hs.mask;
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
     const int i = (plane_fast ? blockIdx.y : blockIdx.x) * kBlock + threadIdx.x;
@@ -752,11 +956,12 @@ __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__rest
         }
         int found = -1;
         if (in_range) {
-            uint32_t h = mix_hash(nk, DW) & mask;
+            uint32_t h = hash_slot(key_hash<D>(nk, hs), hs);
             for (;;) {
                 if (slotmap && !((slotmap[h >> 5] >> (h & 31)) & 1u)) break;
                 uint32_t v = table[h];
                 if (v == kEmpty) break;
+                v &= idmask;
                 uint32_t kv[DW];
                 load_key<DW>(vkeys, (size_t)v, kv);
                 if (key_equal<DW>(nk, kv)) { found = (int)v; break; }
@@ -768,21 +973,234 @@ __global__ __launch_bounds__(kBlock) void neighbor_kernel(const uint32_t *__rest
     }
 }
 
+
+// ----------------------------------------------------------------------------
+// XCD-sliced neighbour lookups (round 5; hash_v = 2).  Where most neighbours do not exist (88 % at l = 0.25) a lookup is a
+// proof of absence, and every random 4-byte read of the 134 MB table, of its 4 MB occupancy bitmap or of a 16-byte key costs
+// a 128-byte line fill: neighbor_kernel<8, true> moved 15.6 GB to write a 643 MB table (profiles/r04_summary.md), at the
+// line-fill bandwidth of the fabric.  Here the probing runs on a MAP of four bits per slot -- 0 = empty, else 1 +
+// fingerprint % 15 -- and every lookup is served by the XCD that owns the slot's eighth of that map: workgroup b serves
+// slice b % 8 of vertex tile b / 8 (workgroups b and b + 8 share an XCD, MI355X_MICROARCH.md "Workgroup dispatch"), so an
+// XCD only ever reads 1/8 of the map (2 MB at 2^25 slots), which stays in its 4 MB L2.  The price is that all 8 XCDs look
+// at every (vertex, axis): that has to cost a handful of instructions, which the linear hash provides -- the neighbour's
+// pre-mix hash is the vertex's own plus a constant per (axis, tap), and the owning slice is the top 3 bits of one product.
+// The table and a key are touched only when a nibble matches the lookup's own (the neighbour exists, or 1 in 15 of the
+// occupied slots met on the way).  Placement is a speed assumption only: each (tile, slice) pair is one workgroup wherever
+// it runs.  Positive taps only, hits mirrored (the SYMMETRIC form of neighbor_kernel); same table, bit for bit.
+__global__ __launch_bounds__(kBlock) void nibmap_kernel(const uint32_t *__restrict__ table, uint64_t nwords, int fp_on,
+                                                        uint32_t *__restrict__ nib)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (w >= nwords) return;
+    const uint4 a = reinterpret_cast<const uint4 *>(table)[2 * w], b = reinterpret_cast<const uint4 *>(table)[2 * w + 1];
+    const uint32_t t[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t nb = t[j] == kEmpty ? 0u : (fp_on ? fp_nibble(t[j] >> kFpShift) : 1u);
+        out |= nb << (4 * j);
+    }
+    nib[w] = out;
+}
+
+struct NbrDelta { uint32_t d[PLX_MAX_DIM + 1]; };       // s(neighbour along axis, nid = +1) - s(vertex)
+
+constexpr int kSlicedQueue = 1024;  // nibble matches a workgroup can park in LDS before it resolves them
+// consecutive vertices per thread of neighbor_sliced_kernel: their d+1 ownership bits share one 64-bit mask
+constexpr int sliced_vpt(int d1) { return d1 <= 16 ? 4 : (d1 <= 32 ? 2 : 1); }
+
+// vs0[v] = the pre-mix hash s(key of v), stored by the numbering passes: a thread starts from 4 bytes per vertex instead of
+// unpacking a 16-byte key and eight multiplies -- and it does so once per XCD.  A thread takes V consecutive vertices and
+// decides with an add, a shift and a compare per (vertex, axis) which lookups its XCD owns (the top 3 bits of s + delta),
+// collecting them in ONE 64-bit mask; it then pops them two at a time, so that a map load has most lanes active and two
+// are in flight per lane.  A lookup walks the nibbles from its home slot: an empty one is the proof of absence (98 % end
+// there without touching anything but the map); a nibble equal to its own fingerprint's is PARKED in an LDS queue, and the
+// workgroup resolves the parked ones together at the end -- table word, fingerprint byte, key compare, dense lanes.
+// History (m = 8.9e6, l = 0.25): one vertex per thread, key hashed by all 8 XCDs, d+1 predicated map loads: 1.15 ms at 40 %
+// issue utilisation; four vertices per thread with matches resolved where they occur: 1.21 ms (two dependent HBM round
+// trips in most loop iterations of every wave); + the parking queue: 0.97 ms, now bound by instruction issue (2,900 VALU
+// instructions per wave: a multiply per ownership test, per-vertex 64-bit masks with select chains in the pop).
+template <int D>
+__device__ __forceinline__ int sliced_resolve(const uint32_t *__restrict__ vkeys, const uint32_t *__restrict__ table,
+                                              const uint32_t *__restrict__ nib, uint32_t mask, uint32_t idmask, int fp_on, int i,
+                                              int axis, int t, uint32_t sn, uint32_t h)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    uint32_t kw[DW];
+    load_key<DW>(vkeys, (size_t)i, kw);
+    uint32_t nk[DW];
+#pragma unroll
+    for (int j = 0; j < DW; ++j) nk[j] = 0;
+    bool in_range = true;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const int kc = (int)(int16_t)((kw[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu);
+        const int v = kc - t + ((c == axis) ? t * D1 : 0);        // h:541-542
+        in_range = in_range && v >= -32768 && v <= 32767;
+        nk[c >> 1] |= ((uint32_t)v & 0xFFFFu) << ((c & 1) * 16);
+    }
+    if (!in_range) return -1;
+    const uint32_t fpn = lin_fp(sn), mynib = fp_nibble(fpn);
+    uint32_t w = nib[h >> 3];
+    for (;;) {
+        const uint32_t nb = (w >> ((h & 7u) * 4)) & 15u;
+        if (nb == 0) return -1;
+        if (!fp_on || nb == mynib) {
+            const uint32_t tw = table[h];
+            if (!fp_on || (tw >> kFpShift) == fpn) {
+                const uint32_t v = tw & idmask;
+                uint32_t kv[DW];
+                load_key<DW>(vkeys, (size_t)v, kv);
+                if (key_equal<DW>(nk, kv)) return (int)v;
+            }
+        }
+        h = (h + 1) & mask;
+        if ((h & 7u) == 0) w = nib[h >> 3];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void neighbor_sliced_kernel(const uint32_t *__restrict__ vs0, const uint32_t *__restrict__ vkeys,
+                                                                 int m, int64_t mstride, int order,
+                                                                 const uint32_t *__restrict__ table, HashSel hs, uint32_t idmask,
+                                                                 int fp_on, const uint32_t *__restrict__ nib, NbrDelta nd,
+                                                                 int *__restrict__ nbr, const uint8_t *__restrict__ vaxis)
+{
+    constexpr int D1 = D + 1;
+    constexpr int V = sliced_vpt(D1);
+    constexpr int B = 64 / V;                          // mask bits per vertex (>= d+1)
+    __shared__ uint32_t delta[D1];
+    __shared__ uint32_t q_sn[kSlicedQueue], q_h[kSlicedQueue];
+    __shared__ uint32_t q_who[kSlicedQueue];          // vertex index within the workgroup's tile (12 bits) | axis << 12 | tap << 20
+    __shared__ int q_count;
+    if (threadIdx.x < D1) delta[threadIdx.x] = nd.d[threadIdx.x];
+    if (threadIdx.x == 0) q_count = 0;
+    __syncthreads();
+    const uint32_t slice = blockIdx.x & 7u;
+    const int tile0 = (int)(blockIdx.x >> 3) * kBlock * V;
+    const int i0 = tile0 + threadIdx.x * V;
+    const bool live = i0 < m;
+    uint32_t s0[V], known[V];                           // (vs0 and vaxis are padded to whole vectors)
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s0[j] = 0; known[j] = 0xFFu; }
+    if (live) {
+        if constexpr (V == 4) {
+            const uint4 s4 = *reinterpret_cast<const uint4 *>(vs0 + i0);
+            s0[0] = s4.x; s0[1] = s4.y; s0[2] = s4.z; s0[3] = s4.w;
+            if (vaxis) {
+                const uint32_t k4 = *reinterpret_cast<const uint32_t *>(vaxis + i0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) known[j] = (k4 >> (8 * j)) & 0xFFu;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s0[j] = vs0[i0 + j]; if (vaxis) known[j] = vaxis[i0 + j]; }
+        }
+    }
+    const uint32_t mask = hs.mask;
+    const int shift = hs.shift;
+    auto write_hit = [&](int i, int axis, int t, int found) {
+        const size_t plane = (size_t)axis * 2 * order * mstride;
+        nbr[plane + (size_t)(order + t - 1) * mstride + i] = found;
+        nbr[plane + (size_t)(order - t) * mstride + found] = i;
+    };
+    for (int t = 1; t <= order; ++t) {
+        // which (vertex, axis) lookups of this tap belong to this XCD's eighth of the map: bit j * B + axis
+        unsigned long long own = 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            unsigned long long oj = 0;
+#pragma unroll
+            for (int axis = 0; axis < D1; ++axis)
+                oj |= (unsigned long long)(((s0[j] + (uint32_t)t * nd.d[axis]) >> 29) == slice) << axis;
+            // tap +1 along axis (known & 63) came from the embedding (nbr_rows_init_kernel); bit 7: its mirror is ours to store
+            if (t == 1 && known[j] != 0xFFu) {
+                oj &= ~(1ull << (known[j] & 63u));
+                if ((known[j] & 0x80u) && slice == 0 && live && i0 + j < m) {
+                    const size_t plane = (size_t)(known[j] & 63u) * 2 * order * mstride;
+                    const int u = nbr[plane + (size_t)order * mstride + i0 + j];
+                    nbr[plane + (size_t)(order - 1) * mstride + u] = i0 + j;
+                }
+            }
+            if (!live || i0 + j >= m) oj = 0;
+            own |= oj << (j * B);
+        }
+        // pop them two at a time (any vertex, any axis); walk the nibbles from the home slot
+        while (own) {
+            uint32_t sn[2], h[2], w[2], who[2];
+            bool valid[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                valid[u] = own != 0;
+                const int bit = valid[u] ? __ffsll((long long)own) - 1 : 0;
+                own &= own - 1;                               // (0 stays 0)
+                const int j = bit / B, axis = bit % B;
+                uint32_t sj = s0[0];
+#pragma unroll
+                for (int q = 1; q < V; ++q) sj = (q == j) ? s0[q] : sj;
+                sn[u] = sj + (uint32_t)t * delta[axis];
+                h[u] = lin_slotbits(sn[u]) >> shift;
+                who[u] = (uint32_t)(threadIdx.x * V + j) | ((uint32_t)axis << 12) | ((uint32_t)t << 20);
+            }
+            w[0] = nib[h[0] >> 3];
+            w[1] = valid[1] ? nib[h[1] >> 3] : 0u;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                uint32_t hh = h[u], ww = w[u];
+                uint32_t nb = (ww >> ((hh & 7u) * 4)) & 15u;
+                if (!valid[u] || nb == 0) continue;                      // an empty home slot: the proof of absence
+                const uint32_t mynib = fp_nibble(lin_fp(sn[u]));
+                for (;;) {
+                    if (!fp_on || nb == mynib) {
+                        const int pos = atomicAdd(&q_count, 1);
+                        if (pos < kSlicedQueue) {
+                            q_sn[pos] = sn[u]; q_h[pos] = hh; q_who[pos] = who[u];
+                        } else {                                           // queue full: resolve it here
+                            const int i = tile0 + (int)(who[u] & 0xFFFu), axis = (int)((who[u] >> 12) & 0xFFu);
+                            const int found = sliced_resolve<D>(vkeys, table, nib, mask, idmask, fp_on, i, axis, t, sn[u], hh);
+                            if (found >= 0) write_hit(i, axis, t, found);
+                        }
+                        break;
+                    }
+                    hh = (hh + 1) & mask;
+                    if ((hh & 7u) == 0) ww = nib[hh >> 3];
+                    nb = (ww >> ((hh & 7u) * 4)) & 15u;
+                    if (nb == 0) break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nq = min(q_count, kSlicedQueue);
+    for (int k = threadIdx.x; k < nq; k += kBlock) {
+        const uint32_t who = q_who[k];
+        const int i = tile0 + (int)(who & 0xFFFu), axis = (int)((who >> 12) & 0xFFu), t = (int)(who >> 20);
+        const int found = sliced_resolve<D>(vkeys, table, nib, mask, idmask, fp_on, i, axis, t, q_sn[k], q_h[k]);
+        if (found >= 0) write_hit(i, axis, t, found);
+    }
+}
+
 // ----------------------------------------------------------------------------
 // compaction of the neighbour table for sparse lattices.  A "quad" is 4 consecutive
 // vertices (what one blur thread handles); bit j*2r+s of its mask says neighbour s
 // of vertex j exists.  Ids are stored densely in (quad, bit) order; a wave of the
 // blur kernel finds its ids at cbase[wave] + (prefix of popcounts over its lanes).
 
-__device__ __forceinline__ uint32_t quad_mask(const int *__restrict__ nbr_axis, int64_t mstride, int taps2,
-                                              int i0, int m)
+// the 4 x taps2 ids of a quad, one 16-byte load per tap plane (i0 is a multiple of 4, mstride of 64), and their mask
+__device__ __forceinline__ uint32_t quad_load(const int *__restrict__ nbr_axis, int64_t mstride, int taps2, int i0, int m,
+                                              int (&ids)[6][4])
 {
     uint32_t mask = 0;
-    for (int j = 0; j < 4; ++j) {
-        const int i = i0 + j;
-        if (i >= m) break;
-        for (int s = 0; s < taps2; ++s)
-            if (nbr_axis[s * mstride + i] >= 0) mask |= 1u << (j * taps2 + s);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {                                  // (compile-time indices: the ids stay in registers)
+        if (s < taps2) {
+            const int4 v = *reinterpret_cast<const int4 *>(nbr_axis + (size_t)s * mstride + i0);
+            ids[s][0] = v.x; ids[s][1] = v.y; ids[s][2] = v.z; ids[s][3] = v.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < m && ids[s][j] >= 0) mask |= 1u << (j * taps2 + s);
+        }
     }
     return mask;
 }
@@ -797,7 +1215,8 @@ __global__ __launch_bounds__(kBlock) void compact_count_kernel(const int *__rest
     const int *nb = nbr + (size_t)axis * taps2 * mstride;
     uint32_t mask = 0;
     if (q < nquads) {
-        mask = quad_mask(nb, mstride, taps2, (int)(q * 4), m);
+        int ids[6][4];
+        mask = quad_load(nb, mstride, taps2, (int)(q * 4), m, ids);
         cmask[(size_t)axis * nquads + q] = mask;
     }
     int cnt = __popc(mask);
@@ -807,18 +1226,38 @@ __global__ __launch_bounds__(kBlock) void compact_count_kernel(const int *__rest
     if ((threadIdx.x & 63) == 0 && w < nqwaves) cbase[(size_t)axis * (nqwaves + 1) + w] = (uint32_t)cnt;
 }
 
-// exclusive scan of the wave counts of every axis (one workgroup per axis); totals -> counters[2 + axis]
-__global__ __launch_bounds__(kBlock) void compact_scan_kernel(uint32_t *__restrict__ cbase, int64_t nqwaves,
+// exclusive scan of the wave counts of every axis (one 1024-thread workgroup per axis, 16 counts per thread and step: the
+// 256-thread, one-count-per-thread form took 103 us for 35 k counts -- 137 dependent steps); totals -> counters[2 + axis]
+constexpr int kScanT = 1024, kScanIpt = 16;
+__global__ __launch_bounds__(kScanT) void compact_scan_kernel(uint32_t *__restrict__ cbase, int64_t nqwaves,
                                                               int *__restrict__ counters)
 {
+    __shared__ int wsum[kScanT / 64];
     uint32_t *base = cbase + (size_t)blockIdx.x * (nqwaves + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int carry = 0;
-    for (int64_t b = 0; b < nqwaves; b += kBlock) {
-        const int64_t i = b + threadIdx.x;
-        const int v = (i < nqwaves) ? (int)base[i] : 0;
-        int total;
-        const int ex = block_exclusive_scan(v, &total);
-        if (i < nqwaves) base[i] = (uint32_t)(carry + ex);
+    for (int64_t b = 0; b < nqwaves; b += (int64_t)kScanT * kScanIpt) {
+        const int64_t i0 = b + (int64_t)threadIdx.x * kScanIpt;
+        int v[kScanIpt], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kScanIpt; ++k) { v[k] = (i0 + k < nqwaves) ? (int)base[i0 + k] : 0; sum += v[k]; }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry + incl - sum, total = 0;
+#pragma unroll
+        for (int w = 0; w < kScanT / 64; ++w) { const int t = wsum[w]; if (w < wave) before += t; total += t; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kScanIpt; ++k) {
+            if (i0 + k < nqwaves) base[i0 + k] = (uint32_t)before;
+            before += v[k];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) { base[nqwaves] = (uint32_t)carry; counters[2 + blockIdx.x] = carry; }
@@ -847,10 +1286,14 @@ __global__ __launch_bounds__(kBlock) void compact_fill_kernel(const int *__restr
     if (q >= nquads) return;
     const int64_t w = q >> 6;
     int64_t pos = ao.off[axis] + cbase[(size_t)axis * (nqwaves + 1) + w] + (incl - cnt);
-    const int i0 = (int)(q * 4);
+    if (mask == 0) return;
+    int ids[6][4];
+    (void)quad_load(nb, mstride, taps2, (int)(q * 4), m, ids);
+#pragma unroll
     for (int j = 0; j < 4; ++j)
-        for (int s = 0; s < taps2; ++s)
-            if (mask & (1u << (j * taps2 + s))) cids[pos++] = nb[s * mstride + i0 + j];
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+            if (s < taps2 && (mask & (1u << (j * taps2 + s)))) cids[pos++] = ids[s][j];
 }
 
 // ----------------------------------------------------------------------------
@@ -1032,7 +1475,8 @@ __global__ __launch_bounds__(kBlock) void vertex_permute_kernel(const uint32_t *
                                                                 const uint32_t *__restrict__ vkeys_old,
                                                                 const uint32_t *__restrict__ vslot_old,
                                                                 uint32_t *__restrict__ vkeys_new, uint32_t *__restrict__ vslot_new,
-                                                                uint32_t *__restrict__ table)
+                                                                uint32_t *__restrict__ table, int fp_on,
+                                                                uint32_t *__restrict__ vs0)
 {
     constexpr int DW = (D + 1) / 2;
     const int nw = blockIdx.x * kBlock + threadIdx.x;
@@ -1041,9 +1485,19 @@ __global__ __launch_bounds__(kBlock) void vertex_permute_kernel(const uint32_t *
     uint32_t k[DW];
     load_key<DW>(vkeys_old, (size_t)old, k);
     store_key<DW>(vkeys_new, (size_t)nw, k);
+    if (vs0) vs0[nw] = lin_hash_packed<D>(k);
     const uint32_t slot = vslot_old[old];
     vslot_new[nw] = slot;
-    table[slot] = (uint32_t)nw;
+    table[slot] = table_word<D>((uint32_t)nw, k, fp_on);
+}
+
+// does this build renumber its m vertices along the Morton curve?  (renumber_vertices; asked before the numbering pass too,
+// which stores final ids itself when the answer is no)
+static bool will_renumber(const plx_lattice *L, int64_t m, int64_t corners)
+{
+    if (g_vertex_order == 0 || m < 2) return false;
+    if (g_vertex_order == 1 && (L->single_use || m < kMortonMinVertices || 10 * m > 9 * corners)) return false;
+    return true;
 }
 
 template <int D>
@@ -1055,8 +1509,7 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
     const int m = (int)L->m;
     L->vertex_order = 0;
     L->vcode = nullptr;
-    if (g_vertex_order == 0 || m < 2) return PLX_OK;
-    if (g_vertex_order == 1 && (L->single_use || m < kMortonMinVertices || 10 * (int64_t)m > 9 * corners)) return PLX_OK;
+    if (!will_renumber(L, m, corners)) return PLX_OK;
     L->vertex_order = 1;
     CodeArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -1100,11 +1553,40 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
     }
     vertex_permute_kernel<D><<<nb, kBlock, 0, stream>>>(L->vorder.as<uint32_t>(), m, L->vkeys.as<uint32_t>(),
                                                         L->vslot.as<uint32_t>(), L->vkeys_alt.as<uint32_t>(),
-                                                        L->vslot_alt.as<uint32_t>(), L->table.as<uint32_t>());
+                                                        L->vslot_alt.as<uint32_t>(), L->table.as<uint32_t>(),
+                                                        L->table_idmask != 0xFFFFFFFFu ? 1 : 0,
+                                                        L->vs0_valid ? L->vs0.as<uint32_t>() : nullptr);
     std::swap(L->vkeys, L->vkeys_alt);
     std::swap(L->vslot, L->vslot_alt);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
+}
+
+static HashSel hash_sel(const plx_lattice *L)
+{
+    HashSel hs;
+    hs.v2 = L->table_hash == 2 ? 1 : 0;
+    hs.mask = L->table_mask;
+    hs.shift = 32 - L->table_bits;
+    return hs;
+}
+
+// table geometry + the hash in force for a table of `cap` slots (a power of two, 2^10 .. 2^32)
+static void set_table(plx_lattice *L, uint64_t cap)
+{
+    L->table_mask = (uint32_t)(cap - 1);
+    L->table_bits = 0;
+    while ((1ull << L->table_bits) < cap) ++L->table_bits;
+    L->table_hash = g_hash_v == 2 ? 2 : 1;
+    L->table_idmask = 0xFFFFFFFFu;
+}
+
+// fingerprints ride in the table words of numbered vertices when the ids leave the top byte free
+static int table_fp_on(plx_lattice *L, int64_t m)
+{
+    const int on = (L->table_hash == 2 && g_table_fp != 0 && m < (1ll << kFpShift) - 1) ? 1 : 0;
+    L->table_idmask = on ? ((1u << kFpShift) - 1u) : 0xFFFFFFFFu;
+    return on;
 }
 
 // ---- stage 1: everything that depends only on this lattice's own points --------------------
@@ -1132,7 +1614,7 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     // table capacity: power of two >= 2E  (load factor <= 0.5)
     uint64_t cap = 1024;
     while (cap < 2ull * (uint64_t)E) cap <<= 1;
-    L->table_mask = (uint32_t)(cap - 1);
+    set_table(L, cap);
 
     // ---- point order
     OrderArgs oa;
@@ -1156,6 +1638,10 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     PLX_TRY(ensure(L->eslot, (size_t)E * 4));
     PLX_TRY(ensure(L->evid, (size_t)E * 4));
     PLX_TRY(ensure(L->flagmask, (size_t)n * 8));
+    const bool want_rank = g_hash_v == 2 && g_nbr_sliced != 0 && g_nbr_seed != 0;
+    constexpr int WR = (D1 + 3) / 4;
+    if (want_rank) PLX_TRY(ensure(L->prank, (size_t)n * WR * 4));
+    L->prank_valid = false;
     PLX_TRY(ensure(L->blockcnt, (size_t)(nblocks + 1) * 4));
     PLX_TRY(ensure(L->table, (size_t)cap * 4));
     PLX_TRY(ensure(L->counters, 256));
@@ -1191,16 +1677,25 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
         iota_kernel<<<nblocks, kBlock, 0, stream>>>(L->perm.as<uint32_t>(), n);
     }
     embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, L->perm.as<uint32_t>(), n, sf, L->ekeys.as<uint32_t>(),
-                                                    L->ew.as<float>(), L->counters.as<int>());
+                                                    L->ew.as<float>(), L->counters.as<int>(),
+                                                    want_rank ? L->prank.as<uint32_t>() : nullptr);
     mark();
+    // flag_own: the insert marks owners (bit 31 of eslot: the table must not need that bit) and displaced corners (flagmask
+    // doubles as the displaced mask until flag_own_kernel turns it into the first-touch mask in place)
+    const bool flag_own = g_flag_own != 0 && L->table_bits <= 31;
+    if (flag_own) PLX_HIP_TRY(hipMemsetAsync(L->flagmask.p, 0, (size_t)n * 8, stream));
     const int plane_fast = (g_insert_plane_fast != 0 && nblocks <= 65535) ? 1 : 0;
     insert_kernel<D><<<plane_fast ? dim3(D1, nblocks) : dim3(nblocks, D1), kBlock, 0, stream>>>(
-        L->ekeys.as<uint32_t>(), n, L->table.as<uint32_t>(), L->table_mask, L->eslot.as<uint32_t>(), g_insert_dedupe,
-        plane_fast);
+        L->ekeys.as<uint32_t>(), n, L->table.as<uint32_t>(), hash_sel(L), L->eslot.as<uint32_t>(), g_insert_dedupe,
+        plane_fast, flag_own ? L->flagmask.as<uint32_t>() : nullptr);
     mark();
     L->flags_valid = !L->for_merge;      // the first-touch bits of this build's points stay in flagmask (plx_first.hip reads them)
-    flag_kernel<D1><<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
-                                                    L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
+    if (flag_own)
+        flag_own_kernel<D1><<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->flagmask.as<uint32_t>(), n,
+                                                            L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
+    else
+        flag_kernel<D1><<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
+                                                        L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
     scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
     int h_cnt[2];
     PLX_TRY(read_back(L, L->counters.as<int>(), 2, h_cnt, stream));   // m sizes everything below
@@ -1212,12 +1707,28 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     L->m = m;
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));
     PLX_TRY(ensure(L->vslot, (size_t)m * 4 + 16));
+    L->vs0_valid = L->table_hash == 2 && g_nbr_sliced != 0 && !L->for_merge;
+    if (L->vs0_valid) PLX_TRY(ensure(L->vs0, ((size_t)m + 8) * 4));
+    if (want_rank) PLX_TRY(ensure(L->vowner, ((size_t)m + 8) * 4));
+    const int fp_on = table_fp_on(L, m);
+    // the ids handed out here are final unless a renumbering follows (a local stage's are final as LOCAL ids: the merge maps them)
+    const bool ids_final = L->for_merge || !will_renumber(L, m, E);
+    const bool assign_evid = g_assign_evid != 0 && ids_final;
     assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->blockcnt.as<int>(),
                                                      L->eslot.as<uint32_t>(), L->ekeys.as<uint32_t>(), n,
-                                                     L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>());
+                                                     L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>(), fp_on,
+                                                     assign_evid ? L->evid.as<int>() : nullptr,
+                                                     (L->vs0_valid && ids_final) ? L->vs0.as<uint32_t>() : nullptr,
+                                                     (want_rank && ids_final) ? L->vowner.as<uint32_t>() : nullptr);
     if (!L->for_merge) PLX_TRY(renumber_vertices<D>(L, E, stream));   // (a job built from local rows renumbers the union, after the merge)
     mark();
-    ids_kernel<<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n, L->evid.as<int>());
+    if (assign_evid)
+        ids_rest_kernel<<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->flagmask.as<uint32_t>(), L->table.as<uint32_t>(), n, D1,
+                                                        L->evid.as<int>(), L->table_idmask);
+    else
+        ids_kernel<<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n, L->evid.as<int>(),
+                                                             L->table_idmask);
+    L->prank_valid = want_rank && !L->for_merge;
     mark();
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -1230,7 +1741,7 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void merge_insert_kernel(const uint32_t *__restrict__ keys, int M,
-                                                              uint32_t *__restrict__ table, uint32_t mask,
+                                                              uint32_t *__restrict__ table, HashSel hs,
                                                               uint32_t *__restrict__ slot)
 {
     constexpr int DW = (D + 1) / 2;
@@ -1238,7 +1749,8 @@ __global__ __launch_bounds__(kBlock) void merge_insert_kernel(const uint32_t *__
     if (idx >= M) return;
     uint32_t k[DW];
     load_key<DW>(keys, (size_t)idx, k);
-    uint32_t h = mix_hash(k, DW) & mask;
+    const uint32_t mask = hs.mask;
+    uint32_t h = hash_slot(key_hash<D>(k, hs), hs);
     for (;;) {
         uint32_t o = table[h];
         if (o == kEmpty) {
@@ -1278,7 +1790,8 @@ __global__ __launch_bounds__(kBlock) void merge_assign_kernel(const uint32_t *__
                                                               const uint32_t *__restrict__ slot,
                                                               const uint32_t *__restrict__ keys, int M,
                                                               uint32_t *__restrict__ table,
-                                                              uint32_t *__restrict__ gkeys, uint32_t *__restrict__ vslot)
+                                                              uint32_t *__restrict__ gkeys, uint32_t *__restrict__ vslot, int fp_on,
+                                                              uint32_t *__restrict__ vs0)
 {
     constexpr int DW = (D + 1) / 2;
     const int idx = blockIdx.x * kBlock + threadIdx.x;
@@ -1286,21 +1799,22 @@ __global__ __launch_bounds__(kBlock) void merge_assign_kernel(const uint32_t *__
     int total;
     const int gid = blockoff[blockIdx.x] + block_exclusive_scan(first, &total);
     if (idx < M && first) {
-        table[slot[idx]] = (uint32_t)gid;
-        vslot[gid] = slot[idx];
         uint32_t k[DW];
         load_key<DW>(keys, (size_t)idx, k);
+        table[slot[idx]] = table_word<D>((uint32_t)gid, k, fp_on);
+        vslot[gid] = slot[idx];
         store_key<DW>(gkeys, (size_t)gid, k);
+        if (vs0) vs0[gid] = lin_hash_packed<D>(k);
     }
 }
 
 // evid[i] = global id of local vertex evid[i]  (its key sits at all_keys[my_off + local id])
 __global__ __launch_bounds__(kBlock) void merge_remap_kernel(int *__restrict__ evid, int64_t E,
                                                              const uint32_t *__restrict__ slot,
-                                                             const uint32_t *__restrict__ table, int my_off)
+                                                             const uint32_t *__restrict__ table, int my_off, uint32_t idmask)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < E) evid[i] = (int)table[slot[my_off + evid[i]]];
+    if (i < E) evid[i] = (int)(table[slot[my_off + evid[i]]] & idmask);
 }
 
 template <int D>
@@ -1327,9 +1841,9 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
     PLX_TRY(ensure(L->merge_slot, (size_t)M * 4 + 16));
     PLX_TRY(ensure(L->merge_flags, (size_t)M * 4 + 16));
     PLX_TRY(ensure(L->blockcnt, (size_t)(nblocks + 1) * 4));
-    L->table_mask = (uint32_t)(cap - 1);
+    set_table(L, cap);
     PLX_HIP_TRY(hipMemsetAsync(L->table.p, 0xFF, (size_t)cap * 4, stream));
-    merge_insert_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_all_keys, (int)M, L->table.as<uint32_t>(), L->table_mask,
+    merge_insert_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_all_keys, (int)M, L->table.as<uint32_t>(), hash_sel(L),
                                                            L->merge_slot.as<uint32_t>());
     merge_flag_kernel<<<nblocks, kBlock, 0, stream>>>(L->merge_slot.as<uint32_t>(), L->table.as<uint32_t>(), (int)M,
                                                       L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>());
@@ -1339,15 +1853,20 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
     const int m = h_cnt[0];
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));   // local keys are no longer needed: all_keys holds them
     PLX_TRY(ensure(L->vslot, (size_t)m * 4 + 16));
+    L->vs0_valid = L->table_hash == 2 && g_nbr_sliced != 0;
+    if (L->vs0_valid) PLX_TRY(ensure(L->vs0, ((size_t)m + 8) * 4));
+    const int fp_on = table_fp_on(L, m);
     merge_assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>(),
                                                            L->merge_slot.as<uint32_t>(), d_all_keys, (int)M,
-                                                           L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>());
+                                                           L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>(), fp_on,
+                                                           L->vs0_valid ? L->vs0.as<uint32_t>() : nullptr);
     L->m = m;
     PLX_TRY(renumber_vertices<D>(L, L->merge_total_points > 0 ? L->merge_total_points * D1 : M, stream));
     const int64_t E = L->n * D1;
     merge_remap_kernel<<<ceil_div(E, kBlock), kBlock, 0, stream>>>(L->evid.as<int>(), E, L->merge_slot.as<uint32_t>(),
-                                                                   L->table.as<uint32_t>(), (int)my_off);
+                                                                   L->table.as<uint32_t>(), (int)my_off, L->table_idmask);
     L->m = m;
+    L->prank_valid = false;      // (the first-touch flags of the local stage name local vertices)
     L->partial_cover = true;     // this rank's points do not touch every vertex: splat zero-fills first
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
@@ -1409,14 +1928,6 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         const int nplane_fast = (g_insert_plane_fast != 0 && ceil_div(m, kBlock) <= 65535) ? 1 : 0;
         dim3 ngrid(ceil_div(m, kBlock), D1);
         if (nplane_fast) ngrid = dim3(D1, ceil_div(m, kBlock));
-        const uint32_t *slotmap = nullptr;
-        if (g_nbr_bitmap == 2 || (g_nbr_bitmap == 1 && m >= (1 << 22))) {
-            const uint64_t cap = (uint64_t)L->table_mask + 1u;       // a power of two >= 1024
-            PLX_TRY(ensure(L->slotmap, (size_t)cap / 8 + 8));
-            slotmap_kernel<<<ceil_div(cap, kBlock), kBlock, 0, stream>>>(L->table.as<uint32_t>(), cap,
-                                                                         L->slotmap.as<unsigned long long>());
-            slotmap = L->slotmap.as<uint32_t>();
-        }
         // Morton-numbered lattices: most lookups are decided by a binary search in a window of the sorted codes
         NbrCode nc;
         memset(&nc, 0, sizeof(nc));
@@ -1428,14 +1939,50 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
                 memcpy(nc.pos[c], L->vcode_pos[c], 16);
             }
         }
-        if (g_nbr_symmetric) {
+        const bool sliced = L->table_hash == 2 && L->vs0_valid && g_nbr_symmetric && ceil_div(m, kBlock) < (1 << 28) &&
+                            (g_nbr_sliced == 2 || (g_nbr_sliced == 1 && vcode == nullptr && m >= (1 << 20)));
+        const uint32_t *slotmap = nullptr;
+        if (!sliced && (g_nbr_bitmap == 2 || (g_nbr_bitmap == 1 && m >= (1 << 22)))) {
+            const uint64_t cap = (uint64_t)L->table_mask + 1u;       // a power of two >= 1024
+            PLX_TRY(ensure(L->slotmap, (size_t)cap / 8 + 8));
+            slotmap_kernel<<<ceil_div(cap, kBlock), kBlock, 0, stream>>>(L->table.as<uint32_t>(), cap,
+                                                                         L->slotmap.as<unsigned long long>());
+            slotmap = L->slotmap.as<uint32_t>();
+        }
+        if (sliced) {
+            const uint64_t cap = (uint64_t)L->table_mask + 1u;
+            PLX_TRY(ensure(L->nibmap, (size_t)cap / 2 + 16));
+            const int fp_on = L->table_idmask != 0xFFFFFFFFu ? 1 : 0;
+            nibmap_kernel<<<ceil_div(cap / 8, kBlock), kBlock, 0, stream>>>(L->table.as<uint32_t>(), cap / 8, fp_on,
+                                                                            L->nibmap.as<uint32_t>());
+            NbrDelta nd;
+            uint32_t sum = 0;
+            for (int c = 0; c < D; ++c) sum += kHashMulHost[c];
+            for (int a = 0; a < D; ++a) nd.d[a] = (uint32_t)D1 * kHashMulHost[a] - sum;
+            nd.d[D] = 0u - sum;
+            const uint8_t *vaxis = nullptr;
+            if (g_nbr_seed != 0 && L->prank_valid && L->vertex_order == 0 && !L->partial_cover) {
+                // (first-touch numbering only: vowner and evid then name the same, final ids)
+                PLX_TRY(ensure(L->vaxis, (size_t)L->mstride + 16));
+                PLX_HIP_TRY(hipMemsetAsync(L->vaxis.p, 0xFF, (size_t)L->mstride + 16, stream));
+                nbr_rows_init_kernel<D><<<ceil_div(L->mstride, kBlock), kBlock, 0, stream>>>(
+                    L->vowner.as<uint32_t>(), L->evid.as<int>(), L->prank.as<uint32_t>(), (int)L->n, m, L->mstride, order,
+                    L->nbr.as<int>(), L->vaxis.as<uint8_t>());
+                vaxis = L->vaxis.as<uint8_t>();
+            } else {
+                PLX_HIP_TRY(hipMemsetAsync(L->nbr.p, 0xFF, (size_t)D1 * 2 * order * L->mstride * 4, stream));
+            }
+            neighbor_sliced_kernel<D><<<8u * (unsigned)ceil_div(m, kBlock * sliced_vpt(D1)), kBlock, 0, stream>>>(
+                L->vs0.as<uint32_t>(), L->vkeys.as<uint32_t>(), m, L->mstride, order, L->table.as<uint32_t>(), hash_sel(L),
+                L->table_idmask, fp_on, L->nibmap.as<uint32_t>(), nd, L->nbr.as<int>(), vaxis);
+        } else if (g_nbr_symmetric) {
             PLX_HIP_TRY(hipMemsetAsync(L->nbr.p, 0xFF, (size_t)D1 * 2 * order * L->mstride * 4, stream));
             neighbor_kernel<D, true><<<ngrid, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, L->mstride, order,
-                                                                    L->table.as<uint32_t>(), L->table_mask,
+                                                                    L->table.as<uint32_t>(), hash_sel(L), L->table_idmask,
                                                                     L->nbr.as<int>(), nplane_fast, slotmap, vcode, nc, g_nbr_window);
         } else {
             neighbor_kernel<D, false><<<ngrid, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, L->mstride, order,
-                                                                     L->table.as<uint32_t>(), L->table_mask,
+                                                                     L->table.as<uint32_t>(), hash_sel(L), L->table_idmask,
                                                                      L->nbr.as<int>(), nplane_fast, slotmap, vcode, nc, g_nbr_window);
         }
         L->vcode = nullptr;                                       // (the sort buffers are free for their next user)
@@ -1459,7 +2006,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         dim3 cgrid((unsigned)ceil_div(L->nqwaves * 64, kBlock), D1);
         compact_count_kernel<<<cgrid, kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, taps2, L->nquads,
                                                            L->nqwaves, L->cmask.as<uint32_t>(), L->cbase.as<uint32_t>());
-        compact_scan_kernel<<<D1, kBlock, 0, stream>>>(L->cbase.as<uint32_t>(), L->nqwaves, L->counters.as<int>());
+        compact_scan_kernel<<<D1, kScanT, 0, stream>>>(L->cbase.as<uint32_t>(), L->nqwaves, L->counters.as<int>());
         int h_axis[2 + PLX_MAX_DIM + 1];
         PLX_TRY(read_back(L, L->counters.as<int>(), 2 + D1, h_axis, stream));
         AxisOffsets ao;

@@ -74,6 +74,12 @@ struct Tune {
     int perm_rows = 1;   // multi-column row permutations: 1 = 16-byte chunks in, LDS-transposed whole-line stores out; 0 = the round-3 per-float / per-chunk kernels
     int nbr_window = 512;   // Morton-numbered lattices: neighbour lookups first search this many sorted codes next to the vertex (0 = hash only)
     int nbr_bitmap = 1;   // neighbour lookups test a slot-occupancy bitmap before they touch the hash table: 0 never, 1 when m >= 2^22, 2 always
+    int hash_v = 2;   // vertex table hash: 1 = 64-bit mix of the packed key words; 2 = linear in the key coordinates + one multiplicative mix (a neighbour's hash is the vertex's own plus a constant, slot = top bits)
+    int table_fp = 1;   // hash_v = 2, m < 2^24: the table word of a numbered vertex carries 8 fingerprint bits of its key above the id
+    int nbr_sliced = 1;   // neighbour lookups served by the XCD that owns the slot's eighth of a 4-bit-per-slot map (L2 resident): 0 never, 1 when the lattice keeps first-touch numbering and m >= 2^20, 2 always (needs hash_v = 2)
+    int flag_own = 1;   // first-touch flags without table gathers: the insert marks who claimed / lowered a slot (top bit of eslot) and who was displaced
+    int assign_evid = 1;   // the numbering pass stores the vertex id of every first-touch corner itself when the numbering is final; the id lookup then serves the other corners only
+    int nbr_seed = 1;   // sliced neighbour lookups: the +1 neighbour that is a corner of the vertex's own first-touch simplex comes from the embedding, no lookup
     int splat_first = 1;   // vd = 1 splat on lattices where almost every corner owns its vertex: first-touch corners store, the rest add (0 never, 1 when m >= 0.9 nnz, 2 whenever representable, 3 = 2 without the contiguous-range store)
     // diagnostic ablations: the members always exist (one layout for both libraries), but only libplx_diag.so knows
     // their names and compiles the branches behind them (PLX_DIAG_VALUE)
@@ -115,6 +121,12 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_nbr_window (plx::tl_tune->nbr_window)
 #define g_perm_rows (plx::tl_tune->perm_rows)
 #define g_splat_first (plx::tl_tune->splat_first)
+#define g_flag_own (plx::tl_tune->flag_own)
+#define g_assign_evid (plx::tl_tune->assign_evid)
+#define g_nbr_seed (plx::tl_tune->nbr_seed)
+#define g_hash_v (plx::tl_tune->hash_v)
+#define g_table_fp (plx::tl_tune->table_fp)
+#define g_nbr_sliced (plx::tl_tune->nbr_sliced)
 #define g_splat_ablate (plx::tl_tune->splat_ablate)
 #define g_blur_ablate (plx::tl_tune->blur_ablate)
 #define g_block_ablate (plx::tl_tune->block_ablate)
@@ -150,6 +162,9 @@ struct plx_lattice {
     int64_t nnz = 0;               // owned CSR entries = n_own * (d+1)
     int64_t nchunks = 0;           // ceil(nnz / kSplatChunk)
     uint32_t table_mask = 0;       // capacity - 1
+    int table_bits = 0;            // log2(capacity)
+    int table_hash = 1;            // hash function the table of this build was filled under (Tune::hash_v)
+    uint32_t table_idmask = 0xFFFFFFFFu;   // id bits of a numbered vertex's table word (0x00FFFFFF when the word carries a fingerprint)
 
     // point order: perm[i] = original row of the i-th point in lattice order (shard-major, then
     // lexicographic in the rounded lattice coordinates); every per-point array below is in that order
@@ -166,6 +181,13 @@ struct plx_lattice {
     plx::DevBuf counters;   // int32  [8]            {m, error flag, ...}
     plx::DevBuf sort_keys_in, sort_vals_in, sort_vals_out, sort_temp;
     plx::DevBuf slotmap;    // uint32 [capacity / 32] one bit per hash slot: occupied (neighbour lookups of large lattices)
+    plx::DevBuf prank;      // uint32 [n][ceil((d+1)/4)] one byte per coordinate: its rank in the point's simplex (h:427-457), lattice order
+    plx::DevBuf vowner;     // uint32 [m]            first-touch corner e = p (d+1) + r of every vertex (first-touch numbering; neighbour seeding)
+    plx::DevBuf vs0;        // uint32 [m]            pre-mix hash of every vertex key (hash_v = 2; sliced neighbour lookups)
+    bool vs0_valid = false;
+    plx::DevBuf vaxis;      // uint8  [m]            blur axis whose +1 neighbour was taken from the vertex's first-touch simplex (255: none)
+    bool prank_valid = false;      // prank / flagmask describe THIS build's points and final vertex ids (plain single-process builds)
+    plx::DevBuf nibmap;     // uint32 [capacity / 8]  four bits per hash slot: 0 empty, else 1 + fingerprint % 15 (XCD-sliced neighbour lookups)
 
     // structure
     plx::DevBuf vkeys;      // uint32 [m][DW]        packed vertex keys, in vertex id order

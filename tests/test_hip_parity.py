@@ -66,6 +66,49 @@ def _relabel(lat, o):
     return to_oracle
 
 
+ROUND5_BUILD_DEFAULTS = {"hash_v": 2, "table_fp": 1, "nbr_sliced": 1, "nbr_seed": 1, "flag_own": 1, "assign_evid": 1,
+                         "vertex_order": 1, "nbr_bitmap": 1}
+
+
+@pytest.mark.parametrize("tunes", [
+    {"nbr_sliced": 2},                                         # sliced lookups + neighbours seeded from the embedding
+    {"nbr_sliced": 2, "nbr_seed": 0},                          # sliced lookups alone
+    {"nbr_sliced": 2, "table_fp": 0},                          # occupancy-only nibbles
+    {"nbr_sliced": 2, "vertex_order": 2},                      # Morton-numbered: sliced lookups, no seeding
+    {"hash_v": 1, "flag_own": 0, "assign_evid": 0},            # the round-4 build
+    {"hash_v": 2, "nbr_sliced": 0, "nbr_bitmap": 2},           # linear hash under the round-4 lookups
+    {"flag_own": 1, "assign_evid": 1, "vertex_order": 0},      # own / displaced flags, ids stored by the numbering pass
+], ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()))
+def test_structure_bit_exact_round5_build_paths(plx, small, tunes):
+    """Every build variant of round 5 (linear hash, fingerprinted table words, XCD-sliced neighbour lookups, neighbours
+    seeded from the embedding, own / displaced first-touch flags, ids stored by the numbering pass) builds the oracle's
+    structure bit for bit: vertex keys, per-corner vertex ids, the whole neighbour table."""
+    z, names = small
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    try:
+        for k, v in tunes.items():
+            nv.check(lib.plx_tune(k.encode(), v), "plx_tune")
+        lat = plx.Lattice()
+        for name in names:
+            ref, taps = z[f"{name}/ref"], z[f"{name}/taps"]
+            o = _clean_oracle(ref, taps)
+            lat.build(torch.from_numpy(ref).cuda(), taps)
+            assert lat.m == o.m, name
+            to_oracle = _relabel(lat, o)
+            perm = lat.export(nv.ARRAY_POINT_PERM).astype(np.int64)
+            ev = lat.export(nv.ARRAY_ENTRY_VERTEX)
+            assert np.array_equal(to_oracle[ev], o.entry_vertex[perm].T), name
+            nbr = lat.export(nv.ARRAY_NEIGHBORS)
+            mapped = np.where(nbr >= 0, to_oracle[np.maximum(nbr, 0)], -1)
+            assert np.array_equal(mapped, o.neighbors()[:, :, to_oracle]), name
+            o.close()
+        lat.close()
+    finally:
+        for k, v in ROUND5_BUILD_DEFAULTS.items():
+            nv.check(lib.plx_tune(k.encode(), v), "plx_tune")
+
+
 def test_structure_bit_exact(plx, small):
     """Keys, per-point simplex corners, barycentric weights, neighbour table and CSR
     against the duplicate-free oracle, bit for bit, modulo the (checked) relabelling
