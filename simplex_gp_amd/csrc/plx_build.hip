@@ -311,11 +311,15 @@ __device__ __forceinline__ void order_coords(const float *__restrict__ x, int p,
 // range[2c] = max q_c, range[2c+1] = max -q_c over all points (range[] preset to a very negative number)
 template <int D>
 __global__ __launch_bounds__(kBlock) void coord_range_kernel(const float *__restrict__ x, int n, ScaleArgs sf, int zcurve,
-                                                             int ncoord, int *__restrict__ range)
+                                                             int ncoord, int *__restrict__ range, int stride)
 {
     constexpr int D1 = D + 1;
     __shared__ int red[kBlock / 64][2 * kMaxOrderCoords];
-    const int p = blockIdx.x * kBlock + threadIdx.x;
+    // stride > 1: the range of every stride-th point.  The order keys clamp a coordinate to its range (sortkey_kernel), so a
+    // point beyond the sampled extremes sorts with the outermost cell: the order only places points in memory, and the
+    // extreme cells of a cloud hold a handful of them.  (The full pass read all of x a second time: 23 us at N = 1e6.)
+    const long long pl = ((long long)blockIdx.x * kBlock + threadIdx.x) * stride;
+    const int p = (int)(pl < n ? pl : n - 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int q[D1];
     order_coords<D>(x, min(p, n - 1), sf, zcurve, q);          // a padding thread repeats the last point: no effect on the range
@@ -411,6 +415,46 @@ __global__ __launch_bounds__(kBlock) void sortkey_kernel(const float *__restrict
 }
 
 // ----------------------------------------------------------------------------
+// The point record (round 5): what the embedding knows about one point in a few words -- the first d coordinates of its
+// (fixed-up) nearest zero-colour vertex as packed int16 (DW words) and the rank of every coordinate as one byte each
+// ((d+2)/4... words) -- from which the key of any of its d+1 corners follows with one select and one add per coordinate
+// (h:468-471).  It replaces ekeys, the d+1 packed corner keys per point (144 bytes per point at d = 8 against 32): the
+// embedding wrote 172 MB that the insert fetched back (522 MB by the counters) only to hash every key once.
+template <int D> struct Rec {
+    static constexpr int D1 = D + 1, DW = (D + 1) / 2, WR = (D1 + 3) / 4;
+    static constexpr int W = (DW + WR + 3) & ~3;                   // words per record: whole 16-byte vectors
+};
+
+template <int D>
+__device__ __forceinline__ void rec_load(const uint32_t *__restrict__ prec, size_t p, int (&gr)[D], int (&rk)[D + 1])
+{
+    using R = Rec<D>;
+    uint32_t w[R::W];
+#pragma unroll
+    for (int j = 0; j < R::W / 4; ++j) {
+        const uint4 v = reinterpret_cast<const uint4 *>(prec + p * R::W)[j];
+        w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) gr[i] = (int)(int16_t)((w[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu);
+#pragma unroll
+    for (int i = 0; i <= D; ++i) rk[i] = (int)((w[R::DW + (i >> 2)] >> ((i & 3) * 8)) & 0xFFu);
+}
+
+// key of corner r (packed int16), h:468-471
+template <int D>
+__device__ __forceinline__ void rec_key(const int (&gr)[D], const int (&rk)[D + 1], int r, uint32_t (&kw)[(D + 1) / 2])
+{
+#pragma unroll
+    for (int j = 0; j < (D + 1) / 2; ++j) kw[j] = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const int c = gr[i] + ((rk[i] <= D - r) ? r : (r - (D + 1)));
+        kw[i >> 1] |= ((uint32_t)c & 0xFFFFu) << ((i & 1) * 16);
+    }
+}
+
+// ----------------------------------------------------------------------------
 // embed: h:395-471 for one point per thread, everything in registers
 
 template <int D>
@@ -418,13 +462,13 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__
                                                        const uint32_t *__restrict__ perm, int n, ScaleArgs sf,
                                                        uint32_t *__restrict__ ekeys,
                                                        float *__restrict__ ew, int *__restrict__ counters,
-                                                       uint32_t *__restrict__ prank)
+                                                       uint32_t *__restrict__ prec, int *__restrict__ vrange)
 {
     constexpr int D1 = D + 1;
     constexpr int DW = (D + 1) / 2;
-    constexpr int WR = (D1 + 3) / 4;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= n) return;
+    __shared__ int vred[2 * kMaxOrderCoords];
+    const bool valid = blockIdx.x * kBlock + threadIdx.x < n;
+    const int p = valid ? blockIdx.x * kBlock + threadIdx.x : n - 1;      // (a padding thread repeats the last point and stores nothing)
 
     const size_t row = perm[p];          // original row of the p-th point in lattice order
     float pos[D];
@@ -506,16 +550,54 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__
 
     if (bad) atomicOr(&counters[1], 1);
 
-    // the final ranks, one byte per coordinate: corner r-1 is the +1 blur neighbour of corner r along the coordinate
-    // whose rank is d-r+1 (seed_neighbors_kernel)
-    if (prank) {
-        uint32_t rw[WR];
+    // Range of the blur-axis coordinates a_c = (k_d - k_c) / (d+1), c < d, over this point's d+1 vertices: what the Morton
+    // renumbering lays its codes out over (renumber_vertices; it used to find it with a pass over the vertex keys and a
+    // read-back of its own).  At corner 0 the canonical offsets vanish, a_c(0) = (gr_d - gr_c) / (d+1); corner r adds
+    // canonical[r][rank_d] - canonical[r][rank_c] = +(d+1) for the corners with rank_d <= d-r < rank_c, -(d+1) for those with
+    // rank_c <= d-r < rank_d (h:364-369): the coordinate runs over [a_c(0), a_c(0) + 1] if rank_c > rank_d, else over
+    // [a_c(0) - 1, a_c(0)].  Workgroup maxima through LDS, then one guarded atomicMax per workgroup and bound.
+    if (vrange) {
+        // thread 0's values seed the workgroup maxima; a thread then adds only what exceeds the word it reads (neighbouring
+        // points of the lattice order differ by a step or two, so a handful of LDS atomics per workgroup remain; 256 threads
+        // adding to the same 32 words one after the other cost 100 us per build)
+        int hi[D < kMaxOrderCoords ? D : kMaxOrderCoords], nlo[D < kMaxOrderCoords ? D : kMaxOrderCoords];
 #pragma unroll
-        for (int j = 0; j < WR; ++j) rw[j] = 0;
+        for (int c = 0; c < D; ++c)
+            if (c < kMaxOrderCoords) {
+                const int a0 = (gr[D] - gr[c]) / D1;                 // exact: all coordinates of a lattice point agree mod d+1
+                hi[c] = a0 + (rk[c] > rk[D] ? 1 : 0);
+                nlo[c] = -(a0 - (rk[c] < rk[D] ? 1 : 0));
+                if (threadIdx.x == 0) { vred[2 * c] = hi[c]; vred[2 * c + 1] = nlo[c]; }
+            }
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < D1; ++i) rw[i >> 2] |= ((uint32_t)rk[i] & 0xFFu) << ((i & 3) * 8);
+        for (int c = 0; c < D; ++c)
+            if (c < kMaxOrderCoords) {
+                if (hi[c] > vred[2 * c]) atomicMax(&vred[2 * c], hi[c]);
+                if (nlo[c] > vred[2 * c + 1]) atomicMax(&vred[2 * c + 1], nlo[c]);
+            }
+        __syncthreads();
+        const int nred = 2 * (D < kMaxOrderCoords ? D : kMaxOrderCoords);
+        if ((int)threadIdx.x < nred) {
+            const int v = vred[threadIdx.x];
+            if (v > __hip_atomic_load(&vrange[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&vrange[threadIdx.x], v);
+        }
+    }
+    if (!valid) return;
+
+    // the point record: greedy (first d coordinates) + the final ranks, one byte per coordinate
+    if (prec) {
+        using R = Rec<D>;
+        uint32_t w[R::W];
 #pragma unroll
-        for (int j = 0; j < WR; ++j) prank[(size_t)p * WR + j] = rw[j];
+        for (int j = 0; j < R::W; ++j) w[j] = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) w[i >> 1] |= ((uint32_t)gr[i] & 0xFFFFu) << ((i & 1) * 16);
+#pragma unroll
+        for (int i = 0; i < D1; ++i) w[R::DW + (i >> 2)] |= ((uint32_t)rk[i] & 0xFFu) << ((i & 3) * 8);
+#pragma unroll
+        for (int j = 0; j < R::W / 4; ++j)
+            reinterpret_cast<uint4 *>(prec + (size_t)p * R::W)[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
     }
 
     // h:468-471: corner r has key greedy + canonical[r][rank]
@@ -530,7 +612,7 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__
             kw[i >> 1] |= ((uint32_t)c & 0xFFFFu) << ((i & 1) * 16);
         }
         const size_t idx = (size_t)r * n + p;
-        store_key<DW>(ekeys, idx, kw);
+        if (ekeys) store_key<DW>(ekeys, idx, kw);
         ew[idx] = bary[r];
     }
 }
@@ -642,6 +724,229 @@ __global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restri
     if (valid) eslot[idx] = (disp && own) ? (h | 0x80000000u) : h;
 }
 
+// insert_v = 2 (round 5): one thread per POINT, keys from the point records, a fast path and a parked slow path.
+// The one-corner-per-thread kernel above is bound by the latency of its dependent accesses (table word -> owner's key ->
+// atomic -> atomic) times the waves the chip holds: a wave lives until its SLOWEST lane is through, and with 64 lanes there
+// nearly always is one that has to claim an empty slot or lower an index (two or three dependent atomics, ~10 us), while on
+// a lattice whose corners share vertices 90 % of the lanes only need to see that their key is already in the table under a
+// smaller index -- two plain loads.  Here a thread rebuilds its point's corner keys in registers (one select + add per
+// coordinate; no 144-byte key block per point is written or read), the lanes holding equal keys of the same corner index
+// elect a leader exactly as above, and insert_chains(d) corners go through the FAST path together: table word, owner's
+// record, compare.  Whatever needs an atomic or another probe is PARKED in an LDS queue (leader, its follower lanes, the
+// slot reached) and the workgroup works the queue off at the end with dense lanes; a full queue (lattices where every
+// corner claims a slot) sends the rest through the same loop on the spot.  Same table, same first-touch marks.
+constexpr int insert_chains(int d) { return d <= 10 ? 3 : (d <= 20 ? 2 : 1); }      // (two records of d = 32 are 56 registers)
+constexpr int kInsertQueue = 512;
+
+// the probe loop of one corner from slot h on: returns the slot of its key; *own = this corner put its index there
+template <int D>
+__device__ __forceinline__ uint32_t probe_insert(const uint32_t *__restrict__ prec, uint32_t *__restrict__ table, uint32_t mask,
+                                                 uint32_t *__restrict__ disp, const uint32_t (&k)[(D + 1) / 2], uint32_t e,
+                                                 uint32_t h, bool *own)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    *own = false;
+    for (;;) {
+        uint32_t o = table[h];
+        if (o == kEmpty) {
+            o = atomicCAS(&table[h], kEmpty, e);
+            if (o == kEmpty) { *own = true; return h; }      // claimed an empty slot
+        }
+        if (o == e) return h;
+        int ogr[D], ork[D1];
+        rec_load<D>(prec, (size_t)(o / D1), ogr, ork);
+        uint32_t ko[DW];
+        rec_key<D>(ogr, ork, (int)(o % D1), ko);
+        if (key_equal<DW>(k, ko)) {
+            if (e < o) {
+                if (disp) {
+                    const uint32_t old = atomicMin(&table[h], e);
+                    if (old > e) {
+                        *own = true;
+                        const uint32_t pd = old / D1, rd = old - pd * D1;
+                        atomicOr(&disp[2 * (size_t)pd + (rd >> 5)], 1u << (rd & 31));
+                    }
+                } else {
+                    atomicMin(&table[h], e);
+                }
+            }
+            return h;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void insert_point_kernel(const uint32_t *__restrict__ prec, int n,
+                                                              uint32_t *__restrict__ table, HashSel hs,
+                                                              uint32_t *__restrict__ eslot, int dedupe,
+                                                              uint32_t *__restrict__ disp, int ntiles, int remap)
+{
+    constexpr int D1 = D + 1;
+    constexpr int DW = (D + 1) / 2;
+    constexpr int G = insert_chains(D) < D1 ? insert_chains(D) : D1;
+    __shared__ uint32_t q_pbase[kInsertQueue], q_h[kInsertQueue], q_who[kInsertQueue];      // who = corner r | leader lane << 8
+    __shared__ unsigned long long q_peers[kInsertQueue];                                    // lanes of the wave holding this key
+    __shared__ int q_count;
+    // XCD-aware tile order (tile_index; plx_tune insert_xcd bit 0, off): every XCD inserts one contiguous eighth of the
+    // lattice-ordered points, so that the ~22 corners sharing a vertex meet its table line in ONE L2.  Measured SLOWER
+    // (N = 1e6, l = 1: 183 -> 231 us): eight ranges running side by side claim their shared vertices out of index order
+    // and lower them afterwards, and the in-order sweep loses the "smaller index already in place" fast path it lives on.
+    // The id lookup (bit 1, on) has no such order to lose: 39 -> 34 us.
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    if (threadIdx.x == 0) q_count = 0;
+    __syncthreads();
+    const int p = tile * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = p < n;
+    int gr[D], rk[D1];
+    rec_load<D>(prec, (size_t)(valid ? p : 0), gr, rk);
+    const uint32_t mask = hs.mask;
+    int q_full = 0;                                     // this thread has seen the queue full: no more LDS atomics on it
+
+    for (int r0 = 0; r0 < D1; r0 += G) {
+        uint32_t k[G][DW], h[G], e[G], o[G];
+        unsigned long long peers[G];
+        int leader[G];
+        bool pend[G], own[G], parked[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int r = r0 + g;
+            const bool live = valid && r < D1;
+            rec_key<D>(gr, rk, r < D1 ? r : 0, k[g]);
+            const uint32_t hk = key_hash<D>(k[g], hs);
+            e[g] = (uint32_t)p * D1 + r;
+            leader[g] = lane;
+            peers[g] = 1ull << lane;
+            if (dedupe) {
+                // the lanes of the wave with this key, the lowest of them its leader: candidates by 10 hash bits, confirmed
+                // on the key itself (a lane whose candidate group holds another key probes for itself)
+                unsigned long long grp = __ballot(live);
+#pragma unroll
+                for (int b = 0; b < 10; ++b) {
+                    const bool bit = (hk >> (22 + b)) & 1u;
+                    const unsigned long long mb = __ballot(bit);
+                    grp &= bit ? mb : ~mb;
+                }
+                const int cand = live ? __ffsll((long long)grp) - 1 : lane;
+                bool same = true;
+#pragma unroll
+                for (int j = 0; j < DW; ++j) same = same && (__shfl(k[g][j], cand) == k[g][j]);
+                leader[g] = same ? cand : lane;
+                // the followers of a leader are the lanes of its group that confirmed it
+                const unsigned long long conf = __ballot(live && same);
+                peers[g] = same ? (grp & conf) : (1ull << lane);
+            }
+            h[g] = hash_slot(hk, hs);
+            pend[g] = live && leader[g] == lane;
+            own[g] = false;
+            parked[g] = false;
+        }
+        // fast path: the slot's word, its owner's record, one compare
+#pragma unroll
+        for (int g = 0; g < G; ++g) o[g] = pend[g] ? table[h[g]] : 0u;
+        int ogr[G][D], ork[G][D1];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (pend[g] && o[g] != kEmpty) rec_load<D>(prec, (size_t)(o[g] / D1), ogr[g], ork[g]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (!pend[g]) continue;
+            bool done = false;
+            if (o[g] != kEmpty) {
+                uint32_t ko[DW];
+                rec_key<D>(ogr[g], ork[g], (int)(o[g] % D1), ko);
+                done = key_equal<DW>(k[g], ko) && o[g] <= e[g];          // the key is there under a smaller index: nothing to do
+            }
+            pend[g] = false;
+            if (!done) {
+                const int pos = (q_full == 0) ? atomicAdd(&q_count, 1) : kInsertQueue;
+                if (pos < kInsertQueue) {
+                    q_pbase[pos] = (uint32_t)(p - lane); q_h[pos] = h[g]; q_who[pos] = (uint32_t)(r0 + g) | ((uint32_t)lane << 8);
+                    q_peers[pos] = peers[g];
+                    parked[g] = true;
+                } else {
+                    q_full = 1;
+                    pend[g] = true;                                     // queue full: this corner probes here
+                }
+            }
+        }
+        // the corners that found the queue full (lattices where every corner claims a slot): their probe loops advance
+        // together, table loads back to back, then the owners' records
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) any = any || pend[g];
+            if (!any) break;
+#pragma unroll
+            for (int g = 0; g < G; ++g) o[g] = pend[g] ? table[h[g]] : 0u;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (pend[g] && o[g] == kEmpty) {
+                    o[g] = atomicCAS(&table[h[g]], kEmpty, e[g]);
+                    if (o[g] == kEmpty) { own[g] = true; pend[g] = false; }      // claimed an empty slot
+                }
+                if (pend[g] && o[g] == e[g]) pend[g] = false;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (pend[g]) rec_load<D>(prec, (size_t)(o[g] / D1), ogr[g], ork[g]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (!pend[g]) continue;
+                uint32_t ko[DW];
+                rec_key<D>(ogr[g], ork[g], (int)(o[g] % D1), ko);
+                if (key_equal<DW>(k[g], ko)) {
+                    if (e[g] < o[g]) {
+                        if (disp) {
+                            const uint32_t old = atomicMin(&table[h[g]], e[g]);
+                            if (old > e[g]) {
+                                own[g] = true;
+                                const uint32_t pd = old / D1, rd = old - pd * D1;
+                                atomicOr(&disp[2 * (size_t)pd + (rd >> 5)], 1u << (rd & 31));
+                            }
+                        } else {
+                            atomicMin(&table[h[g]], e[g]);
+                        }
+                    }
+                    pend[g] = false;
+                } else {
+                    h[g] = (h[g] + 1) & mask;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int r = r0 + g;
+            uint32_t hh = h[g];
+            int pk = parked[g] ? 1 : 0;
+            if (dedupe) { hh = __shfl(hh, leader[g]); pk = __shfl(pk, leader[g]); }
+            if (valid && r < D1 && !pk) eslot[(size_t)r * n + p] = (disp && own[g]) ? (hh | 0x80000000u) : hh;
+        }
+    }
+    __syncthreads();
+    const int nq = min(q_count, kInsertQueue);
+    for (int q = threadIdx.x; q < nq; q += kBlock) {
+        const uint32_t pbase = q_pbase[q], who = q_who[q];
+        const int r = (int)(who & 0xFFu), ll = (int)(who >> 8);
+        const uint32_t pl = pbase + (uint32_t)ll;
+        int lgr[D], lrk[D1];
+        rec_load<D>(prec, (size_t)pl, lgr, lrk);
+        uint32_t kq[DW];
+        rec_key<D>(lgr, lrk, r, kq);
+        bool ownq;
+        const uint32_t hq = probe_insert<D>(prec, table, mask, disp, kq, pl * D1 + (uint32_t)r, q_h[q], &ownq);
+        unsigned long long pm = q_peers[q];
+        while (pm) {
+            const int fl = __ffsll((long long)pm) - 1;
+            pm &= pm - 1;
+            eslot[(size_t)r * n + pbase + fl] = (fl == ll && disp && ownq) ? (hq | 0x80000000u) : hq;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------
 // number: first-touch flags per point, counted per workgroup ...
 
@@ -702,17 +1007,37 @@ __global__ __launch_bounds__(kBlock) void flag_own_kernel(const uint32_t *__rest
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
 
-// ... scanned by one workgroup (nblocks <= ~16k for n = 4e6) ...
-__global__ __launch_bounds__(kBlock) void scan_blocks_kernel(int *__restrict__ blockcnt, int nblocks,
-                                                             int *__restrict__ counters)
+// ... scanned by one 1024-thread workgroup, 16 counts per thread and step (nblocks <= ~16k for n = 4e6: one step; the
+// 256-thread, one-count-per-thread form took 16 dependent steps, 10.8 us, for the 3,907 counts of N = 1e6) ...
+constexpr int kWideScanT = 1024, kWideScanIpt = 16;
+__global__ __launch_bounds__(kWideScanT) void scan_blocks_kernel(int *__restrict__ blockcnt, int nblocks,
+                                                                 int *__restrict__ counters)
 {
+    __shared__ int wsum[kWideScanT / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int carry = 0;
-    for (int base = 0; base < nblocks; base += kBlock) {
-        int i = base + threadIdx.x;
-        int v = (i < nblocks) ? blockcnt[i] : 0;
-        int total;
-        int ex = block_exclusive_scan(v, &total);
-        if (i < nblocks) blockcnt[i] = carry + ex;
+    for (int base = 0; base < nblocks; base += kWideScanT * kWideScanIpt) {
+        const int i0 = base + (int)threadIdx.x * kWideScanIpt;
+        int v[kWideScanIpt], sum = 0;
+#pragma unroll
+        for (int k = 0; k < kWideScanIpt; ++k) { v[k] = (i0 + k < nblocks) ? blockcnt[i0 + k] : 0; sum += v[k]; }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = carry + incl - sum, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWideScanT / 64; ++w) { const int t = wsum[w]; if (w < wave) before += t; total += t; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kWideScanIpt; ++k) {
+            if (i0 + k < nblocks) blockcnt[i0 + k] = before;
+            before += v[k];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) counters[0] = carry;   // m
@@ -723,7 +1048,8 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restrict__ flagmask,
                                                         const int *__restrict__ blockoff,
                                                         const uint32_t *__restrict__ eslot,
-                                                        const uint32_t *__restrict__ ekeys, int n,
+                                                        const uint32_t *__restrict__ ekeys,
+                                                        const uint32_t *__restrict__ prec, int n,
                                                         uint32_t *__restrict__ table,
                                                         uint32_t *__restrict__ vkeys, uint32_t *__restrict__ vslot, int fp_on,
                                                         int *__restrict__ evid, uint32_t *__restrict__ vs0,
@@ -736,7 +1062,9 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
     if (p < n) { bits = flagmask[2 * (size_t)p]; bits_hi = flagmask[2 * (size_t)p + 1]; }
     int total;
     int id = blockoff[blockIdx.x] + block_exclusive_scan(__popc(bits) + __popc(bits_hi), &total);
-    if (p >= n) return;
+    if (p >= n || (bits | bits_hi) == 0) return;
+    int gr[D], rk[D1];
+    if (prec) rec_load<D>(prec, (size_t)p, gr, rk);
 #pragma unroll
     for (int r = 0; r < D1; ++r) {
         bool first = (r < 32) ? ((bits >> r) & 1u) : ((bits_hi >> (r - 32)) & 1u);
@@ -744,7 +1072,8 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
             const size_t idx = (size_t)r * n + p;
             const uint32_t slot = eslot[idx] & 0x7FFFFFFFu;
             uint32_t k[DW];
-            load_key<DW>(ekeys, idx, k);
+            if (prec) rec_key<D>(gr, rk, r, k);
+            else load_key<DW>(ekeys, idx, k);
             table[slot] = table_word<D>((uint32_t)id, k, fp_on);
             vslot[id] = slot;
             store_key<DW>(vkeys, (size_t)id, k);
@@ -758,9 +1087,11 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
 
 __global__ __launch_bounds__(kBlock) void ids_kernel(const uint32_t *__restrict__ eslot,
                                                      const uint32_t *__restrict__ table, int n,
-                                                     int *__restrict__ evid, uint32_t idmask)
+                                                     int *__restrict__ evid, uint32_t idmask, int ntiles, int remap)
 {
-    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const int tile = tile_index(ntiles, remap);      // (XCD-aware: the table lines of a vertex are read by one L2)
+    if (tile < 0) return;
+    const int p = tile * kBlock + threadIdx.x;
     if (p >= n) return;
     const size_t idx = (size_t)blockIdx.y * n + p;
     evid[idx] = (int)(table[eslot[idx] & 0x7FFFFFFFu] & idmask);
@@ -797,11 +1128,12 @@ __global__ __launch_bounds__(kBlock) void ids_rest_kernel(const uint32_t *__rest
 // stores that each became a 32-byte write, 699 MB for 81 MB of payload, 420 us on top of the 100 us memset.)
 template <int D>
 __global__ __launch_bounds__(kBlock) void nbr_rows_init_kernel(const uint32_t *__restrict__ vowner, const int *__restrict__ evid,
-                                                               const uint32_t *__restrict__ prank, int n, int m, int64_t mstride,
+                                                               const uint32_t *__restrict__ prec, int n, int m, int64_t mstride,
                                                                int order, int *__restrict__ nbr, uint8_t *__restrict__ vaxis)
 {
     constexpr int D1 = D + 1;
     constexpr int WR = (D1 + 3) / 4;
+    using R = Rec<D>;
     const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (v >= mstride) return;
     int axis_plus = 255, axis_minus = 255, u_plus = -1, u_minus = -1;
@@ -811,7 +1143,7 @@ __global__ __launch_bounds__(kBlock) void nbr_rows_init_kernel(const uint32_t *_
         const int r = (int)(e - p * D1);
         uint32_t rw[WR];
 #pragma unroll
-        for (int j = 0; j < WR; ++j) rw[j] = prank[(size_t)p * WR + j];
+        for (int j = 0; j < WR; ++j) rw[j] = prec[(size_t)p * R::W + R::DW + j];
         const int want_plus = (r == 0) ? 0 : D - r + 1, want_minus = D - r;
 #pragma unroll
         for (int i = 0; i < D1; ++i) {
@@ -1501,7 +1833,7 @@ static bool will_renumber(const plx_lattice *L, int64_t m, int64_t corners)
 }
 
 template <int D>
-static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream)
+static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream, const int *h_range_known = nullptr)
 {
     // corners: how many (point, vertex) incidences stand behind the m vertices -- n (d+1) of the whole job, or the sum of
     // the per-rank vertex counts when only those are known (plx_build_merge); the same number on every rank
@@ -1523,11 +1855,16 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
     PLX_TRY(ensure(L->vslot_alt, (size_t)m * 4 + 16));
     const int nb = ceil_div(m, kBlock);
     // range of every blur-axis coordinate -> exactly the code bits it needs (counters[32 ..] preset to a very negative int)
-    int *range = L->counters.as<int>() + 32;
-    PLX_HIP_TRY(hipMemsetAsync(range, 0x80, 2 * kMaxOrderCoords * sizeof(int), stream));
-    vertex_range_kernel<D><<<nb, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, ca.ncoord, range);
     int h_range[2 * kMaxOrderCoords];
-    PLX_TRY(read_back(L, range, 2 * ca.ncoord, h_range, stream));
+    if (h_range_known) {
+        // (the embedding already found the range of every blur-axis coordinate: it came back with m)
+        memcpy(h_range, h_range_known, sizeof(h_range));
+    } else {
+        int *range = L->counters.as<int>() + 32;
+        PLX_HIP_TRY(hipMemsetAsync(range, 0x80, 2 * kMaxOrderCoords * sizeof(int), stream));
+        vertex_range_kernel<D><<<nb, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, ca.ncoord, range);
+        PLX_TRY(read_back(L, range, 2 * ca.ncoord, h_range, stream));
+    }
     const int key_bits = layout_key_bits(h_range, ca.ncoord, 0, ca.lo, ca.bits, ca.drop, &ca.maxbits);
     vertex_code_kernel<D><<<nb, kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), m, ca, L->sortkey_in.as<unsigned long long>(),
                                                      L->iota.as<uint32_t>());
@@ -1633,14 +1970,15 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     PLX_TRY(ensure(L->sortkey_out, (size_t)n * 8));
     PLX_TRY(ensure(L->sort_temp, radix_temp_bytes(n)));
 
-    PLX_TRY(ensure(L->ekeys, (size_t)E * DW * 4));
+    const bool point_insert = g_insert_v == 2;
+    if (!point_insert) PLX_TRY(ensure(L->ekeys, (size_t)E * DW * 4));
     PLX_TRY(ensure(L->ew, (size_t)E * 4));
     PLX_TRY(ensure(L->eslot, (size_t)E * 4));
     PLX_TRY(ensure(L->evid, (size_t)E * 4));
     PLX_TRY(ensure(L->flagmask, (size_t)n * 8));
-    const bool want_rank = g_hash_v == 2 && g_nbr_sliced != 0 && g_nbr_seed != 0;
-    constexpr int WR = (D1 + 3) / 4;
-    if (want_rank) PLX_TRY(ensure(L->prank, (size_t)n * WR * 4));
+    const bool want_rank = g_hash_v == 2 && g_nbr_sliced != 0 && g_nbr_seed != 0;      // the neighbour seeding reads the ranks
+    const bool want_rec = want_rank || point_insert;
+    if (want_rec) PLX_TRY(ensure(L->prank, (size_t)n * Rec<D>::W * 4 + 16));
     L->prank_valid = false;
     PLX_TRY(ensure(L->blockcnt, (size_t)(nblocks + 1) * 4));
     PLX_TRY(ensure(L->table, (size_t)cap * 4));
@@ -1656,7 +1994,9 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
             // range of every rounded coordinate -> exactly the key bits it needs (counters[32 ..] preset to a very negative int)
             int *range = L->counters.as<int>() + 32;
             PLX_HIP_TRY(hipMemsetAsync(range, 0x80, 2 * kMaxOrderCoords * sizeof(int), stream));
-            coord_range_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, n, sf, oa.zcurve, oa.ncoord, range);
+            const int rstride = (g_order_sample > 1 && n >= (1 << 16)) ? g_order_sample : 1;
+            coord_range_kernel<D><<<ceil_div(ceil_div(n, rstride), kBlock), kBlock, 0, stream>>>(d_ref, n, sf, oa.zcurve, oa.ncoord, range,
+                                                                                                 rstride);
             int h_range[2 * kMaxOrderCoords];
             PLX_TRY(read_back(L, range, 2 * oa.ncoord, h_range, stream));
             key_bits = shard_bits + layout_key_bits(h_range, oa.ncoord, shard_bits, oa.lo, oa.bits, oa.drop, &oa.maxbits);
@@ -1676,18 +2016,28 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     } else {
         iota_kernel<<<nblocks, kBlock, 0, stream>>>(L->perm.as<uint32_t>(), n);
     }
-    embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, L->perm.as<uint32_t>(), n, sf, L->ekeys.as<uint32_t>(),
-                                                    L->ew.as<float>(), L->counters.as<int>(),
-                                                    want_rank ? L->prank.as<uint32_t>() : nullptr);
+    // counters[30] = m, [31] = key-range error flag, [32 .. 63] = range of the vertices' blur-axis coordinates: one read-back
+    int *cnt = L->counters.as<int>() + 30;
+    const bool embed_range = g_embed_vrange != 0 && !L->for_merge && g_vertex_order != 0;
+    if (embed_range) PLX_HIP_TRY(hipMemsetAsync(cnt + 2, 0x80, 2 * kMaxOrderCoords * sizeof(int), stream));
+    embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, L->perm.as<uint32_t>(), n, sf,
+                                                    point_insert ? nullptr : L->ekeys.as<uint32_t>(),
+                                                    L->ew.as<float>(), cnt, want_rec ? L->prank.as<uint32_t>() : nullptr,
+                                                    embed_range ? cnt + 2 : nullptr);
     mark();
     // flag_own: the insert marks owners (bit 31 of eslot: the table must not need that bit) and displaced corners (flagmask
     // doubles as the displaced mask until flag_own_kernel turns it into the first-touch mask in place)
     const bool flag_own = g_flag_own != 0 && L->table_bits <= 31;
     if (flag_own) PLX_HIP_TRY(hipMemsetAsync(L->flagmask.p, 0, (size_t)n * 8, stream));
     const int plane_fast = (g_insert_plane_fast != 0 && nblocks <= 65535) ? 1 : 0;
-    insert_kernel<D><<<plane_fast ? dim3(D1, nblocks) : dim3(nblocks, D1), kBlock, 0, stream>>>(
-        L->ekeys.as<uint32_t>(), n, L->table.as<uint32_t>(), hash_sel(L), L->eslot.as<uint32_t>(), g_insert_dedupe,
-        plane_fast, flag_own ? L->flagmask.as<uint32_t>() : nullptr);
+    if (point_insert)
+        insert_point_kernel<D><<<tile_grid(nblocks, g_insert_xcd & 1), kBlock, 0, stream>>>(
+            L->prank.as<uint32_t>(), n, L->table.as<uint32_t>(), hash_sel(L), L->eslot.as<uint32_t>(), g_insert_dedupe,
+            flag_own ? L->flagmask.as<uint32_t>() : nullptr, nblocks, g_insert_xcd & 1);
+    else
+        insert_kernel<D><<<plane_fast ? dim3(D1, nblocks) : dim3(nblocks, D1), kBlock, 0, stream>>>(
+            L->ekeys.as<uint32_t>(), n, L->table.as<uint32_t>(), hash_sel(L), L->eslot.as<uint32_t>(), g_insert_dedupe,
+            plane_fast, flag_own ? L->flagmask.as<uint32_t>() : nullptr);
     mark();
     L->flags_valid = !L->for_merge;      // the first-touch bits of this build's points stay in flagmask (plx_first.hip reads them)
     if (flag_own)
@@ -1696,9 +2046,9 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     else
         flag_kernel<D1><<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
                                                         L->flagmask.as<uint32_t>(), L->blockcnt.as<int>());
-    scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
-    int h_cnt[2];
-    PLX_TRY(read_back(L, L->counters.as<int>(), 2, h_cnt, stream));   // m sizes everything below
+    scan_blocks_kernel<<<1, kWideScanT, 0, stream>>>(L->blockcnt.as<int>(), nblocks, cnt);
+    int h_cnt[2 + 2 * kMaxOrderCoords];
+    PLX_TRY(read_back(L, cnt, embed_range ? 2 + 2 * kMaxOrderCoords : 2, h_cnt, stream));   // m sizes everything below
     if (h_cnt[1] != 0) {
         set_error("a lattice coordinate left the int16 key range (|x/lengthscale| too large, NaN or Inf)");
         return PLX_ERR_KEY_RANGE;
@@ -1715,19 +2065,21 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     const bool ids_final = L->for_merge || !will_renumber(L, m, E);
     const bool assign_evid = g_assign_evid != 0 && ids_final;
     assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->blockcnt.as<int>(),
-                                                     L->eslot.as<uint32_t>(), L->ekeys.as<uint32_t>(), n,
+                                                     L->eslot.as<uint32_t>(), point_insert ? nullptr : L->ekeys.as<uint32_t>(),
+                                                     point_insert ? L->prank.as<uint32_t>() : nullptr, n,
                                                      L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>(), fp_on,
                                                      assign_evid ? L->evid.as<int>() : nullptr,
                                                      (L->vs0_valid && ids_final) ? L->vs0.as<uint32_t>() : nullptr,
                                                      (want_rank && ids_final) ? L->vowner.as<uint32_t>() : nullptr);
-    if (!L->for_merge) PLX_TRY(renumber_vertices<D>(L, E, stream));   // (a job built from local rows renumbers the union, after the merge)
+    if (!L->for_merge) PLX_TRY(renumber_vertices<D>(L, E, stream, embed_range ? h_cnt + 2 : nullptr));   // (a job built from local rows renumbers the union, after the merge)
     mark();
     if (assign_evid)
         ids_rest_kernel<<<nblocks, kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->flagmask.as<uint32_t>(), L->table.as<uint32_t>(), n, D1,
                                                         L->evid.as<int>(), L->table_idmask);
     else
-        ids_kernel<<<dim3(nblocks, D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n, L->evid.as<int>(),
-                                                             L->table_idmask);
+        ids_kernel<<<dim3(tile_grid(nblocks, g_insert_xcd >> 1), D1), kBlock, 0, stream>>>(L->eslot.as<uint32_t>(), L->table.as<uint32_t>(), n,
+                                                                                           L->evid.as<int>(), L->table_idmask, nblocks,
+                                                                                           g_insert_xcd >> 1);
     L->prank_valid = want_rank && !L->for_merge;
     mark();
     PLX_HIP_TRY(hipGetLastError());
@@ -1847,7 +2199,7 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
                                                            L->merge_slot.as<uint32_t>());
     merge_flag_kernel<<<nblocks, kBlock, 0, stream>>>(L->merge_slot.as<uint32_t>(), L->table.as<uint32_t>(), (int)M,
                                                       L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>());
-    scan_blocks_kernel<<<1, kBlock, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
+    scan_blocks_kernel<<<1, kWideScanT, 0, stream>>>(L->blockcnt.as<int>(), nblocks, L->counters.as<int>());
     int h_cnt[2];
     PLX_TRY(read_back(L, L->counters.as<int>(), 2, h_cnt, stream));
     const int m = h_cnt[0];

@@ -77,6 +77,11 @@ struct Tune {
     int hash_v = 2;   // vertex table hash: 1 = 64-bit mix of the packed key words; 2 = linear in the key coordinates + one multiplicative mix (a neighbour's hash is the vertex's own plus a constant, slot = top bits)
     int table_fp = 1;   // hash_v = 2, m < 2^24: the table word of a numbered vertex carries 8 fingerprint bits of its key above the id
     int nbr_sliced = 1;   // neighbour lookups served by the XCD that owns the slot's eighth of a 4-bit-per-slot map (L2 resident): 0 never, 1 when the lattice keeps first-touch numbering and m >= 2^20, 2 always (needs hash_v = 2)
+    int insert_xcd = 2;   // XCD-aware tile order (each XCD one contiguous eighth of the points): bit 0 the point-per-thread insert (measured slower), bit 1 the id lookup
+    int order_sample = 8;   // point-order key layout from the coordinate ranges of every k-th point (1: of all points); from 65,536 points up
+    int embed_vrange = 0;   // 1: the embedding finds the range of the vertices' blur-axis coordinates (Morton renumbering) itself -- no pass over the vertex keys, no read-back of its own; measured: saves 22 us there, costs the embedding 30 (l = 1) to 70 us (l = 0.25): off
+    int blk_sort = 5;   // per-block LDS sort of the block tables: 0 = (vertex, corner) pairs, 4 bits per pass; 4 / 5 / 6 = corner index packed under the vertex id, keys only, that many bits per pass
+    int insert_v = 2;   // hashed insert: 1 = one thread per corner over the packed corner keys (ekeys); 2 = one thread per point over the point records, several probe chains in flight per thread
     int flag_own = 1;   // first-touch flags without table gathers: the insert marks who claimed / lowered a slot (top bit of eslot) and who was displaced
     int assign_evid = 1;   // the numbering pass stores the vertex id of every first-touch corner itself when the numbering is final; the id lookup then serves the other corners only
     int nbr_seed = 1;   // sliced neighbour lookups: the +1 neighbour that is a corner of the vertex's own first-touch simplex comes from the embedding, no lookup
@@ -121,6 +126,11 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_nbr_window (plx::tl_tune->nbr_window)
 #define g_perm_rows (plx::tl_tune->perm_rows)
 #define g_splat_first (plx::tl_tune->splat_first)
+#define g_insert_xcd (plx::tl_tune->insert_xcd)
+#define g_order_sample (plx::tl_tune->order_sample)
+#define g_embed_vrange (plx::tl_tune->embed_vrange)
+#define g_blk_sort (plx::tl_tune->blk_sort)
+#define g_insert_v (plx::tl_tune->insert_v)
 #define g_flag_own (plx::tl_tune->flag_own)
 #define g_assign_evid (plx::tl_tune->assign_evid)
 #define g_nbr_seed (plx::tl_tune->nbr_seed)
@@ -181,7 +191,7 @@ struct plx_lattice {
     plx::DevBuf counters;   // int32  [8]            {m, error flag, ...}
     plx::DevBuf sort_keys_in, sort_vals_in, sort_vals_out, sort_temp;
     plx::DevBuf slotmap;    // uint32 [capacity / 32] one bit per hash slot: occupied (neighbour lookups of large lattices)
-    plx::DevBuf prank;      // uint32 [n][ceil((d+1)/4)] one byte per coordinate: its rank in the point's simplex (h:427-457), lattice order
+    plx::DevBuf prank;      // uint32 [n][W]         the point records (plx_build.hip, Rec<D>): packed greedy coordinates + one rank byte per coordinate (h:427-457), lattice order
     plx::DevBuf vowner;     // uint32 [m]            first-touch corner e = p (d+1) + r of every vertex (first-touch numbering; neighbour seeding)
     plx::DevBuf vs0;        // uint32 [m]            pre-mix hash of every vertex key (hash_v = 2; sliced neighbour lookups)
     bool vs0_valid = false;
@@ -307,7 +317,7 @@ int selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, hipStrea
 // block tables built in LDS, one workgroup per block (256-thread blocks): sort by vertex + every per-corner record;
 // the block's vertex list lands in rows_tmp[b * cpb + row] and is compacted once the row offsets are scanned
 int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin, int n_own, int P, int d1, int cpb, int vbits,
-                         int ipt, int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
+                         int64_t m_vertices, int ipt, int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
                          int *rows, hipStream_t stream);
 int compact_block_rows(const int *rows_tmp, const int *brow_ptr, int cpb, int64_t nblocks, int *brow_vid, hipStream_t stream);
 // plx_splat.hip / plx_blur.hip / plx_slice.hip

@@ -117,15 +117,21 @@ int selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, hipStrea
 // Replaces a global radix sort of all nnz keys + a count pass + a fill pass (0.37 + 0.02 + 0.11 ms at N = 1e6, d = 8).
 // The block's vertex list goes to a block-strided scratch (rows_tmp[b * cpb + row]); blk_compact_kernel moves it
 // behind the row offsets once those are scanned.
-template <int IPT>
+// PACKED (round 5): the block-local corner index rides in the low CB bits of the key (vertex id above it) and the sort moves
+// keys only, RBITS bits per pass -- half the LDS exchange traffic per pass of the (key, value) form and fewer passes than
+// rocPRIM's default 4 bits (20 key bits: 5 -> 4 passes).  The sort covers the vertex bits alone and is stable, so equal
+// vertices keep (corner, point) order exactly as before: same tables, bit for bit.  Needs vbits + CB <= 32 (with 2^vbits > m).
+template <int IPT, bool PACKED, int RBITS>
 __global__ __launch_bounds__(256) void blk_sort_fill_kernel(const int *__restrict__ evid, const float *__restrict__ ew, int n,
                                                             int own_begin, int n_own, int P, int d1, int cpb, int vbits,
                                                             uint16_t *__restrict__ bc_pt, float *__restrict__ bc_w,
                                                             uint16_t *__restrict__ srow, int64_t sstride,
                                                             int *__restrict__ rows_tmp, int *__restrict__ rows)
 {
-    using Sort = rocprim::block_radix_sort<uint32_t, 256, IPT, uint32_t>;
-    __shared__ typename Sort::storage_type storage;
+    using Sort = rocprim::block_radix_sort<uint32_t, 256, IPT, uint32_t, 1, 1, RBITS>;
+    using SortKeys = rocprim::block_radix_sort<uint32_t, 256, IPT, rocprim::empty_type, 1, 1, RBITS>;
+    constexpr int CB = IPT == 16 ? 12 : 13;            // bits of a block-local corner index (256 * IPT corners)
+    __shared__ union { typename Sort::storage_type pairs; typename SortKeys::storage_type keys; } storage;
     __shared__ uint32_t edge_key[256 + 1];             // first key of every thread (+ a sentinel)
     __shared__ uint32_t last_key[256];                 // last key of every thread
     __shared__ int wave_sum[4];
@@ -141,12 +147,19 @@ __global__ __launch_bounds__(256) void blk_sort_fill_kernel(const int *__restric
             const int r = c / np, i = c - r * np;
             keys[j] = (uint32_t)evid[(size_t)r * n + own_begin + p0 + i];
             vals[j] = (uint32_t)c;
+            if (PACKED) keys[j] = (keys[j] << CB) | (uint32_t)c;
         } else {
             keys[j] = 0xFFFFFFFFu;                      // padding sorts behind every vertex (vbits <= 30)
             vals[j] = 0u;
         }
     }
-    Sort().sort(keys, vals, storage, 0, (unsigned)vbits + 1);   // + 1: the padding key's top bit must take part
+    if (PACKED) {
+        SortKeys().sort(keys, storage.keys, (unsigned)CB, (unsigned)(CB + vbits));   // (vbits: 2^vbits > m, so the padding's all-ones field sorts last)
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) { vals[j] = keys[j] & ((1u << CB) - 1u); keys[j] = keys[j] == 0xFFFFFFFFu ? 0xFFFFFFFFu : keys[j] >> CB; }
+    } else {
+        Sort().sort(keys, vals, storage.pairs, 0, (unsigned)vbits + 1);   // + 1: the padding key's top bit must take part
+    }
     // neighbours across threads: the last key of the thread before, the first key of the thread after
     edge_key[tid] = keys[0];
     last_key[tid] = keys[IPT - 1];
@@ -226,16 +239,25 @@ __global__ __launch_bounds__(256) void blk_compact_kernel(const int *__restrict_
 }
 
 int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin, int n_own, int P, int d1, int cpb, int vbits,
-                         int ipt, int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
+                         int64_t m_vertices, int ipt, int64_t nblocks, uint16_t *bc_pt, float *bc_w, uint16_t *srow, int64_t sstride, int *rows_tmp,
                          int *rows, hipStream_t stream)
 {
     if ((ipt != 16 && ipt != 24) || cpb > 256 * ipt || vbits > 30) { set_error("sort_fill_blocks_lds: %d corners per thread, %d per block", ipt, cpb); return PLX_ERR_INVALID; }
-    if (ipt == 16)
-        blk_sort_fill_kernel<16><<<(unsigned)nblocks, 256, (size_t)cpb * 2, stream>>>(evid, ew, n, own_begin, n_own, P, d1, cpb, vbits,
-                                                                                      bc_pt, bc_w, srow, sstride, rows_tmp, rows);
-    else
-        blk_sort_fill_kernel<24><<<(unsigned)nblocks, 256, (size_t)cpb * 2, stream>>>(evid, ew, n, own_begin, n_own, P, d1, cpb, vbits,
-                                                                                      bc_pt, bc_w, srow, sstride, rows_tmp, rows);
+    const int cb = ipt == 16 ? 12 : 13;
+    // packed keys: the vertex field must leave the all-ones value to the padding (ids < m < 2^vb) and fit above the corner bits
+    const int vb = vbits + (((int64_t)1 << vbits) == (int64_t)m_vertices ? 1 : 0);
+    const int mode = (g_blk_sort != 0 && vb + cb <= 32) ? g_blk_sort : 0;      // 0: (key, value) pairs, 4 bits per pass
+#define PLX_BLK_SORT(IPT, PACKED, RBITS)                                                                                        \
+    blk_sort_fill_kernel<IPT, PACKED, RBITS><<<(unsigned)nblocks, 256, (size_t)cpb * 2, stream>>>(                              \
+        evid, ew, n, own_begin, n_own, P, d1, cpb, mode ? vb : vbits, bc_pt, bc_w, srow, sstride, rows_tmp, rows)
+    if (ipt == 16) {
+        if (mode == 0) PLX_BLK_SORT(16, false, 4); else if (mode == 4) PLX_BLK_SORT(16, true, 4);
+        else if (mode == 6) PLX_BLK_SORT(16, true, 6); else PLX_BLK_SORT(16, true, 5);
+    } else {
+        if (mode == 0) PLX_BLK_SORT(24, false, 4); else if (mode == 4) PLX_BLK_SORT(24, true, 4);
+        else if (mode == 6) PLX_BLK_SORT(24, true, 6); else PLX_BLK_SORT(24, true, 5);
+    }
+#undef PLX_BLK_SORT
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }

@@ -67,7 +67,7 @@ def _relabel(lat, o):
 
 
 ROUND5_BUILD_DEFAULTS = {"hash_v": 2, "table_fp": 1, "nbr_sliced": 1, "nbr_seed": 1, "flag_own": 1, "assign_evid": 1,
-                         "vertex_order": 1, "nbr_bitmap": 1}
+                         "vertex_order": 1, "nbr_bitmap": 1, "insert_v": 2, "insert_dedupe": 2}
 
 
 @pytest.mark.parametrize("tunes", [
@@ -75,7 +75,9 @@ ROUND5_BUILD_DEFAULTS = {"hash_v": 2, "table_fp": 1, "nbr_sliced": 1, "nbr_seed"
     {"nbr_sliced": 2, "nbr_seed": 0},                          # sliced lookups alone
     {"nbr_sliced": 2, "table_fp": 0},                          # occupancy-only nibbles
     {"nbr_sliced": 2, "vertex_order": 2},                      # Morton-numbered: sliced lookups, no seeding
-    {"hash_v": 1, "flag_own": 0, "assign_evid": 0},            # the round-4 build
+    {"hash_v": 1, "flag_own": 0, "assign_evid": 0, "insert_v": 1},   # the round-4 build
+    {"insert_v": 1},                                           # corner-per-thread insert under the round-5 hash and flags
+    {"insert_v": 2, "hash_v": 1, "insert_dedupe": 0},          # point-per-thread insert, 64-bit mix hash, every lane probes
     {"hash_v": 2, "nbr_sliced": 0, "nbr_bitmap": 2},           # linear hash under the round-4 lookups
     {"flag_own": 1, "assign_evid": 1, "vertex_order": 0},      # own / displaced flags, ids stored by the numbering pass
 ], ids=lambda t: ",".join(f"{k}={v}" for k, v in t.items()))

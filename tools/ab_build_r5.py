@@ -77,6 +77,8 @@ for ell in args.ells:
                     r["identical"] = True
                 else:
                     r["identical"] = {k: bool(np.array_equal(cur[k], base[k])) for k in cur}
+                    r["out_rel_diff"] = float(np.linalg.norm(cur["out"].astype(np.float64) - base["out"]) / np.linalg.norm(base["out"]))
+                    r["same_key_set"] = bool(np.array_equal(np.unique(cur["keys"], axis=0), np.unique(base["keys"], axis=0))) if cur["keys"].shape[0] < 2_000_000 else None
                 del cur
     for vi, r in enumerate(res):
         r.pop("lat").close()
