@@ -215,12 +215,25 @@ __global__ __launch_bounds__(kBlock) void splat_extras_kernel(const int *__restr
     values[v] = acc;
 }
 
+static int ensure_first_body(plx_lattice *L, hipStream_t stream);
+
+// first_ready is set only once the list is built (or known not to apply): a transient failure -- an allocation, the
+// read-back -- is reported and the next call tries again, instead of pinning the lattice to the sorted-corner path for the
+// rest of its build with n_extra left stale
 int ensure_first(plx_lattice *L, hipStream_t stream)
 {
     if (L->first_ready) return PLX_OK;
     PLX_TRY(refuse_under_capture(stream, "the first-touch splat list of this lattice"));
-    L->first_ready = true;
     L->use_first = false;
+    L->n_extra = 0;
+    const int rc = ensure_first_body(L, stream);
+    if (rc != PLX_OK) { L->use_first = false; L->n_extra = 0; return rc; }
+    L->first_ready = true;
+    return PLX_OK;
+}
+
+static int ensure_first_body(plx_lattice *L, hipStream_t stream)
+{
     const int64_t nnz = L->nnz, m = L->m;
     const int n = (int)L->n, d1 = L->d + 1;
     if (g_splat_first == 0 || L->n_shards != 1 || L->partial_cover || !L->flags_valid || nnz == 0 || nnz != (int64_t)n * d1) return PLX_OK;

@@ -357,7 +357,8 @@ def column_sharded_mll(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4
     precond = model.preconditioner(x, pre_size, K=K) if pre_size > 0 else None
     t = 1 + num_probes
     lo, hi = column_bounds(t, world, rank)
-    stats = torch.zeros(2, dtype=torch.float64, device=y.device)      # [r^T u, sum over local probes of weight_i * quadrature_i]
+    # [r^T u, sum over local probes of weight_i * quadrature_i, logdet(P) as rank 0 computed it]
+    stats = torch.zeros(3, dtype=torch.float64, device=y.device)
     surrogate = None
     info = {"iterations": 0}
     with torch.no_grad():
@@ -390,8 +391,13 @@ def column_sharded_mll(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4
             surrogate = surrogate - (u * r).sum() + 0.5 * (u * KV[:, :1]).sum()
         if Zl.shape[1]:
             surrogate = surrogate - 0.5 * (W * KV[:, p0:]).sum() / num_probes
+    # logdet(P) travels inside the reduced statistics, contributed by ONE rank, so that every rank adds the same number:
+    # the replicated factors are built by the same deterministic kernels from the same inputs, but nothing else in the
+    # estimator relies on that, and a rank whose pivots differed would otherwise return a different value silently
+    if precond is not None and rank == 0:
+        stats[2] = float(precond.logdet())
     all_reduce_sum(stats, group)
-    logdet = stats[1] / num_probes + (precond.logdet() if precond is not None else 0.0)
+    logdet = stats[1] / num_probes + stats[2]
     value = -0.5 * stats[0] - 0.5 * logdet - 0.5 * n * math.log(2 * math.pi)
     if surrogate is None:                                             # a rank without columns: value only, no gradient share
         surrogate = (model.mean * 0.0).sum()

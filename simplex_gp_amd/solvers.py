@@ -189,10 +189,15 @@ class LatticePreconditioner:
         appears in the estimator, nothing more.
     """
 
+    MAX_RANK = 1024          # factor columns the native passes hold (plx_pcg.hip: factor_shape_ok)
+
     def __init__(self, lat, outputscale, noise, rank, rel_tol=1e-6, batch=12, factor_dtype=torch.float16):
         import ctypes
         from . import _native as nv
         lib = nv.lib()
+        if min(int(rank), lat.n_owned) > self.MAX_RANK:
+            raise ValueError(f"LatticePreconditioner holds at most {self.MAX_RANK} factor columns (rank {rank}): use "
+                             "PivotedCholeskyPreconditioner")
         s, noise = float(outputscale), float(noise)
         dev = lat.device
         n = lat.n_owned
@@ -204,6 +209,7 @@ class LatticePreconditioner:
         self.lat, self.n, self.rank, self.kp, self.ld, self.noise, self.outputscale = lat, n, k, kp, ld, noise, s
         self.build_id = lat.build_id        # a lattice object is recycled by the cache: the factor belongs to THIS build of it
         self.ref = None
+        self.ref_key = None                 # (x.data_ptr, x._version, lengthscale._version, shape) the positions were derived from
         self.Lt = torch.zeros(kp, ld, dtype=torch.float32, device=dev)
         diag = torch.full((n,), s, dtype=torch.float32, device=dev)
         row_rank = torch.empty(lat.n, dtype=torch.int32, device=dev)          # caller row of every lattice position (uint32 bits)
@@ -235,7 +241,8 @@ class LatticePreconditioner:
                                                         _vp(row_rank), n, float(rel_tol * s), _vp(accepted), _vp(work), stream),
                              "plx_pchol_factor_batch")
                     a = int(accepted.item())                   # the one host read-back of the batch
-                    assert 1 <= a <= nb, (a, nb)
+                    if not 1 <= a <= nb:               # (an assert would vanish under python -O and a == 0 would spin forever)
+                        raise RuntimeError(f"plx_pchol_factor_batch accepted {a} of {nb} speculated pivots")
                     m += a
                     self.batches += 1
                     # speculation depth follows what the lattice accepts: dense kernels (few, strongly coupled points)
@@ -444,7 +451,13 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     Lanczos tridiagonals rebuilt from the CG coefficients (mBCG), shape [t, k, k].
     """
     floor = _iteration_floor(max_iter, want_tridiag, min_iter, min_tridiag_iter)
-    if lattice_rows and isinstance(precond, LatticePreconditioner) and reduce is None and _native_ok(B) and B.shape[1] <= 16:
+    if lattice_rows:
+        # only the native iteration works in the preconditioner's row order: precond.solve() takes caller-order rows, and
+        # a silently permuted P^-1 is a different preconditioner from the one behind the probes and logdet(P)
+        if not (isinstance(precond, LatticePreconditioner) and reduce is None and _native_ok(B) and B.shape[1] <= 16):
+            raise ValueError("batched_cg(lattice_rows=True) needs a LatticePreconditioner, reduce=None and a contiguous fp32 "
+                             "CUDA right-hand side of at most 16 columns (got %s, reduce=%s, B %s %s)"
+                             % (type(precond).__name__, "set" if reduce is not None else None, tuple(B.shape), B.dtype))
         return _batched_pcg_native(matmul, B, precond, max_iter, tol, want_tridiag, check_every, matmul_dot, floor)
     if precond is not None:
         return _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_every, floor)
@@ -647,9 +660,12 @@ class LatticeGP(nn.Module):
             ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
             ref = ref if ref.is_contiguous() else ref.contiguous()
             pre = cg_args.get("precond")
-            if isinstance(pre, LatticePreconditioner) and pre.ref is not None and pre.ref is not ref and pre.ref.shape == ref.shape \
-                    and torch.equal(pre.ref, ref):
-                ref = pre.ref          # the same positions as a fresh tensor (no K handed over): solve on the preconditioner's lattice
+            if isinstance(pre, LatticePreconditioner) and pre.ref is not None and pre.ref is not ref and pre.ref_key is not None \
+                    and pre.ref_key == (x.data_ptr(), x._version, self.kernel.lengthscale._version, tuple(x.shape)):
+                # the same x and lengthscale the preconditioner was built from, as a fresh tensor (no K handed over): solve
+                # on the preconditioner's lattice.  (Decided from the tensors' identities and version counters: comparing
+                # the n x d positions on the device cost a pass and a host synchronisation per solve.)
+                ref = pre.ref
             lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
             s, noise = self.outputscale, self.noise
             lat.set_lattice_row_order(True)
@@ -687,12 +703,15 @@ class LatticeGP(nn.Module):
         built and applied natively, in the row order of the lattice the solve runs on (LatticePreconditioner)."""
         from . import lattice_kernel as lk
         with torch.no_grad():
-            if lk.LatticeFilterGeneral.method is None and x.is_cuda and x.dtype == torch.float32:
+            # (the native passes hold at most LatticePreconditioner.MAX_RANK factor columns: larger ranks take the torch form)
+            if lk.LatticeFilterGeneral.method is None and x.is_cuda and x.dtype == torch.float32 \
+                    and min(int(rank), x.shape[0]) <= LatticePreconditioner.MAX_RANK:
                 ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
                 ref = ref if ref.is_contiguous() else ref.contiguous()
                 lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
                 pre = LatticePreconditioner(lat, self.outputscale, self.noise, rank, factor_dtype=factor_dtype)
                 pre.ref = ref          # the positions its lattice was built on (kept alive: the lattice-cache key)
+                pre.ref_key = (x.data_ptr(), x._version, self.kernel.lengthscale._version, tuple(x.shape))
                 return pre
             K = self.kernel(x, x) if K is None else K
             return PivotedCholeskyPreconditioner(K.matmul, x.shape[0], self.outputscale, self.noise, rank,

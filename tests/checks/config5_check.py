@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import simplex_gp_amd as plx
 from simplex_gp_amd import solvers
 from oracle import oracle
-from tools.ab_apply import timeit
+from tools.archive.ab_apply import timeit
 
 n, d = 10623, 18
 g = torch.Generator().manual_seed(1234)

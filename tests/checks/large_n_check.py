@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from oracle import oracle
-from tools.ab_apply import timeit, RBF1
+from tools.archive.ab_apply import timeit, RBF1
 n, d = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000, 8
 g = torch.Generator().manual_seed(1234)
 x = torch.randn(n, d, generator=g); v = torch.randn(n, 1, generator=g)

@@ -4,7 +4,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
-from tools.ab_apply import timeit, RBF1
+from tools.archive.ab_apply import timeit, RBF1
 
 def morton(q, bits):
     n, d = q.shape

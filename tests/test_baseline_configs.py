@@ -385,6 +385,28 @@ def test_bench_single_gpu_json_contract():
     assert res["config"]["builds_in_timed_region"] == 1
 
 
+def test_bench_train_step_phases_add_up(plx):
+    """bench.py's training-step leg: the reported phases (median of three profiled steps) add up to the synchronised step
+    they were taken from within 25 %, and the un-synchronised step_ms is not above it (round 4 reported an `optimizer` phase
+    of 73 ms inside a 12.8 ms step: one outlier step)."""
+    import bench
+
+    class Ctx:
+        dev = torch.device("cuda:0")
+
+        @staticmethod
+        def sync():
+            torch.cuda.synchronize()
+
+    out = bench.train_step_leg(Ctx, 60_000, 4, lambda: plx.RBFLattice(order=1, ard_num_dims=4), pre_sizes=(0, 100), steps=2)
+    for key in ("pre_size_0", "pre_size_100"):
+        leg = out[key]
+        assert leg["phases_from"].startswith("median")
+        assert abs(leg["phases_sum_ms"] - leg["profiled_step_ms"]) <= 0.25 * leg["profiled_step_ms"], leg
+        assert leg["step_ms"] <= 1.25 * leg["profiled_step_ms"], leg
+        assert all(v >= 0 for v in leg["phases_ms"].values())
+
+
 @pytest.mark.parametrize("name,n,d", [("houseelectric (10 % of its rows)", 204_928, 11), ("precipitation", 628_474, 3),
                                       ("keggdirected", 48_827, 20), ("elevators", 16_599, 17), ("protein", 45_730, 9)])
 def test_published_shapes_against_the_oracle(plx, name, n, d):

@@ -135,8 +135,11 @@ def test_sharded_mvm_single_process(plx):
     assert torch.equal(op.matmul(v), plx.Lattice().build(x, taps).apply(v))
 
 
-def test_snelson_config1_on_gpu(plx, golden_dir):
-    """BASELINE.json config 1 on the HIP path: |MLL_lattice - MLL_exact| < 0.1 (tests/train_snelson.py:96)."""
+@pytest.mark.parametrize("pre_size", [0, 100])
+def test_snelson_config1_on_gpu(plx, golden_dir, pre_size):
+    """BASELINE.json config 1 on the HIP path: |MLL_lattice - MLL_exact| < 0.1 (tests/train_snelson.py:96).  pre_size = 100 is
+    what the reference's own test trains with (max_preconditioner_size(100), tests/train_snelson.py:48-55): the native
+    pivoted-Cholesky preconditioner then runs inside every training solve (rank 100 of n = 200)."""
     from simplex_gp_amd import solvers
     sn = np.loadtxt(os.path.join(golden_dir, "snelson.csv"), delimiter=",", skiprows=1).astype(np.float32)
     x, y = torch.from_numpy(sn[:, :1].copy()).cuda(), torch.from_numpy(sn[:, 1].copy()).cuda()
@@ -152,11 +155,12 @@ def test_snelson_config1_on_gpu(plx, golden_dir):
     opt = torch.optim.Adam(model.parameters(), lr=0.1)
     for i in range(100):
         opt.zero_grad()
-        (-solvers.marginal_log_likelihood(model, x, y, num_probes=10, cg_tol=1e-4, max_cg_iter=500, seed=i)).backward()
+        (-solvers.marginal_log_likelihood(model, x, y, num_probes=10, cg_tol=1e-4, max_cg_iter=500, seed=i,
+                                          pre_size=pre_size)).backward()
         opt.step()
     with torch.no_grad():
         lattice_mll = float(solvers.marginal_log_likelihood(model, x, y, num_probes=50, cg_tol=1e-5, max_cg_iter=1000, seed=999))
-    print("snelson exact", exact_mll, "lattice", lattice_mll)
+    print("snelson exact", exact_mll, "lattice", lattice_mll, "pre_size", pre_size)
     assert abs(lattice_mll - exact_mll) < 0.1
 
 

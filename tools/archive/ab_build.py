@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import _native as nv
-from tools.ab_apply import RBF1, tune
+from tools.archive.ab_apply import RBF1, tune
 key = sys.argv[1] if len(sys.argv) > 1 else "insert_dedupe"
 vals = [int(a) for a in sys.argv[2:]] or [0, 1]
 n, d = 1_000_000, 8

@@ -3,7 +3,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simplex_gp_amd as plx
-from tools.ab_apply import timeit, RBF1, tune
+from tools.archive.ab_apply import timeit, RBF1, tune
 for (n, d, ell) in [(100000, 4, 1.0), (1000000, 8, 1.0), (1000000, 8, 0.6931), (1000000, 8, 0.25)]:
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(n, d, generator=g); v = torch.randn(n, 1, generator=g).cuda()

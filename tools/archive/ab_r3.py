@@ -7,7 +7,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import _native as nv
-from tools.ab_apply import timeit, RBF1
+from tools.archive.ab_apply import timeit, RBF1
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1_000_000)

@@ -3,7 +3,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import simplex_gp_amd as plx
-from tools.ab_apply import timeit, RBF1, tune
+from tools.archive.ab_apply import timeit, RBF1, tune
 n, d = 1_000_000, 8
 g = torch.Generator().manual_seed(1234)
 x = torch.randn(n, d, generator=g)

@@ -4,7 +4,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simplex_gp_amd as plx
-from tools.ab_apply import RBF1
+from tools.archive.ab_apply import RBF1
 ell, vd = float(sys.argv[1]), int(sys.argv[2])
 n, d = 1_000_000, 8
 g = torch.Generator().manual_seed(1234)

@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simplex_gp_amd as plx
-from tools.ab_apply import timeit, RBF1
+from tools.archive.ab_apply import timeit, RBF1
 for (n, d) in [(200, 1), (100000, 4), (1000000, 8)]:
     g = torch.Generator().manual_seed(0)
     x = torch.randn(n, d, generator=g).cuda(); v = torch.randn(n, 1, generator=g).cuda()

@@ -6,7 +6,7 @@ import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simplex_gp_amd as plx
-from tools.ab_apply import timeit, RBF1
+from tools.archive.ab_apply import timeit, RBF1
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 n_local, d, ell = (int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000), 8, 1.0
 from simplex_gp_amd import _native as nv
