@@ -59,6 +59,8 @@ import time
 
 import numpy as np
 
+T_START = time.perf_counter()      # (multi-rank runs report wall seconds per leg: leg_wall_s)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -85,6 +87,7 @@ def parse_args(argv=None):
     ap.add_argument("--skip-fine", dest="no_fine", action="store_true")
     ap.add_argument("--skip-configs", dest="no_configs", action="store_true", help="skip the config 3/4/5 legs")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo to rehearse ranks on one GPU")
+    ap.add_argument("--skip-weak4", dest="no_weak4", action="store_true", help="multi-rank runs: skip the 4e6-points-per-GPU weak-scaling leg")
     ap.add_argument("--dump", default=None, help="write every rank's output rows of one MVM to <DUMP>.rank<r>.npz (checked by tests/check_bench_dump.py)")
     return ap.parse_args(argv)
 
@@ -881,6 +884,15 @@ def main():
 
     if multi:
         # ---- what the ranks spent where, the exchange, and the other scaling curves
+        leg_wall = {"main": round(time.perf_counter() - T_START, 2)}       # wall seconds per leg on rank 0 (import + data + timed region so far)
+
+        def timed_leg(name, fn):
+            t0 = time.perf_counter()
+            val = fn()
+            ctx.sync()
+            leg_wall[name] = round(time.perf_counter() - t0, 2)
+            log(f"bench.py: leg {name}: {leg_wall[name]} s")
+            return val
         result["rccl_ranks"] = dist.get_world_size()
         result["backend"] = args.backend
         result["warm_mvms_per_s"] = round(job.rate(args.steps), 1)
@@ -888,23 +900,35 @@ def main():
         result["exchange"] = exchange_record(job, vd, result["stage_us"])
         result["allreduce_bytes"] = job.op.exchange_bytes(vd)
         result["build_key_bytes_exchanged"] = getattr(job.op, "key_bytes_exchanged", None)
+        # the build's one exchange, timed (device synchronised around it): the all-gather of the per-rank vertex keys
+        from simplex_gp_amd import distributed as pdist
+        pdist.TIME_GATHER = True
+        job.build()
+        ctx.sync()
+        pdist.TIME_GATHER = False
+        result["build_key_allgather"] = {"kind": "all_gather_into_tensor of the per-rank vertex keys (padded to the largest rank) + "
+                                                 "one small all_gather of the counts",
+                                         "bytes": pdist.LAST_GATHER.get("bytes_out"), "us": round(pdist.LAST_GATHER.get("us") or 0.0, 1)}
         job.close()
         if not args.no_configs:
             short = max(10, args.steps // 2)
             if args.scaling != "strong":
-                result["strong"] = sharded_leg(ctx, args.n, d, args.ell, [1], short)
+                result["strong"] = timed_leg("strong", lambda: sharded_leg(ctx, args.n, d, args.ell, [1], short))
             if args.scaling != "config4":
-                result["config4"] = sharded_leg(ctx, CONFIG4_POINTS, d, 1.0, [1, 11], short)
+                result["config4"] = timed_leg("config4", lambda: sharded_leg(ctx, CONFIG4_POINTS, d, 1.0, [1, 11], short))
             if args.scaling != "weak":
-                result["weak_1e6_per_gpu"] = sharded_leg(ctx, args.n * world, d, args.ell, [1], short)
+                result["weak_1e6_per_gpu"] = timed_leg("weak_1e6_per_gpu", lambda: sharded_leg(ctx, args.n * world, d, args.ell, [1], short))
             # weak scaling with 4e6 points per GPU: where the sharded splat / slice outweigh the replicated blur and the
             # all-reduce
-            result["weak_4e6_per_gpu"] = sharded_leg(ctx, CONFIG4_POINTS * world, d, 1.0, [1], short)
-            result["columns_mode"] = columns_leg(ctx, args.n, d, args.ell, max(20, args.steps))
+            if not args.no_weak4:
+                result["weak_4e6_per_gpu"] = timed_leg("weak_4e6_per_gpu", lambda: sharded_leg(ctx, CONFIG4_POINTS * world, d, 1.0, [1], short))
+            result["columns_mode"] = timed_leg("columns_mode", lambda: columns_leg(ctx, args.n, d, args.ell, max(20, args.steps)))
             # one batched solve split by rows or by columns, and config 4 at vd = 11 on the points x columns grid
-            result["config3_cg"] = config3_multi_leg(ctx, n=args.n)
+            result["config3_cg"] = timed_leg("config3_cg", lambda: config3_multi_leg(ctx, n=args.n))
             cfg4 = result["config4"] if args.scaling != "config4" else result.setdefault("config4", {})
-            cfg4["grid_vd11"] = config4_grid_leg(ctx, short)
+            cfg4["grid_vd11"] = timed_leg("config4_grid_vd11", lambda: config4_grid_leg(ctx, short))
+        result["leg_wall_s"] = leg_wall
+        result["total_wall_s"] = round(time.perf_counter() - T_START, 2)
     else:
         # ---- warm / cold rates and per-stage times on the same lattice
         ref, v, out = job.ref, job.v, job.out

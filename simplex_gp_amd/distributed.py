@@ -47,22 +47,56 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+LAST_GATHER = {}          # the most recent all_gather_rows on this rank: {"us", "bytes_out", "world"}; "us" only under TIME_GATHER
+TIME_GATHER = False       # bench.py: synchronise the device around all_gather_rows and time it (a measuring mode)
+
+
 def all_gather_rows(t_local, group=None, extra=None):
     """Concatenate every rank's rows (row counts may differ) -> (tensor, counts).
     `extra`: a few integers per rank exchanged in the same small collective as the row counts
-    (returned as a third value, one list per rank); one host synchronisation in total."""
+    (returned as a third value, one list per rank).
+
+    Two collectives: the counts (they have to reach the host anyway: plx_build_merge takes them as host integers, and
+    they size the buffers), then ONE all_gather_into_tensor of the rows, padded to the largest count, into one
+    [world, biggest, ...] buffer.  (Rounds 2-4 used the list forms: `world` output tensors per collective and a zero-filled
+    padded copy; the list form stays as the fallback for back ends without all_gather_into_tensor.)"""
+    import time
+    if TIME_GATHER and t_local.is_cuda:
+        torch.cuda.synchronize(t_local.device)
+    t0 = time.perf_counter()
     world = dist.get_world_size(group)
     meta = torch.tensor([t_local.shape[0]] + [int(e) for e in (extra or [])], dtype=torch.int64, device=t_local.device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    table = torch.stack(metas, 0).tolist()
+    metas = torch.empty((world,) + tuple(meta.shape), dtype=meta.dtype, device=meta.device)
+    try:
+        dist.all_gather_into_tensor(metas, meta, group=group)
+        table = metas.tolist()
+    except (RuntimeError, NotImplementedError, AttributeError):
+        lst = [torch.zeros_like(meta) for _ in range(world)]
+        dist.all_gather(lst, meta, group=group)
+        table = torch.stack(lst, 0).tolist()
     counts = [int(row[0]) for row in table]
     biggest = max(counts)
-    padded = torch.zeros((biggest,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
-    padded[: t_local.shape[0]] = t_local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
-    out = torch.cat([p[:k] for p, k in zip(parts, counts)], 0)
+    if all(c == biggest for c in counts):
+        padded = t_local.contiguous()                       # equal counts: nothing to pad, nothing to copy
+    else:
+        padded = torch.empty((biggest,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
+        padded[: t_local.shape[0]] = t_local
+        padded[t_local.shape[0]:] = 0
+    gathered = torch.empty((world,) + tuple(padded.shape), dtype=padded.dtype, device=padded.device)
+    try:
+        dist.all_gather_into_tensor(gathered, padded, group=group)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        gathered = torch.stack(parts, 0)
+    if all(c == biggest for c in counts):
+        out = gathered.reshape((world * biggest,) + tuple(padded.shape[1:]))
+    else:
+        out = torch.cat([gathered[r, :k] for r, k in enumerate(counts)], 0)
+    if TIME_GATHER and out.is_cuda:
+        torch.cuda.synchronize(out.device)
+    LAST_GATHER.update(us=(time.perf_counter() - t0) * 1e6 if TIME_GATHER else None,
+                       bytes_out=out.numel() * out.element_size(), world=world)
     if extra is None:
         return out, counts
     return out, counts, [[int(v) for v in row[1:]] for row in table]

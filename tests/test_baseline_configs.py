@@ -341,6 +341,43 @@ def test_bench_self_launches_its_ranks(tmp_path):
     assert bad.returncode == 2
 
 
+def test_bench_multi_rank_full_legs_rehearsal():
+    """The driver's multi-GPU command with EVERY leg -- `python bench.py --gpus N --steps 20 --warmup 5` -- rehearsed with
+    N = 4 gloo ranks on the one GPU (the GPU boxes admit at most 6 processes on a card, so the 8-rank command itself cannot
+    be rehearsed here; nothing in bench.py depends on the rank count beyond the shard bounds), the fixed-size legs shrunk
+    through PLX_BENCH_CONFIG4_POINTS.  One JSON line, rc 0, every leg present with its exchange record
+    {kind, bytes, us}, wall seconds per leg, the build's key all-gather timed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PLX_BENCH_CONFIG4_POINTS"] = "200000"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20", "--warmup", "5", "--points", "100000",
+           "--backend", "gloo"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 4 and res["rccl_ranks"] == 4 and res["steps"] == 20 and res["warmup"] == 5
+    assert res["value"] > 0 and res["scaling"] == "strong"
+
+    def is_exchange(e):
+        return isinstance(e, dict) and {"kind", "bytes", "us"} <= set(e) and e["us"] >= 0 and e["bytes"] >= 0
+    assert is_exchange(res["exchange"])
+    assert is_exchange(res["build_key_allgather"]) and res["build_key_allgather"]["bytes"] > 0 and res["build_key_allgather"]["us"] > 0
+    for leg in ("config4", "weak_1e6_per_gpu", "weak_4e6_per_gpu"):
+        assert leg in res, leg
+        assert is_exchange(res[leg]["exchange_vd1"]), leg
+        assert res[leg]["mvms_per_s_vd1"] > 0
+    assert is_exchange(res["config4"]["exchange_vd11"])
+    assert "columns_mode" in res and "config3_cg" in res and "grid_vd11" in res["config4"]
+    for mode in ("points", "columns"):
+        assert is_exchange(res["config3_cg"][mode]["exchange"]), mode
+    walls = res["leg_wall_s"]
+    for leg in ("main", "config4", "weak_1e6_per_gpu", "weak_4e6_per_gpu", "columns_mode", "config3_cg", "config4_grid_vd11"):
+        assert leg in walls and walls[leg] >= 0, leg
+    assert res["total_wall_s"] < 600                       # the driver's limit for the real run
+    print("leg_wall_s", walls, "total", res["total_wall_s"])
+
+
 def test_bench_single_rank_rccl_rehearsal():
     """bench.py's own multi-rank code path on real RCCL: PLX_BENCH_SINGLE_RANK_RCCL=1 makes the one-GPU run open a
     world-size-1 "nccl" group (init with device_id, barrier with device_ids, all_reduce of the timings on the device,
