@@ -135,6 +135,19 @@ int plx_build_merge(plx_lattice *lat, const void *d_all_keys, const int64_t *h_c
 int64_t plx_num_points(const plx_lattice *lat);    /* n                              */
 int64_t plx_num_owned(const plx_lattice *lat);     /* rows of this shard             */
 int64_t plx_num_vertices(const plx_lattice *lat);  /* m = hashTable.size(), h:44     */
+/* plx_tune("reference_growth", 1) -- LITERAL parity with the reference CPU path where its hash table doubles.  lookup()
+ * (cpp/permutohedral.h:104-106) hashes with the capacity in force before lookupOffset() (:58-63) grows the table, so the one
+ * lookup that triggers each doubling probes from a stale bucket: a duplicate entry for a key that exists, or a key that
+ * later lookups do not find; grow() (:125-161) then re-places entries in old-position order.  The default build is the
+ * duplicate-free lattice (which is also what the reference's CUDA path builds: its table never grows).  With the switch
+ * on, plx_build / plx_filter replay the reference's table LAYOUT on the host (entry positions only, O(N (d+1)) work, about
+ * a second at N = 1e6) and patch the built structure so that every MVM equals the reference's filter(): the splat
+ * contributions the reference loses are dropped, keys its blur-time lookups cannot find read as absent.  Plain
+ * single-process builds only (ignored by plx_build_local / plx_build_merge).  h_out6 = {replayed (0/1), entries the
+ * reference's table holds (= plx_num_vertices when nothing was replayed or nothing went wrong), dropped (point, corner)
+ * contributions, invisible vertices, blur-time missed neighbour (0/1), inexact (0/1: a combination the patched structure
+ * cannot express -- never observed)}. */
+int plx_reference_growth_info(const plx_lattice *lat, int64_t *h_out6);
 int plx_dim(const plx_lattice *lat);               /* d                              */
 int plx_order(const plx_lattice *lat);             /* (ntaps-1)/2                    */
 /* Row order of d_src / d_out for plx_splat / plx_slice / plx_apply on this lattice:
@@ -345,7 +358,9 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  *   slot-occupancy bitmap before the hash table when m >= 2^22; 0 never, 2 always), "splat_first" (1 = single-column splat by
  *   first-touch stores + a short extras list when m >= 0.9 nnz; 0 never, 2 whenever representable, 3 = 2 with scattered
  *   stores), "perm_rows" (1 = multi-column row permutations by 16-byte chunks / LDS-transposed whole-line stores; 0 = the
- *   per-float forms).
+ *   per-float forms), "reference_growth" (0; 1 = replay the reference CPU path's table-growth quirk: plx_reference_growth_info),
+ *   and the round-5 build switches "hash_v" (2), "table_fp" (1), "nbr_sliced" (1), "nbr_seed" (1), "flag_own" (1),
+ *   "assign_evid" (1), "insert_v" (2), "insert_xcd" (2), "order_sample" (8), "embed_vrange" (0), "blk_sort" (5): DESIGN.md 2.
  * The diagnostic ablations "splat_ablate" / "blur_ablate" / "block_ablate" exist only in libplx_diag.so (make diag).
  * Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "plx_selftest_sort": (_i32, [_i64, _i32, _i32, ctypes.c_uint64, _vp, ctypes.POINTER(_i64)]),
     "plx_set_timing": (_i32, [_vp, _i32]),
     "plx_build_times": (_i32, [_vp, _f32p]),
+    "plx_reference_growth_info": (_i32, [_vp, ctypes.POINTER(_i64)]),
     "plx_apply_times": (_i32, [_vp, _f32p, _i32, ctypes.POINTER(_i32)]),
 }
 

@@ -78,7 +78,7 @@ void release(DevBuf &b)
 static std::vector<DevBuf *> all_bufs(plx_lattice *L)
 {
     return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
-            &L->sort_keys_in, &L->slotmap, &L->nibmap, &L->prank, &L->vaxis, &L->vs0, &L->vowner, &L->ex_vid, &L->ex_pt, &L->ex_w, &L->ex_keys, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
+            &L->sort_keys_in, &L->slotmap, &L->nibmap, &L->prank, &L->vaxis, &L->vs0, &L->vowner, &L->ew_splat, &L->replay_vat, &L->replay_list, &L->replay_invisible, &L->ex_vid, &L->ex_pt, &L->ex_w, &L->ex_keys, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->csr_vid, &L->row_ptr,
             &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
             &L->sortkey_in, &L->sortkey_out,
@@ -270,6 +270,19 @@ int plx_build_merge(plx_lattice *L, const void *d_all_keys, const int64_t *h_cou
 int64_t plx_num_points(const plx_lattice *L) { return L ? L->n : -1; }
 int64_t plx_num_owned(const plx_lattice *L) { return L ? L->own_end - L->own_begin : -1; }
 int64_t plx_num_vertices(const plx_lattice *L) { return (L && L->built) ? L->m : -1; }
+
+int plx_reference_growth_info(const plx_lattice *L, int64_t *h_out6)
+{
+    if (!L || !L->built || !h_out6) { set_error("plx_reference_growth_info: lattice not built"); return PLX_ERR_STATE; }
+    const auto &rp = L->replay;
+    h_out6[0] = rp.active ? 1 : 0;
+    h_out6[1] = rp.active ? rp.m_reference : L->m;
+    h_out6[2] = rp.n_dropped;
+    h_out6[3] = rp.n_invisible;
+    h_out6[4] = rp.blur_miss ? 1 : 0;
+    h_out6[5] = rp.inexact ? 1 : 0;
+    return PLX_OK;
+}
 int plx_dim(const plx_lattice *L) { return L ? L->d : -1; }
 int plx_order(const plx_lattice *L) { return L ? L->order : -1; }
 

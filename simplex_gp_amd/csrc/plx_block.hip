@@ -667,7 +667,7 @@ int build_blocks(plx_lattice *L, hipStream_t stream)
     PLX_TRY(ensure(L->srow, (size_t)d1 * L->srow_stride * 2 + 64));
     PLX_TRY(ensure(L->brow_ptr, (size_t)(nblocks + 1) * 4));
     // one workgroup per block: sort in LDS, per-corner records, row counts; the vertex lists go to sort_keys_in
-    PLX_TRY(sort_fill_blocks_lds(L->evid.as<int>(), L->ew.as<float>(), n, (int)L->own_begin, n_own, P, d1, cpb, vbits, m, E, nblocks,
+    PLX_TRY(sort_fill_blocks_lds(L->evid.as<int>(), splat_weights(L), n, (int)L->own_begin, n_own, P, d1, cpb, vbits, m, E, nblocks,
                                  L->bc_pt.as<uint16_t>(), L->bc_w.as<float>(), L->srow.as<uint16_t>(), L->srow_stride,
                                  L->sort_keys_in.as<int>(), L->brow_ptr.as<int>(), stream));
     blk_scan_kernel<<<1, kBlock, 0, stream>>>(L->brow_ptr.as<int>(), (int)nblocks, L->counters.as<int>() + 40);

@@ -565,7 +565,9 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
     const int m = (int)L->m, d1 = L->d + 1, order = L->order;
     const int vdp = values_stride(vd);
     const bool v1 = (vd == 1 && order >= 1 && order <= 3 && (g_blur_vpt == 2 || g_blur_vpt == 4));
-    if (v1 && m <= kSmallM && g_blur_small) {
+    // reference_growth with invisible vertices: one axis per launch, each followed by the centre-tap correction
+    const bool nocentre = L->replay.active && L->replay.n_invisible > 0;
+    if (v1 && m <= kSmallM && g_blur_small && !nocentre) {
         // result goes where the per-axis path would leave it, so callers see no difference
         float *dst = (d1 & 1) ? d_scratch : d_values;
         const int *nb = L->nbr.as<int>();
@@ -586,7 +588,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
     }
     float *cur = d_values, *nxt = d_scratch;
     bool paired = false;
-    const bool pair_vec = vd > 1 && order == 1 && g_blur_fuse_vec != 0 && !(L->single_use && !L->pairs_ready) && g_blur_narrow && vdp / 4 >= 2 && vdp / 4 <= 4 &&
+    const bool pair_vec = !nocentre && vd > 1 && order == 1 && g_blur_fuse_vec != 0 && !(L->single_use && !L->pairs_ready) && g_blur_narrow && vdp / 4 >= 2 && vdp / 4 <= 4 &&
                           d1 >= 2 && m > 0 && (int64_t)8 * L->mstride < (1ll << 32);
     if (pair_vec) PLX_TRY(ensure_blur_pairs(L, stream));
     for (int axis = 0; axis < d1; ++axis) {
@@ -601,7 +603,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             float *t = cur; cur = nxt; nxt = t;
             continue;
         }
-        if (v1 && order == 1 && L->use_pairs && !L->use_compact && g_blur_fuse != 0 && pair >= 0) {
+        if (!nocentre && v1 && order == 1 && L->use_pairs && !L->use_compact && g_blur_fuse != 0 && pair >= 0) {
             // axes (axis, axis + 1) in one launch
             const int *pn = L->pair_nbr.as<int>() + (size_t)pair * 8 * L->mstride;
             if (g_blur_vpt == 4) {
@@ -667,6 +669,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
                                         L->mstride, vdp / 4, order, L->taps, stream);
             L->kn_blur = "blur_axis_kernel";
         }
+        if (nocentre) PLX_TRY(replay_nocentre_fix(L, cur, nxt, vdp, stream));
         float *t = cur; cur = nxt; nxt = t;
     }
     if (paired) {   // pairs, plus one axis on its own when d + 1 is odd

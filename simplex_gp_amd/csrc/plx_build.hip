@@ -2252,7 +2252,7 @@ int ensure_csr(plx_lattice *L, hipStream_t stream)
                                    stream));
         if (!second) { std::swap(L->sort_keys_in, L->csr_vid); std::swap(L->sort_vals_in, L->sort_vals_out); }
         csr_finalize_kernel<<<ceil_div(L->nnz, kBlock), kBlock, 0, stream>>>(
-            L->csr_vid.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), L->ew.as<float>(), n,
+            L->csr_vid.as<uint32_t>(), L->sort_vals_out.as<uint32_t>(), splat_weights(L), n,
             (int)L->own_begin, (int)L->nnz, m, L->perm.as<uint32_t>(), L->csr_pt.as<int>(), L->csr_row.as<int>(),
             L->csr_w.as<float>());
     }
@@ -2339,6 +2339,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
         }
         L->vcode = nullptr;                                       // (the sort buffers are free for their next user)
     }
+    PLX_TRY(replay_patch_tables(L, stream));   // reference_growth: invisible vertices, the blur-time miss (before anything is derived from the rows)
     PLX_TRY(build_blur_pairs(L, stream));      // composite neighbours for the two-axes-per-launch blur (coarse lattices)
     // compacted copy for sparse lattices (used by the vd = 1 blur when under a quarter of the neighbours exist)
     // Neighbourhoods are only sparse when most corners created a vertex of their own (measured: m/E = 0.19 ->
@@ -2396,6 +2397,8 @@ static int build_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
     int evi = 0;
     L->partial_cover = false;
     PLX_TRY(stage_local<D>(L, d_ref, stream, &evi));
+    L->replay = plx_lattice::Replay();
+    if (g_reference_growth) PLX_TRY(replay_simulate(L, stream));      // the reference CPU path's table-growth quirk (plx_replay.hip)
     PLX_TRY(stage_tables<D>(L, stream, &evi));
     if (L->timing) {
         PLX_HIP_TRY(hipStreamSynchronize(stream));
@@ -2411,6 +2414,7 @@ static int local_typed(plx_lattice *L, const float *d_ref, hipStream_t stream)
     const bool t = L->timing;
     L->timing = false;
     L->partial_cover = false;
+    L->replay = plx_lattice::Replay();
     int rc = stage_local<D>(L, d_ref, stream, &evi);
     L->timing = t;
     return rc;

@@ -264,7 +264,7 @@ static int ensure_first_body(plx_lattice *L, hipStream_t stream)
                                L->sort_vals_out.as<uint32_t>(), extra, end_bit, &second, stream));
     const uint32_t *sk = second ? L->ex_keys.as<uint32_t>() : L->sort_keys_in.as<uint32_t>();
     const uint32_t *sv = second ? L->sort_vals_out.as<uint32_t>() : L->sort_vals_in.as<uint32_t>();
-    extra_finalize_kernel<<<ceil_div(extra, kBlock), kBlock, 0, stream>>>(sk, sv, L->ew.as<float>(), n, (int)extra, L->ex_vid.as<int>(),
+    extra_finalize_kernel<<<ceil_div(extra, kBlock), kBlock, 0, stream>>>(sk, sv, splat_weights(L), n, (int)extra, L->ex_vid.as<int>(),
                                                                          L->ex_pt.as<int>(), L->ex_w.as<float>(), cnt + 1);
     PLX_HIP_TRY(hipGetLastError());
     int h[2];
@@ -284,8 +284,8 @@ int splat_first_impl(plx_lattice *L, const float *d_src, float *d_values, hipStr
     switch (L->d + 1) {
 #define PLX_CASE(D1) \
     case D1: \
-        if (seq) splat_first_seq_kernel<D1><<<grid, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->evid.as<int>(), L->ew.as<float>(), perm, d_src, n, d_values, nt, g_xcd_remap); \
-        else splat_first_kernel<D1><<<grid, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->evid.as<int>(), L->ew.as<float>(), perm, d_src, n, d_values, nt, g_xcd_remap); \
+        if (seq) splat_first_seq_kernel<D1><<<grid, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->evid.as<int>(), splat_weights(L), perm, d_src, n, d_values, nt, g_xcd_remap); \
+        else splat_first_kernel<D1><<<grid, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->evid.as<int>(), splat_weights(L), perm, d_src, n, d_values, nt, g_xcd_remap); \
         break;
         PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9)
         PLX_CASE(10) PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17)

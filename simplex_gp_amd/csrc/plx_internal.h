@@ -80,6 +80,7 @@ struct Tune {
     int insert_xcd = 2;   // XCD-aware tile order (each XCD one contiguous eighth of the points): bit 0 the point-per-thread insert (measured slower), bit 1 the id lookup
     int order_sample = 8;   // point-order key layout from the coordinate ranges of every k-th point (1: of all points); from 65,536 points up
     int embed_vrange = 0;   // 1: the embedding finds the range of the vertices' blur-axis coordinates (Morton renumbering) itself -- no pass over the vertex keys, no read-back of its own; measured: saves 22 us there, costs the embedding 30 (l = 1) to 70 us (l = 0.25): off
+    int reference_growth = 0;   // 1: replay the reference CPU path's hash-table-growth quirk (plx_replay.hip): literal parity with cpp/permutohedral.h where its table doubles; plain single-process builds only, O(N (d+1)) host work per build
     int blk_sort = 5;   // per-block LDS sort of the block tables: 0 = (vertex, corner) pairs, 4 bits per pass; 4 / 5 / 6 = corner index packed under the vertex id, keys only, that many bits per pass
     int insert_v = 2;   // hashed insert: 1 = one thread per corner over the packed corner keys (ekeys); 2 = one thread per point over the point records, several probe chains in flight per thread
     int flag_own = 1;   // first-touch flags without table gathers: the insert marks who claimed / lowered a slot (top bit of eslot) and who was displaced
@@ -129,6 +130,7 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_insert_xcd (plx::tl_tune->insert_xcd)
 #define g_order_sample (plx::tl_tune->order_sample)
 #define g_embed_vrange (plx::tl_tune->embed_vrange)
+#define g_reference_growth (plx::tl_tune->reference_growth)
 #define g_blk_sort (plx::tl_tune->blk_sort)
 #define g_insert_v (plx::tl_tune->insert_v)
 #define g_flag_own (plx::tl_tune->flag_own)
@@ -258,6 +260,20 @@ struct plx_lattice {
     int64_t n_extra = 0;         // corners that are not the first touch of their vertex (nnz - m)
     plx::DevBuf ex_vid, ex_pt, ex_w, ex_keys;   // int32 / int32 / float [n_extra] the extras sorted by vertex; sort scratch
 
+    // plx_tune("reference_growth", 1): what the host replay of the reference's table layout found (plx_replay.hip)
+    struct Replay {
+        bool active = false;          // this build was replayed
+        int64_t m_reference = 0;      // entries the reference's table holds (hashTable.size(): duplicates included)
+        int grows = 0;                // doublings of the reference's table (splat + blur)
+        int n_dropped = 0;            // (point, corner) lookups whose splat contribution the reference loses
+        int n_invisible = 0;          // vertices no blur-time lookup finds
+        bool blur_miss = false;       // blur()'s first lookup fell on a doubling and read an existing neighbour as absent
+        int blur_miss_vertex = 0;
+        bool inexact = false;         // a combination this representation cannot express (see plx_replay.hip)
+    } replay;
+    plx::DevBuf ew_splat;         // float [d+1][n]  the splat's copy of ew with the dropped lookups zeroed (replay mode)
+    plx::DevBuf replay_vat, replay_list, replay_invisible;   // int32 scratch / lists of the replay
+
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
     plx::DevBuf val_a, val_b;                 // float [m][vdp]   (vdp = value row stride, plx_values_stride)
@@ -301,6 +317,12 @@ int unpermute_rows(plx_lattice *L, const float *d_tmp, int vd, float *d_out, con
 int choose_paths(plx_lattice *L, int vd, hipStream_t stream, bool *splat_blocks, bool *slice_blocks);
 int prepare_tables(plx_lattice *L, int vd, hipStream_t stream);
 int splat_block_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);
+// plx_replay.hip (plx_tune "reference_growth")
+int replay_simulate(plx_lattice *L, hipStream_t stream);
+int replay_patch_tables(plx_lattice *L, hipStream_t stream);
+int replay_nocentre_fix(plx_lattice *L, const float *d_old, float *d_new, int vdp, hipStream_t stream);
+// barycentric weights as the SPLAT side reads them (the slice side always reads ew)
+inline const float *splat_weights(const plx_lattice *L) { return L->replay.active ? L->ew_splat.as<float>() : L->ew.as<float>(); }
 // plx_first.hip
 int ensure_first(plx_lattice *L, hipStream_t stream);
 int splat_first_impl(plx_lattice *L, const float *d_src, float *d_values, hipStream_t stream);

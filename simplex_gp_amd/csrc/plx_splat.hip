@@ -578,7 +578,7 @@ int splat_onehot_impl(plx_lattice *L, const int *d_cand, int nb, int vd, float *
 {
     const int vdp = values_stride(vd), d1 = L->d + 1;
     PLX_HIP_TRY(hipMemsetAsync(d_values, 0, (size_t)L->m * vdp * 4, stream));
-    splat_onehot_kernel<<<ceil_div((int64_t)nb * d1, 64), 64, 0, stream>>>(L->evid.as<int>(), L->ew.as<float>(), d_cand, nb, d1, (int)L->n,
+    splat_onehot_kernel<<<ceil_div((int64_t)nb * d1, 64), 64, 0, stream>>>(L->evid.as<int>(), splat_weights(L), d_cand, nb, d1, (int)L->n,
                                                                            vdp, d_values);
     L->kn_splat = "splat_onehot_kernel";
     PLX_HIP_TRY(hipGetLastError());

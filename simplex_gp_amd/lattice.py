@@ -203,6 +203,14 @@ class Lattice:
     def set_timing(self, on=True):
         nv.check(nv.lib().plx_set_timing(self._h, 1 if on else 0), "plx_set_timing")
 
+    def reference_growth_info(self):
+        """What the replay of the reference CPU path's table-growth quirk found for this build (plx_tune
+        "reference_growth"): {"replayed", "m_reference", "dropped", "invisible", "blur_miss", "inexact"}."""
+        buf = (ctypes.c_int64 * 6)()
+        nv.check(nv.lib().plx_reference_growth_info(self._h, buf), "plx_reference_growth_info")
+        return {"replayed": bool(buf[0]), "m_reference": int(buf[1]), "dropped": int(buf[2]), "invisible": int(buf[3]),
+                "blur_miss": bool(buf[4]), "inexact": bool(buf[5])}
+
     def build_times_ms(self):
         buf = (ctypes.c_float * 6)()
         nv.check(nv.lib().plx_build_times(self._h, buf), "plx_build_times")

@@ -223,6 +223,104 @@ def test_filter_vs_reference_goldens(plx, small):
     print("worst rel-L2 vs reference goldens:", worst)
 
 
+@pytest.fixture
+def reference_growth(plx):
+    """plx_tune("reference_growth", 1) for the test's builds: the reference CPU path's table-growth quirk replayed."""
+    from simplex_gp_amd import _native as nv
+    nv.check(nv.lib().plx_tune(b"reference_growth", 1), "plx_tune")
+    yield
+    nv.check(nv.lib().plx_tune(b"reference_growth", 0), "plx_tune")
+
+
+def test_reference_growth_replay_vs_reference_goldens(plx, small, reference_growth):
+    """With plx_tune("reference_growth", 1) the boundary call equals the REFERENCE's own output on every golden case at the
+    north star's 1e-4 -- no quirk term -- and the replay reports the reference's vertex count (hashTable.size(), duplicates
+    included).  cloud_grow_quirk_n2000_d8 is the case built to hit a doubling."""
+    z, names = small
+    worst = 0.0
+    for name in names:
+        ref, taps, src, gold, m_ref = (z[f"{name}/{k}"] for k in ("ref", "taps", "src", "out", "m"))
+        lat = plx.Lattice().build(torch.from_numpy(ref).cuda(), taps)
+        out = lat.apply(torch.from_numpy(src).cuda()).cpu().numpy()
+        info = lat.reference_growth_info()
+        assert info["replayed"] and not info["inexact"], (name, info)
+        assert info["m_reference"] == int(m_ref), (name, info, int(m_ref))
+        err = rel_l2(out, gold)
+        worst = max(worst, err)
+        assert err <= TOL_REFERENCE, (name, err, info)
+        once = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), torch.from_numpy(taps)).cpu().numpy()
+        assert rel_l2(once, gold) <= TOL_REFERENCE, name                 # the one-shot boundary call replays too
+        lat.close()
+    print("reference_growth: worst rel-L2 vs reference goldens:", worst)
+
+
+@pytest.mark.parametrize("name", ["n1e5_d4_ell1.0", "n1e5_d4_ell0.25", "n1e5_d4_vd11_ell1.0",
+                                  "n1e6_d8_ell1.0", "n1e6_d8_ell0.6931"])
+def test_reference_growth_replay_large_probes(plx, golden_dir, name, reference_growth):
+    """BASELINE.json config-2 / 3 shapes with the replay on: m == the reference's hashTable.size() and the output within 1e-4
+    of the reference (its probes, and the reference-exact oracle over all rows) with NO quirk term -- n1e5_d4_ell0.25 and
+    n1e6_d8_ell0.6931 are the two BASELINE inputs where the quirk alone moves the reference by more than 1e-4."""
+    z = np.load(os.path.join(golden_dir, "filter_large.npz"))
+    n, d, vd = (int(v) for v in z[f"{name}/shape"])
+    g = torch.Generator().manual_seed(int(z[f"{name}/seed"]))
+    x = torch.randn(n, d, generator=g)
+    v = torch.randn(n, vd, generator=g)
+    ref = (x / float(z[f"{name}/ell"])).contiguous()
+    lat = plx.Lattice().build(ref.cuda(), z[f"{name}/taps"])
+    out = lat.apply(v.cuda()).cpu().numpy()
+    info = lat.reference_growth_info()
+    print(name, info)
+    assert info["replayed"] and not info["inexact"]
+    assert info["m_reference"] == int(z[f"{name}/m"]), (info, int(z[f"{name}/m"]))
+    stride = int(z[f"{name}/stride"])
+    head, strided = z[f"{name}/out_head"], z[f"{name}/out_strided"]
+    scale = float(z[f"{name}/out_l2"]) / np.sqrt(n * vd)
+    assert np.linalg.norm(out[:512] - head) / (scale * np.sqrt(head.size)) <= TOL_REFERENCE
+    assert np.linalg.norm(out[::stride] - strided) / (scale * np.sqrt(strided.size)) <= TOL_REFERENCE
+    assert abs(np.linalg.norm(out.astype(np.float64)) / float(z[f"{name}/out_l2"]) - 1) <= TOL_REFERENCE
+    exact = oracle.filter(v.numpy(), ref.numpy(), z[f"{name}/taps"])          # exact_mode: the reference, bit for bit
+    err = rel_l2(out, exact)
+    print(name, "rel-L2 vs the reference-exact oracle, replay on:", err)
+    assert err <= TOL_REFERENCE
+    lat.close()
+
+
+QUIRK_SURVEY_SHAPES = [(16_599, 17, 0.6931), (45_730, 9, 0.6931), (48_827, 20, 0.6931), (100_000, 4, 0.25), (100_000, 4, 1.0),
+                       (20_000, 8, 0.5), (200_000, 8, 1.0), (10_623, 18, 1.0), (60_000, 3, 0.1), (300_000, 8, 0.6931),
+                       (2_000, 8, 0.5), (120_000, 6, 0.4)]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_reference_growth_replay_quirk_survey(plx, reference_growth, seed):
+    """The quirk survey's twelve shapes x three seeds (tests/checks/quirk_survey.py: the reference moves its own output by
+    0 ... 2.9e-3 on them) with the replay on: rel-L2 against the reference-exact oracle <= 1e-4 on every input, no quirk
+    term, and the replay's vertex count equal to the reference's."""
+    import bench
+    worst, hit = 0.0, 0
+    for n, d, ell in QUIRK_SURVEY_SHAPES:
+        g = torch.Generator().manual_seed(1000 * seed + n % 997 + d)
+        x = torch.randn(n, d, generator=g)
+        v = torch.randn(n, 1, generator=g)
+        ref = (x / ell).contiguous()
+        taps = bench.RBF1
+        exact, m_exact = oracle.filter(v.numpy(), ref.numpy(), taps, return_m=True)
+        oracle.set_exact_mode(False)
+        clean = oracle.filter(v.numpy(), ref.numpy(), taps)
+        oracle.set_exact_mode(True)
+        lat = plx.Lattice().build(ref.cuda(), taps)
+        out = lat.apply(v.cuda()).cpu().numpy()
+        info = lat.reference_growth_info()
+        quirk = rel_l2(clean, exact)
+        err = rel_l2(out, exact)
+        hit += quirk > TOL_REFERENCE
+        worst = max(worst, err)
+        assert info["replayed"] and not info["inexact"], (n, d, ell, info)
+        assert info["m_reference"] == m_exact, (n, d, ell, info, m_exact)
+        assert err <= TOL_REFERENCE, (n, d, ell, err, quirk, info)
+        lat.close()
+    print(f"seed {seed}: worst rel-L2 vs the reference with the replay on {worst:.2e}; inputs where the quirk alone exceeds 1e-4: {hit}")
+
+
 @pytest.mark.parametrize("name", ["n1e5_d4_ell1.0", "n1e5_d4_ell0.25", "n1e5_d4_vd11_ell1.0",
                                   "n1e6_d8_ell1.0", "n1e6_d8_ell0.6931"])
 def test_large_vs_reference_probes(plx, golden_dir, name):
