@@ -158,6 +158,42 @@ def test_config4_full_size_eight_shards(plx):
         lat.close()
 
 
+@pytest.mark.parametrize("key", ["config4_n4e6_d8_ell1.0", "config5_n10623_d18_matern3"])
+def test_config_probes_with_reference_growth_replay(plx, key):
+    """The reference's own output at config 4 (N = 4e6, d = 8: its table holds one duplicate vertex, m = 660,227) and on the
+    config-5 stand-in (Matern-1.5 order 3, d = 18: no duplicate, neighbours read as absent at the doublings, 4.2e-4 on its
+    output) with plx_tune("reference_growth", 1): probes of the reference within 1e-4, no quirk term, and the replay's
+    vertex count equal to the reference's."""
+    import bench
+    from simplex_gp_amd import _native as nv
+    z = np.load(os.path.join(ROOT, "tests", "golden", "filter_large.npz"))
+    n, d, vd = (int(v) for v in z[f"{key}/shape"])
+    if key.startswith("config4"):
+        x, v = bench.synth(n, d, 11)
+        v = v[:, :1].contiguous()
+    else:
+        g = torch.Generator().manual_seed(int(z[f"{key}/seed"]))
+        x = torch.randn(n, d, generator=g)
+        v = torch.randn(n, 1, generator=g)
+    ref = (x / float(z[f"{key}/ell"])).contiguous()
+    assert np.array_equal(ref[:8].numpy(), z[f"{key}/ref_head"]) and np.array_equal(v[:8].numpy(), z[f"{key}/src_head"])
+    nv.check(nv.lib().plx_tune(b"reference_growth", 1), "plx_tune")
+    try:
+        lat = plx.Lattice().build(ref.cuda(), z[f"{key}/taps"])
+        out = lat.apply(v.cuda()).cpu().numpy()
+        info = lat.reference_growth_info()
+    finally:
+        nv.check(nv.lib().plx_tune(b"reference_growth", 0), "plx_tune")
+    print(key, info)
+    assert info["replayed"] and not info["inexact"] and info["m_reference"] == int(z[f"{key}/m"])
+    stride = int(z[f"{key}/stride"])
+    assert rel_l2(out[:512], z[f"{key}/out_head"]) <= 1e-4
+    assert rel_l2(out[::stride], z[f"{key}/out_strided"]) <= 1e-4
+    assert abs(np.linalg.norm(out.astype(np.float64)) / float(z[f"{key}/out_l2"]) - 1) <= 1e-4
+    assert abs(float(out.astype(np.float64).sum()) - float(z[f"{key}/out_sum"])) <= 1e-4 * float(z[f"{key}/out_abs_sum"])
+    lat.close()
+
+
 def test_rccl_world_size_one():
     """RCCL on real hardware: a child process opens a world-size-1 "nccl" process group (device_id=...) and runs the
     sharded path with its collectives forced on -- key all-gather, vertex all-reduce, CG dot-product all-reduce, barrier
