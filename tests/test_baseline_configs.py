@@ -471,12 +471,12 @@ def test_bench_train_step_phases_add_up(plx):
         def sync():
             torch.cuda.synchronize()
 
-    out = bench.train_step_leg(Ctx, 60_000, 4, lambda: plx.RBFLattice(order=1, ard_num_dims=4), pre_sizes=(0, 100), steps=2)
+    out = bench.train_step_leg(Ctx, 200_000, 6, lambda: plx.RBFLattice(order=1, ard_num_dims=6), pre_sizes=(0, 100), steps=3)
     for key in ("pre_size_0", "pre_size_100"):
         leg = out[key]
         assert leg["phases_from"].startswith("median")
         assert abs(leg["phases_sum_ms"] - leg["profiled_step_ms"]) <= 0.25 * leg["profiled_step_ms"], leg
-        assert leg["step_ms"] <= 1.25 * leg["profiled_step_ms"], leg
+        assert leg["step_ms"] <= 1.6 * leg["profiled_step_ms"], leg      # (host-bound at this size: generous)
         assert all(v >= 0 for v in leg["phases_ms"].values())
 
 
