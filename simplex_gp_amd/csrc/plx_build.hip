@@ -858,7 +858,16 @@ __global__ __launch_bounds__(kBlock) void insert_point_kernel(const uint32_t *__
             if (o[g] != kEmpty) {
                 uint32_t ko[DW];
                 rec_key<D>(ogr[g], ork[g], (int)(o[g] % D1), ko);
-                done = key_equal<DW>(k[g], ko) && o[g] <= e[g];          // the key is there under a smaller index: nothing to do
+                if (key_equal<DW>(k[g], ko)) {
+                    if (o[g] <= e[g]) {
+                        done = true;                                     // the key is there under a smaller index: nothing to do
+                    } else if (!disp) {
+                        // ... under a LARGER one (a later point's workgroup got here first): lower it.  Without the own /
+                        // displaced marks nobody needs the value the atomic returns, so the wave does not wait for it
+                        atomicMin(&table[h[g]], e[g]);
+                        done = true;
+                    }
+                }
             }
             pend[g] = false;
             if (!done) {
