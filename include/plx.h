@@ -360,7 +360,7 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  *   stores), "perm_rows" (1 = multi-column row permutations by 16-byte chunks / LDS-transposed whole-line stores; 0 = the
  *   per-float forms), "reference_growth" (0; 1 = replay the reference CPU path's table-growth quirk: plx_reference_growth_info),
  *   and the round-5 build switches "hash_v" (2), "table_fp" (1), "nbr_sliced" (1), "nbr_seed" (1), "flag_own" (1),
- *   "assign_evid" (1), "insert_v" (2), "insert_xcd" (2), "order_sample" (8), "embed_vrange" (0), "blk_sort" (5): DESIGN.md 2.
+ *   "assign_evid" (1), "insert_v" (2), "insert_xcd" (2), "order_sample" (8), "embed_vrange" (0), "blk_sort" (15): DESIGN.md 2.
  * The diagnostic ablations "splat_ablate" / "blur_ablate" / "block_ablate" exist only in libplx_diag.so (make diag).
  * Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);

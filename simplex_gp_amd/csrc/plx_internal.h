@@ -81,7 +81,7 @@ struct Tune {
     int order_sample = 8;   // point-order key layout from the coordinate ranges of every k-th point (1: of all points); from 65,536 points up
     int embed_vrange = 0;   // 1: the embedding finds the range of the vertices' blur-axis coordinates (Morton renumbering) itself -- no pass over the vertex keys, no read-back of its own; measured: saves 22 us there, costs the embedding 30 (l = 1) to 70 us (l = 0.25): off
     int reference_growth = 0;   // 1: replay the reference CPU path's hash-table-growth quirk (plx_replay.hip): literal parity with cpp/permutohedral.h where its table doubles; plain single-process builds only, O(N (d+1)) host work per build
-    int blk_sort = 5;   // per-block LDS sort of the block tables: 0 = (vertex, corner) pairs, 4 bits per pass; 4 / 5 / 6 = corner index packed under the vertex id, keys only, that many bits per pass
+    int blk_sort = 15;   // per-block LDS sort of the block tables: 0 = (vertex, corner) pairs, 4 bits per pass; 4 / 5 / 6 = corner index packed under the vertex id, keys only, that many bits per pass, 256 threads; 15 = 5 bits with 512 threads
     int insert_v = 2;   // hashed insert: 1 = one thread per corner over the packed corner keys (ekeys); 2 = one thread per point over the point records, several probe chains in flight per thread
     int flag_own = 1;   // first-touch flags without table gathers: the insert marks who claimed / lowered a slot (top bit of eslot) and who was displaced
     int assign_evid = 1;   // the numbering pass stores the vertex id of every first-touch corner itself when the numbering is final; the id lookup then serves the other corners only

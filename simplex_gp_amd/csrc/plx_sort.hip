@@ -121,20 +121,24 @@ int selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, hipStrea
 // keys only, RBITS bits per pass -- half the LDS exchange traffic per pass of the (key, value) form and fewer passes than
 // rocPRIM's default 4 bits (20 key bits: 5 -> 4 passes).  The sort covers the vertex bits alone and is stable, so equal
 // vertices keep (corner, point) order exactly as before: same tables, bit for bit.  Needs vbits + CB <= 32 (with 2^vbits > m).
-template <int IPT, bool PACKED, int RBITS>
-__global__ __launch_bounds__(256) void blk_sort_fill_kernel(const int *__restrict__ evid, const float *__restrict__ ew, int n,
+template <int E, bool PACKED, int RBITS, int T>
+__global__ __launch_bounds__(T) void blk_sort_fill_kernel(const int *__restrict__ evid, const float *__restrict__ ew, int n,
                                                             int own_begin, int n_own, int P, int d1, int cpb, int vbits,
                                                             uint16_t *__restrict__ bc_pt, float *__restrict__ bc_w,
                                                             uint16_t *__restrict__ srow, int64_t sstride,
                                                             int *__restrict__ rows_tmp, int *__restrict__ rows)
 {
-    using Sort = rocprim::block_radix_sort<uint32_t, 256, IPT, uint32_t, 1, 1, RBITS>;
-    using SortKeys = rocprim::block_radix_sort<uint32_t, 256, IPT, rocprim::empty_type, 1, 1, RBITS>;
-    constexpr int CB = IPT == 16 ? 12 : 13;            // bits of a block-local corner index (256 * IPT corners)
+    // a block holds 256 * E corners (E = 16 or 24), sorted by T threads with IPT = 256 E / T corners each (T = 512: half the
+    // serial depth per thread of every sort pass; N = 1e6: 133 -> 108 us; T = 1024: 139)
+    constexpr int IPT = 256 * E / T;
+    static_assert(IPT % 4 == 0, "the blocked stores move 4 corners at a time");
+    using Sort = rocprim::block_radix_sort<uint32_t, T, IPT, uint32_t, 1, 1, RBITS>;
+    using SortKeys = rocprim::block_radix_sort<uint32_t, T, IPT, rocprim::empty_type, 1, 1, RBITS>;
+    constexpr int CB = E == 16 ? 12 : 13;              // bits of a block-local corner index (256 * E corners)
     __shared__ union { typename Sort::storage_type pairs; typename SortKeys::storage_type keys; } storage;
-    __shared__ uint32_t edge_key[256 + 1];             // first key of every thread (+ a sentinel)
-    __shared__ uint32_t last_key[256];                 // last key of every thread
-    __shared__ int wave_sum[4];
+    __shared__ uint32_t edge_key[T + 1];               // first key of every thread (+ a sentinel)
+    __shared__ uint32_t last_key[T];                   // last key of every thread
+    __shared__ int wave_sum[T / 64];
     extern __shared__ uint16_t srow_tile[];            // [d1][np] block-local row of every corner, point major per corner
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void blk_sort_fill_kernel(const int *__restric
     // neighbours across threads: the last key of the thread before, the first key of the thread after
     edge_key[tid] = keys[0];
     last_key[tid] = keys[IPT - 1];
-    if (tid == 0) edge_key[256] = 0xFFFFFFFFu;
+    if (tid == 0) edge_key[T] = 0xFFFFFFFFu;
     __syncthreads();
     const uint32_t next_first = edge_key[tid + 1];
     const uint32_t prev_last = tid == 0 ? 0u : last_key[tid - 1];
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void blk_sort_fill_kernel(const int *__restric
     __syncthreads();
     int before = incl - heads, total = 0;
 #pragma unroll
-    for (int wv = 0; wv < 4; ++wv) {
+    for (int wv = 0; wv < T / 64; ++wv) {
         if (wv < wave) before += wave_sum[wv];
         total += wave_sum[wv];
     }
@@ -214,17 +218,23 @@ __global__ __launch_bounds__(256) void blk_sort_fill_kernel(const int *__restric
         if (live) srow_tile[c] = (uint16_t)lrow;
         if (head[j]) rows_tmp[k0 + lrow] = (int)keys[j];
     }
-    // blocked stores: 16 consecutive corners per thread = 32 bytes of bc_pt, 64 bytes of bc_w (the arrays have slack)
+    // blocked stores: IPT consecutive corners per thread = 2 IPT bytes of bc_pt, 4 IPT bytes of bc_w (the arrays have slack)
     if (tid * IPT < nc) {
+        if constexpr (IPT % 8 == 0) {
 #pragma unroll
-        for (int q = 0; q < IPT / 8; ++q)
-            *reinterpret_cast<uint4 *>(bc_pt + k0 + tid * IPT + 8 * q) = make_uint4(ptw[4 * q], ptw[4 * q + 1], ptw[4 * q + 2], ptw[4 * q + 3]);
+            for (int q = 0; q < IPT / 8; ++q)
+                *reinterpret_cast<uint4 *>(bc_pt + k0 + tid * IPT + 8 * q) = make_uint4(ptw[4 * q], ptw[4 * q + 1], ptw[4 * q + 2], ptw[4 * q + 3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < IPT / 4; ++q)
+                *reinterpret_cast<uint2 *>(bc_pt + k0 + tid * IPT + 4 * q) = make_uint2(ptw[2 * q], ptw[2 * q + 1]);
+        }
 #pragma unroll
         for (int q = 0; q < IPT / 4; ++q)
             *reinterpret_cast<float4 *>(bc_w + k0 + tid * IPT + 4 * q) = make_float4(wq[4 * q], wq[4 * q + 1], wq[4 * q + 2], wq[4 * q + 3]);
     }
     __syncthreads();
-    for (int c = tid; c < nc; c += 256) {
+    for (int c = tid; c < nc; c += T) {
         const int r = c / np, i = c - r * np;
         srow[(size_t)r * sstride + p0 + i] = srow_tile[c];
     }
@@ -247,15 +257,19 @@ int sort_fill_blocks_lds(const int *evid, const float *ew, int n, int own_begin,
     // packed keys: the vertex field must leave the all-ones value to the padding (ids < m < 2^vb) and fit above the corner bits
     const int vb = vbits + (((int64_t)1 << vbits) == (int64_t)m_vertices ? 1 : 0);
     const int mode = (g_blk_sort != 0 && vb + cb <= 32) ? g_blk_sort : 0;      // 0: (key, value) pairs, 4 bits per pass
-#define PLX_BLK_SORT(IPT, PACKED, RBITS)                                                                                        \
-    blk_sort_fill_kernel<IPT, PACKED, RBITS><<<(unsigned)nblocks, 256, (size_t)cpb * 2, stream>>>(                              \
+#define PLX_BLK_SORT(E, PACKED, RBITS, T)                                                                                       \
+    blk_sort_fill_kernel<E, PACKED, RBITS, T><<<(unsigned)nblocks, T, (size_t)cpb * 2, stream>>>(                               \
         evid, ew, n, own_begin, n_own, P, d1, cpb, mode ? vb : vbits, bc_pt, bc_w, srow, sstride, rows_tmp, rows)
+    // mode: 0 = (key, value) pairs, 4 bits per pass; 4 / 5 / 6 = packed keys at that many bits per pass, 256 threads;
+    // 15 = packed keys, 5 bits, 512 threads
     if (ipt == 16) {
-        if (mode == 0) PLX_BLK_SORT(16, false, 4); else if (mode == 4) PLX_BLK_SORT(16, true, 4);
-        else if (mode == 6) PLX_BLK_SORT(16, true, 6); else PLX_BLK_SORT(16, true, 5);
+        if (mode == 0) PLX_BLK_SORT(16, false, 4, 256); else if (mode == 4) PLX_BLK_SORT(16, true, 4, 256);
+        else if (mode == 6) PLX_BLK_SORT(16, true, 6, 256); else if (mode == 5) PLX_BLK_SORT(16, true, 5, 256);
+        else PLX_BLK_SORT(16, true, 5, 512);
     } else {
-        if (mode == 0) PLX_BLK_SORT(24, false, 4); else if (mode == 4) PLX_BLK_SORT(24, true, 4);
-        else if (mode == 6) PLX_BLK_SORT(24, true, 6); else PLX_BLK_SORT(24, true, 5);
+        if (mode == 0) PLX_BLK_SORT(24, false, 4, 256); else if (mode == 4) PLX_BLK_SORT(24, true, 4, 256);
+        else if (mode == 6) PLX_BLK_SORT(24, true, 6, 256); else if (mode == 5) PLX_BLK_SORT(24, true, 5, 256);
+        else PLX_BLK_SORT(24, true, 5, 512);
     }
 #undef PLX_BLK_SORT
     PLX_HIP_TRY(hipGetLastError());
