@@ -178,6 +178,17 @@ int plx_splat(plx_lattice *lat, const float *d_src, int vd, float *d_values, voi
  * other columns and rows are zero.  What a pivoted Cholesky of the operator asks for: rows of K = slice(blur(this)).
  * Single-shard lattices. */
 int plx_splat_onehot(plx_lattice *lat, const int32_t *d_points, int nb, int vd, float *d_values, void *stream);
+/* The whole filter of nb <= 16 one-hot columns: d_out [n][vd] (rows as plx_set_row_order says) = K [e_p0 .. e_p(nb-1) 0 ..],
+ * p_b = d_points[b] in LATTICE order as above -- plx_splat_onehot + plx_blur + plx_slice in one call.  sparse != 0: the
+ * three stages run on the FRONTIER of the columns' non-zero vertex rows (d + 1 rows per column after the splat, at most
+ * 2 r + 1 times as many after every blur axis) instead of streaming all m rows d + 1 times; same operations in the same
+ * order as the dense kernels, so the same numbers.  The frontier path needs vd == 1 or vd % 4 == 0 with a 16-byte
+ * aligned d_out and a lattice built without "reference_growth"; otherwise (and with sparse == 0) the call runs the three
+ * dense stages.  d_values / d_scratch: [m][plx_values_stride(vd)] each, distinct, clobbered.  *d_frontier (device int32,
+ * optional): vertex rows the last blur axis worked on (m for the dense stages) -- a caller that batches such calls reads
+ * it back to see when the frontier stops being small.  Single-shard lattices. */
+int plx_filter_onehot(plx_lattice *lat, const int32_t *d_points, int nb, int vd, float *d_values, float *d_scratch,
+                      float *d_out, int sparse, int32_t *d_frontier, void *stream);
 
 /*
  * Stage 2 -- blur (h:513-572): d+1 Jacobi passes over the neighbour table,

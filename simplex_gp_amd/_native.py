@@ -51,6 +51,7 @@ _SIGNATURES = {
     "plx_set_row_order": (_i32, [_vp, _i32]),
     "plx_splat": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "plx_splat_onehot": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
+    "plx_filter_onehot": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
     "plx_blur": (_i32, [_vp, _vp, _vp, _i32, ctypes.POINTER(_i32), _vp]),
     "plx_slice": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "plx_apply": (_i32, [_vp, _vp, _i32, _vp, _vp]),

@@ -78,7 +78,7 @@ void release(DevBuf &b)
 static std::vector<DevBuf *> all_bufs(plx_lattice *L)
 {
     return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
-            &L->sort_keys_in, &L->slotmap, &L->nibmap, &L->prank, &L->vaxis, &L->vs0, &L->vowner, &L->ew_splat, &L->replay_vat, &L->replay_list, &L->replay_invisible, &L->ex_vid, &L->ex_pt, &L->ex_w, &L->ex_keys, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
+            &L->sort_keys_in, &L->slotmap, &L->nibmap, &L->prank, &L->vaxis, &L->vs0, &L->vowner, &L->ew_splat, &L->replay_vat, &L->replay_list, &L->replay_invisible, &L->oh_pos, &L->oh_list, &L->oh_cnt, &L->ex_vid, &L->ex_pt, &L->ex_w, &L->ex_keys, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->csr_vid, &L->row_ptr,
             &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
             &L->sortkey_in, &L->sortkey_out,
@@ -334,6 +334,19 @@ int plx_splat_onehot(plx_lattice *L, const int32_t *d_points, int nb, int vd, fl
     if (L->n_shards != 1 || L->partial_cover) { set_error("plx_splat_onehot: single-shard lattices only"); return PLX_ERR_STATE; }
     DeviceGuard g(L->device);
     return splat_onehot_impl(L, d_points, nb, vd, d_values, (hipStream_t)stream);
+}
+
+int plx_filter_onehot(plx_lattice *L, const int32_t *d_points, int nb, int vd, float *d_values, float *d_scratch, float *d_out,
+                      int sparse, int32_t *d_frontier, void *stream)
+{
+    EntryScope sc(L, stream);
+    PLX_TRY(check_apply(L, d_values, d_scratch, vd, "plx_filter_onehot"));
+    if (!d_points || !d_out) { set_error("plx_filter_onehot: NULL argument"); return PLX_ERR_INVALID; }
+    if (d_values == d_scratch) { set_error("plx_filter_onehot: d_values and d_scratch must be different buffers"); return PLX_ERR_INVALID; }
+    if (nb < 1 || nb > vd || nb > 16) { set_error("plx_filter_onehot: %d one-hot columns in %d (at most 16)", nb, vd); return PLX_ERR_INVALID; }
+    if (L->n_shards != 1 || L->partial_cover) { set_error("plx_filter_onehot: single-shard lattices only"); return PLX_ERR_STATE; }
+    DeviceGuard g(L->device);
+    return filter_onehot_impl(L, d_points, nb, vd, d_values, d_scratch, d_out, sparse, d_frontier, (hipStream_t)stream);
 }
 
 int plx_blur(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch, void *stream)

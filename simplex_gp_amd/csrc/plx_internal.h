@@ -274,6 +274,9 @@ struct plx_lattice {
     plx::DevBuf ew_splat;         // float [d+1][n]  the splat's copy of ew with the dropped lookups zeroed (replay mode)
     plx::DevBuf replay_vat, replay_list, replay_invisible;   // int32 scratch / lists of the replay
 
+    // plx_filter_onehot (plx_onehot.hip): frontier of the non-zero vertex rows
+    plx::DevBuf oh_pos, oh_list, oh_cnt;      // int32 [m] position of a vertex in the list or -1; int32 [m] the list; int32 counters
+
     // apply workspace
     plx::DevBuf head_partial, tail_partial;   // float [nchunks][vd]
     plx::DevBuf val_a, val_b;                 // float [m][vdp]   (vdp = value row stride, plx_values_stride)
@@ -345,6 +348,9 @@ int compact_block_rows(const int *rows_tmp, const int *brow_ptr, int cpb, int64_
 // plx_splat.hip / plx_blur.hip / plx_slice.hip
 int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipStream_t stream);
 int splat_onehot_impl(plx_lattice *L, const int *d_cand, int nb, int vd, float *d_values, hipStream_t stream);
+// plx_onehot.hip: K e_p for nb points (splat, blur, slice of one-hot columns); sparse != 0: on the frontier of the non-zeros where the lattice allows
+int filter_onehot_impl(plx_lattice *L, const int *d_cand, int nb, int vd, float *d_values, float *d_scratch, float *d_out,
+                       int sparse, int *d_frontier, hipStream_t stream);
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
 int build_blur_pairs(plx_lattice *L, hipStream_t stream);   // composite neighbour tables of the two-axes-per-launch blur

@@ -416,36 +416,36 @@ __global__ __launch_bounds__(kBlock) void pchol_top_partial_kernel(const float *
     }
 }
 
-// Batch state (device): stf[0] = residual diagonal at the pivot of the next in-batch step, stf[1 + b'] = L[pivot][m + b']
-// of the in-batch columns already written; sti[0] = stop (the argmax is not among the batch's unused candidates),
-// sti[1] = accepted, sti[2] = bit mask of the candidates used so far, sti[4 + b] = the candidate (batch column) step b uses.
+// Batch state (device ints, two slots of 8: slot[0] = stop (the argmax is not among the batch's unused candidates),
+// slot[1] = bit mask of the candidates used so far, slot[2] = the candidate (batch column) the step uses, slot[3] = the
+// residual diagonal at its pivot (float bits).  Step b runs under state S_b; S_0 is seeded by plx_pchol_select (the first
+// candidate IS the argmax), S_b (b >= 1) follows from S_(b-1) and the argmax partials step b - 1 left.
 // The candidates are the nb largest diagonal entries when the batch starts, but the ORDER in which the sequential
 // algorithm takes them is only known step by step (an entry touched by an earlier pivot's column falls behind untouched
 // ones): every step looks its true argmax up among the unused candidates, so a batch only ends when the argmax is an
 // entry whose kernel row was not computed.
 __global__ __launch_bounds__(1024) void pchol_top_final_kernel(const uint64_t *__restrict__ pkey, const int *__restrict__ pidx,
-                                                               int count, int nb, int *__restrict__ cand,
-                                                               float *__restrict__ stf, int *__restrict__ sti)
+                                                               int parts, int nb, int *__restrict__ cand,
+                                                               int *__restrict__ state)
 {
+    // every part's list is sorted (largest first): a `parts`-way merge, one list head per thread (parts <= 1024), one
+    // workgroup argmax per output instead of a scan of all parts * nb keys
     __shared__ uint64_t skey[1024 / 64];
     __shared__ int sidx[1024 / 64];
-    __shared__ uint64_t s_last;
-    uint64_t last = ~0ull;
+    __shared__ int s_win;
+    const int p = threadIdx.x;
+    int head = 0;
     for (int r = 0; r < nb; ++r) {
-        uint64_t best = 0;
-        int bi = -1;
-        for (int x = threadIdx.x; x < count; x += blockDim.x) {
-            const uint64_t key = pkey[x];
-            if (key < last && key > best) { best = key; bi = pidx[x]; }
-        }
-        block_argmax(best, bi, skey, sidx);
+        uint64_t best = (p < parts && head < nb) ? pkey[(size_t)p * nb + head] : 0;
+        int who = p;
+        block_argmax(best, who, skey, sidx);
         if (threadIdx.x == 0) {
-            cand[r] = bi;
-            if (r == 0) { stf[0] = __uint_as_float((uint32_t)(best >> 32)); sti[0] = 0; sti[1] = 0; sti[2] = 1; sti[4] = 0; }
-            s_last = best;
+            s_win = best ? who : -1;
+            if (!best) cand[r] = -1;
+            if (r == 0) { state[0] = 0; state[1] = 1; state[2] = 0; state[3] = (int)(uint32_t)(best >> 32); }
         }
         __syncthreads();
-        last = s_last;
+        if (p == s_win) { cand[r] = pidx[(size_t)p * nb + head]; ++head; }     // keys are distinct (the rank is part of the key)
         __syncthreads();
     }
 }
@@ -466,28 +466,69 @@ __global__ __launch_bounds__(kBlock) void pchol_gather_kernel(const float *__res
     W[x] = (b < nb && cand[b] >= 0) ? lt[(int64_t)j * ld + cand[b]] : 0.f;
 }
 
-// in-batch step b: column m + b of the factor from the panel row b, corrected by the in-batch columns before it;
-// the residual diagonal is updated in place and its argmax partials are left for pchol_step_final_kernel
-__global__ __launch_bounds__(kBlock) void pchol_step_kernel(float *__restrict__ lt, int64_t ld, int m, int b,
+// in-batch step b: column m + b of the factor from the panel row of the candidate the step uses, corrected by the
+// in-batch columns before it; the residual diagonal is updated in place and every workgroup leaves the argmax of its part
+// of the updated diagonal.  Which candidate step b uses is decided at the START of its launch, by every workgroup for
+// itself from the partials step b - 1 left (1024 keys: a few microseconds, against a launch of a single-workgroup kernel
+// between every two steps -- 5 us per step, a third of the step); workgroup 0 records the decision for step b + 1 in
+// the state slot no workgroup of this launch reads, and the partials alternate between two halves of their buffer for
+// the same reason.  Nothing is read that was written earlier in the same launch.
+__global__ __launch_bounds__(kBlock) void pchol_step_kernel(float *__restrict__ lt, int64_t ld, int m, int b, int nb,
                                                             const float *__restrict__ rowsT, float *__restrict__ diag,
                                                             const uint32_t *__restrict__ rank, int64_t n,
-                                                            const int *__restrict__ cand, const float *__restrict__ stf,
-                                                            const int *__restrict__ sti, float tol_abs,
-                                                            uint64_t *__restrict__ pkey, int *__restrict__ pidx)
+                                                            const int *__restrict__ cand, int *__restrict__ state,
+                                                            float tol_abs, uint64_t *__restrict__ pkey, int *__restrict__ pidx,
+                                                            int *__restrict__ accepted)
 {
     __shared__ uint64_t skey[kBlock / 64];
     __shared__ int sidx[kBlock / 64];
-    if (sti[0]) return;
-    const float dmax = stf[0];
-    const bool ok = dmax > tol_abs;
-    const float root = sqrtf(fmaxf(dmax, 1e-30f));
-    const int col_b = sti[4 + b];               // the batch column (candidate) this step uses
-    const int piv = cand[col_b];
-    float w[kPcholMaxBatch];
-#pragma unroll
-    for (int q = 0; q < kPcholMaxBatch; ++q) w[q] = q < b ? stf[1 + q] : 0.f;
+    __shared__ int s_stop, s_col;
+    __shared__ float s_dmax, s_w[kPcholMaxBatch];
     uint64_t best = 0;
     int bi = -1;
+    if (b == 0) {
+        if (threadIdx.x == 0) { s_stop = state[0]; s_col = state[2]; s_dmax = __int_as_float(state[3]); }
+    } else {
+        const int *prev = state + 8 * ((b - 1) & 1);
+        int *cur = state + 8 * (b & 1);
+        if (prev[0]) {                             // (uniform) the batch ended at an earlier step
+            if (blockIdx.x == 0 && threadIdx.x == 0) cur[0] = 1;
+            return;
+        }
+        const uint64_t *pk = pkey + (size_t)((b - 1) & 1) * kPcholParts;
+        const int *pi = pidx + (size_t)((b - 1) & 1) * kPcholParts;
+        for (int x = threadIdx.x; x < (int)gridDim.x; x += kBlock) {
+            const uint64_t key = pk[x];
+            if (key > best) { best = key; bi = pi[x]; }
+        }
+        block_argmax(best, bi, skey, sidx);
+        if (threadIdx.x == 0) {
+            // the sequential algorithm's next pivot is the argmax `bi`: is its kernel row in this batch, still unused?
+            const int used = prev[1];
+            int j = -1;
+            for (int q = 0; q < nb; ++q)
+                if (!((used >> q) & 1) && cand[q] == bi) { j = q; break; }
+            s_stop = j < 0;
+            s_col = j;
+            s_dmax = __uint_as_float((uint32_t)(best >> 32));
+            if (blockIdx.x == 0) { cur[0] = j < 0; cur[1] = used | (j < 0 ? 0 : 1 << j); cur[2] = j; cur[3] = (int)(uint32_t)(best >> 32); }
+        }
+    }
+    __syncthreads();
+    if (s_stop) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *accepted = b + 1;       // what the host reads back after the batch
+    const float dmax = s_dmax;
+    const bool ok = dmax > tol_abs;
+    const float root = sqrtf(fmaxf(dmax, 1e-30f));
+    const int col_b = s_col;                    // the batch column (candidate) this step uses
+    const int piv = cand[col_b];
+    if ((int)threadIdx.x < b) s_w[threadIdx.x] = lt[(int64_t)(m + threadIdx.x) * ld + piv];    // L[pivot][m + q] of the in-batch columns so far
+    __syncthreads();
+    float w[kPcholMaxBatch];
+#pragma unroll
+    for (int q = 0; q < kPcholMaxBatch; ++q) w[q] = q < b ? s_w[q] : 0.f;
+    best = 0;
+    bi = -1;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         float v = rowsT[(int64_t)col_b * ld + i];
 #pragma unroll
@@ -502,48 +543,10 @@ __global__ __launch_bounds__(kBlock) void pchol_step_kernel(float *__restrict__ 
         if (key > best) { best = key; bi = (int)i; }
     }
     block_argmax(best, bi, skey, sidx);
-    if (threadIdx.x == 0) { pkey[blockIdx.x] = best; pidx[blockIdx.x] = bi; }
-}
-
-__global__ __launch_bounds__(1024) void pchol_step_final_kernel(const uint64_t *__restrict__ pkey, const int *__restrict__ pidx,
-                                                                int count, const float *__restrict__ lt, int64_t ld, int m,
-                                                                int b, int nb, const int *__restrict__ cand,
-                                                                float *__restrict__ stf, int *__restrict__ sti)
-{
-    __shared__ uint64_t skey[1024 / 64];
-    __shared__ int sidx[1024 / 64];
-    __shared__ int s_go;
-    if (sti[0]) return;
-    uint64_t best = 0;
-    int bi = -1;
-    for (int x = threadIdx.x; x < count; x += blockDim.x) {
-        const uint64_t key = pkey[x];
-        if (key > best) { best = key; bi = pidx[x]; }
-    }
-    block_argmax(best, bi, skey, sidx);
-    __shared__ int s_bi;
     if (threadIdx.x == 0) {
-        s_bi = bi;
-        sti[1] = b + 1;
-        int go = 0;
-        if (b + 1 < nb) {
-            // the sequential algorithm's next pivot is the argmax `bi`: is its kernel row in this batch, still unused?
-            const int used = sti[2];
-            int j = -1;
-            for (int q = 0; q < nb; ++q)
-                if (!((used >> q) & 1) && cand[q] == bi) { j = q; break; }
-            if (j < 0) sti[0] = 1;
-            else {
-                sti[2] = used | (1 << j);
-                sti[4 + b + 1] = j;
-                stf[0] = __uint_as_float((uint32_t)(best >> 32));
-                go = 1;
-            }
-        }
-        s_go = go;
+        pkey[(size_t)(b & 1) * kPcholParts + blockIdx.x] = best;
+        pidx[(size_t)(b & 1) * kPcholParts + blockIdx.x] = bi;
     }
-    __syncthreads();
-    if (s_go && (int)threadIdx.x <= b) stf[1 + threadIdx.x] = lt[(int64_t)(m + threadIdx.x) * ld + s_bi];
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
@@ -601,10 +604,10 @@ static size_t pcg_gram_floats(int kp) { return (size_t)kGramBlocksMax * kPcgCols
 
 // work layout of the pchol calls (bytes)
 struct PcholWork {
-    float *rowsT; float *W; uint64_t *pkey; int *pidx; float *stf; int *sti;
+    float *rowsT; float *W; uint64_t *pkey; int *pidx; int *state;
     static size_t bytes(int64_t ld, int kp)
     {
-        return (size_t)kPcgCols * ld * 4 + (size_t)kp * kPcgCols * 4 + (size_t)kPcholParts * kPcholMaxBatch * 12 + 256;
+        return (size_t)kPcgCols * ld * 4 + (size_t)kp * kPcgCols * 4 + (size_t)kPcholParts * kPcholMaxBatch * 12 + 512;
     }
     PcholWork(void *base, int64_t ld, int kp)
     {
@@ -613,8 +616,7 @@ struct PcholWork {
         W = (float *)p; p += (size_t)kp * kPcgCols * 4;
         pkey = (uint64_t *)p; p += (size_t)kPcholParts * kPcholMaxBatch * 8;
         pidx = (int *)p; p += (size_t)kPcholParts * kPcholMaxBatch * 4;
-        stf = (float *)p; p += 128;
-        sti = (int *)p;
+        state = (int *)p;
     }
 };
 
@@ -721,7 +723,7 @@ extern "C" int plx_pchol_select(const float *d_diag, const uint32_t *d_rank, int
     hipStream_t s = (hipStream_t)stream;
     const int parts = std::min<int64_t>(kPcholParts, ceil_div(n, kBlock));
     pchol_top_partial_kernel<<<parts, kBlock, 0, s>>>(d_diag, d_rank, n, nb, w.pkey, w.pidx);
-    pchol_top_final_kernel<<<1, 1024, 0, s>>>(w.pkey, w.pidx, parts * nb, nb, d_cand, w.stf, w.sti);
+    pchol_top_final_kernel<<<1, 1024, 0, s>>>(w.pkey, w.pidx, parts, nb, d_cand, w.state);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }
@@ -754,12 +756,9 @@ extern "C" int plx_pchol_factor_batch(float *d_lt, int64_t ld, int kp, int m_don
     // panel: rowsT[b][i] = scale * rows[i][b] - sum_{j < m} L[i][j] L[cand_b][j]
     PLX_TRY((apply_launch<true, false>(d_lt, ld, m_done, d_rows, n, t, w.W, d_scale, w.rowsT, ld, nullptr, s)));
     const int parts = std::min<int64_t>(kPcholParts, ceil_div(n, kBlock));
-    for (int b = 0; b < nb; ++b) {
-        pchol_step_kernel<<<parts, kBlock, 0, s>>>(d_lt, ld, m_done, b, w.rowsT, d_diag, d_rank, n, d_cand, w.stf, w.sti, tol_abs,
-                                                   w.pkey, w.pidx);
-        pchol_step_final_kernel<<<1, 1024, 0, s>>>(w.pkey, w.pidx, parts, d_lt, ld, m_done, b, nb, d_cand, w.stf, w.sti);
-    }
+    for (int b = 0; b < nb; ++b)
+        pchol_step_kernel<<<parts, kBlock, 0, s>>>(d_lt, ld, m_done, b, nb, w.rowsT, d_diag, d_rank, n, d_cand, w.state, tol_abs,
+                                                   w.pkey, w.pidx, d_accepted);
     PLX_HIP_TRY(hipGetLastError());
-    PLX_HIP_TRY(hipMemcpyAsync(d_accepted, w.sti + 1, 4, hipMemcpyDeviceToDevice, s));
     return PLX_OK;
 }

@@ -293,6 +293,26 @@ class Lattice:
         nv.check(rc, "plx_splat_onehot")
         return values
 
+    def filter_onehot(self, points, nb, values, scratch, out, vd=None, sparse=True, frontier=None):
+        """out[:, b] = K e_p for p = points[b] (device int32, lattice-order point indices), b < nb <= 16: splat_onehot +
+        blur + slice in one call; sparse=True runs them on the frontier of the columns' non-zero vertex rows
+        (plx_filter_onehot).  values / scratch: two [m, values_stride(vd)] buffers (clobbered); out: [n, vd], rows in
+        the order set_lattice_row_order() says; frontier (optional device int32 [1]) receives the vertex rows the last
+        blur axis worked on."""
+        vd = out.shape[1] if vd is None else vd
+        _check_f32_cuda(values, "values"); _check_f32_cuda(scratch, "scratch"); _check_f32_cuda(out, "out")
+        assert values.shape[1] == self.values_stride(vd) and values.is_contiguous() and scratch.shape == values.shape
+        assert scratch.is_contiguous() and values.shape[0] >= self.m and points.dtype == torch.int32 and points.numel() >= nb
+        assert out.is_contiguous() and out.shape == (self.n_owned, vd)
+        with torch.cuda.device(self.device):
+            rc = nv.lib().plx_filter_onehot(self._h, ctypes.c_void_p(points.data_ptr()), int(nb), vd,
+                                            ctypes.c_void_p(values.data_ptr()), ctypes.c_void_p(scratch.data_ptr()),
+                                            ctypes.c_void_p(out.data_ptr()), 1 if sparse else 0,
+                                            ctypes.c_void_p(frontier.data_ptr()) if frontier is not None else None,
+                                            _stream_ptr(self.device))
+        nv.check(rc, "plx_filter_onehot")
+        return out
+
     def blur(self, values, scratch=None, vd=None):
         """Returns the tensor holding the blurred values (either `values` or `scratch`).
         `values` is [m, values_stride(vd)]; vd defaults to its width."""

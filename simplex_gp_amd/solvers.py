@@ -170,6 +170,45 @@ def _vp(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_host_threads_checked = False
+
+
+def cap_host_threads(force=False):
+    """Once per process, before the first small host factorisation of a solve (the k x k Cholesky of the
+    preconditioner, the Lanczos tridiagonals' eigen-decompositions): if the process runs under a cgroup CPU quota
+    smaller than the thread pool torch / MKL would start (a container that SEES 256 CPUs but may use 16 of them -- the
+    MI355X boxes), cap the pool at half the quota.  A 128-thread pool spinning for a 100 x 100 Cholesky uses up the
+    quota of the scheduler period and the whole process is throttled for the rest of it: measured as 30-100 ms stalls
+    in a few of every hundred calls (cpu.stat: nr_throttled), in whatever the host thread happened to be doing.
+    Nothing is changed when OMP_NUM_THREADS / MKL_NUM_THREADS are set (the user has decided) or no quota applies.
+    Returns the thread count in force."""
+    global _host_threads_checked
+    if _host_threads_checked and not force:
+        return torch.get_num_threads()
+    _host_threads_checked = True
+    import os
+    if os.environ.get("OMP_NUM_THREADS") or os.environ.get("MKL_NUM_THREADS"):
+        return torch.get_num_threads()
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]               # cgroup v2
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())         # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        cap = max(1, int(quota) // 2)
+        if torch.get_num_threads() > cap:
+            torch.set_num_threads(cap)
+    return torch.get_num_threads()
+
+
 class LatticePreconditioner:
     """The same preconditioner, P = L L^T + sigma^2 I with L the rank-k pivoted Cholesky factor of s K, on the HIP path
     (experiments/train_simplexgp.py:36: the reference trains with max_preconditioner_size(100)).
@@ -190,8 +229,9 @@ class LatticePreconditioner:
     """
 
     MAX_RANK = 1024          # factor columns the native passes hold (plx_pcg.hip: factor_shape_ok)
+    SPARSE_ROWS_MAX_FRACTION = 0.5    # kernel rows are computed on the frontier of their non-zero vertex rows while a batch's frontier stays under this share of the lattice
 
-    def __init__(self, lat, outputscale, noise, rank, rel_tol=1e-6, batch=12, factor_dtype=torch.float16):
+    def __init__(self, lat, outputscale, noise, rank, rel_tol=1e-6, batch=12, factor_dtype=torch.float16, sparse_rows=True):
         import ctypes
         from . import _native as nv
         lib = nv.lib()
@@ -218,12 +258,14 @@ class LatticePreconditioner:
             nv.check(lib.plx_copy_point_perm(lat._h, _vp(row_rank), stream), "plx_copy_point_perm")
             work = torch.empty(int(lib.plx_pchol_work_bytes(ld, kp)), dtype=torch.uint8, device=dev)
             cand = torch.empty(16, dtype=torch.int32, device=dev)
-            accepted = torch.zeros(1, dtype=torch.int32, device=dev)
+            status = torch.zeros(2, dtype=torch.int32, device=dev)    # [pivots the batch accepted, vertex rows its filter worked on]
+            accepted, frontier = status[0:1], status[1:2]
             scale = torch.tensor([s, 1.0], dtype=torch.float32, device=dev)
             was_lattice = lat.lattice_rows
             lat.set_lattice_row_order(True)
             bufs = {}
-            m, B, self.batches = 0, max(1, min(int(batch), 16)), 0
+            m, B, self.batches, self.sparse_batches = 0, max(1, min(int(batch), 16)), 0, 0
+            sparse = bool(sparse_rows)
             try:
                 while m < k:
                     nb = min(B, k - m, n)
@@ -233,18 +275,21 @@ class LatticePreconditioner:
                     rows, vals, scratch = bufs[t]
                     nv.check(lib.plx_pchol_select(_vp(diag), _vp(row_rank), n, nb, ld, kp, _vp(cand), _vp(work), stream),
                              "plx_pchol_select")
-                    # K e_p for the nb candidates: the splat of one-hot columns is d + 1 numbers per column (plx_splat_onehot),
-                    # then the usual blur and slice
-                    lat.splat_onehot(cand, nb, vals, vd=t)
-                    lat.slice(lat.blur(vals, scratch, vd=t), rows, vd=t)
+                    # K e_p for the nb candidates: splat, blur and slice of one-hot columns, on the frontier of their
+                    # non-zero vertex rows while that is a small part of the lattice (plx_filter_onehot)
+                    lat.filter_onehot(cand, nb, vals, scratch, rows, vd=t, sparse=sparse, frontier=frontier)
                     nv.check(lib.plx_pchol_factor_batch(_vp(self.Lt), ld, kp, m, _vp(rows), t, _vp(scale), _vp(cand), nb, _vp(diag),
                                                         _vp(row_rank), n, float(rel_tol * s), _vp(accepted), _vp(work), stream),
                              "plx_pchol_factor_batch")
-                    a = int(accepted.item())                   # the one host read-back of the batch
+                    a, front = status.tolist()                 # the one host read-back of the batch
                     if not 1 <= a <= nb:               # (an assert would vanish under python -O and a == 0 would spin forever)
                         raise RuntimeError(f"plx_pchol_factor_batch accepted {a} of {nb} speculated pivots")
                     m += a
                     self.batches += 1
+                    self.sparse_batches += int(sparse)
+                    # on a coarse lattice every kernel row touches most vertices: the dense passes are the cheaper ones there
+                    if sparse and front > self.SPARSE_ROWS_MAX_FRACTION * lat.m:
+                        sparse = False
                     # speculation depth follows what the lattice accepts: dense kernels (few, strongly coupled points)
                     # end a batch at the first or second pivot, sparse ones take every candidate
                     B = min(int(batch), 16, 2 * a) if a < nb else min(int(batch), 16, max(B, 2 * a))
@@ -264,6 +309,7 @@ class LatticePreconditioner:
         A = self.Lt[:k].reshape(k, 64, ld // 64).permute(1, 0, 2)
         C = torch.bmm(A, A.transpose(1, 2)).double().sum(0) + noise * torch.eye(k, dtype=torch.float64, device=dev)
         # the k x k factorisation and inverse on the host: 80 KB each way, against a dozen ~100 us launches of the device solver
+        cap_host_threads()
         self._chol = torch.linalg.cholesky(C.cpu())
         cinv = torch.eye(kp, dtype=torch.float64) / noise
         cinv[:k, :k] = torch.cholesky_inverse(self._chol)
@@ -603,6 +649,8 @@ def slq_terms(tridiag):
     launches for eleven 20 x 20 problems; the copy is a few KB and the solve has just synchronised anyway)."""
     dev = tridiag.device
     small = dev.type == "cuda" and tridiag.shape[0] * tridiag.shape[-1] ** 2 <= 1 << 18
+    if small:
+        cap_host_threads()
     evals, evecs = torch.linalg.eigh(tridiag.cpu() if small else tridiag)
     terms = ((evecs[:, 0, :] ** 2) * evals.clamp_min(1e-30).log()).sum(-1)
     return terms.to(dev) if small else terms

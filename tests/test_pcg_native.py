@@ -265,3 +265,49 @@ def test_onehot_splat_and_recycled_lattice_guard(plx):
         with pytest.raises(RuntimeError, match="rebuilt"):
             pre.solve(R)
     plx.lattice_cache().clear()
+
+
+@pytest.mark.parametrize("n,d,ell,order", [(20000, 4, 1.0, 1), (30000, 8, 0.5, 1), (3000, 3, 0.3, 2), (5000, 12, 0.8, 1),
+                                           (2000, 2, 0.05, 3), (40000, 6, 2.5, 1), (1500, 18, 1.0, 1)])
+def test_filter_onehot_on_the_frontier_equals_the_dense_stages(plx, n, d, ell, order):
+    """plx_filter_onehot (kernel rows K e_p on the frontier of their non-zero vertex rows) against the dense
+    splat_onehot + blur + slice it replaces (same operations in the same order: equal bits for multi-column rows) and
+    against plx_apply of the one-hot right-hand side; both row orders; candidates that sit next to each other (shared
+    vertices between columns), repeated calls on the same lattice (the position map is reset per call), and a lattice
+    coarse enough that the frontier ends up holding every vertex."""
+    g = torch.Generator().manual_seed(n + d)
+    x = (torch.randn(n, d, generator=g) / ell).cuda()
+    half = np.linspace(0.2, 0.7, order).astype(np.float32)
+    taps = np.concatenate([half, [1.0], half[::-1]]).astype(np.float32)
+    lat = plx.Lattice().build(x, taps)
+    from simplex_gp_amd import _native as nv
+    perm = torch.from_numpy(lat.export(nv.ARRAY_POINT_PERM).astype(np.int64)).cuda()
+    frontier = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for lattice_rows in (True, False):
+        lat.set_lattice_row_order(lattice_rows)
+        for t, nb in ((1, 1), (4, 3), (12, 12), (16, 13), (8, 8)):
+            pts = torch.randperm(n, generator=g)[:nb].to(torch.int32)
+            if nb >= 3:
+                pts[1] = (pts[0] + 1) % n          # neighbours in lattice order: their simplices share vertices
+                pts[2] = pts[0]                    # ... and the same point twice
+            pts = pts.cuda()
+            vals, scratch = lat.new_values(t), lat.new_values(t)
+            dense = torch.full((n, t), 3.0, device="cuda")
+            lat.filter_onehot(pts, nb, vals, scratch, dense, vd=t, sparse=False, frontier=frontier)
+            assert int(frontier.item()) == lat.m
+            got = torch.full((n, t), 5.0, device="cuda")
+            lat.filter_onehot(pts, nb, vals, scratch, got, vd=t, sparse=True, frontier=frontier)
+            f = int(frontier.item())
+            assert (d + 1) <= f <= lat.m
+            rhs = torch.zeros(n, t, device="cuda")
+            rows = pts.long() if lattice_rows else perm[pts.long()]
+            rhs[rows, torch.arange(nb, device="cuda")] = 1.0
+            want = lat.apply(rhs)
+            if t > 1:
+                assert torch.equal(got, dense), (lattice_rows, t, nb, float((got - dense).abs().max()))
+            scale = float(want.abs().max())
+            assert float((got - dense).abs().max()) <= 2e-6 * scale
+            assert float((got - want).abs().max()) <= 2e-6 * scale, (lattice_rows, t, nb)
+            assert got[:, nb:].abs().max() == 0 if nb < t else True
+    lat.set_lattice_row_order(False)
+    lat.close()
