@@ -314,14 +314,20 @@ int plx_pcg_step_direction(float *d_p, const float *d_z, const float *d_rz_new, 
  *                           torch.argmax breaks them on the caller-order vector; seeds the batch state in d_work;
  *   plx_pchol_onehot        d_rhs [n][t] = the nb one-hot columns (t >= nb; the caller runs the MVM on it);
  *   plx_pchol_factor_batch  d_rows [n][t] = K d_rhs.  Panel update against the m_done finished columns
- *                           (d_scale[0] d_rows - L L[cand]^T, one pass over them), then the nb in-batch steps in pivot
- *                           order: column m_done + b = row b / sqrt(pivot) (zero if the pivot is <= tol_abs), residual
- *                           diagonal updated, and the argmax of the updated diagonal looked up ON THE DEVICE among the
- *                           batch's unused candidates (the sequential algorithm may take them in another order than
- *                           their values at the start of the batch suggest) -- the batch ends when the argmax is an entry
- *                           whose kernel row is not in it.  *d_accepted (device int32) = columns written (>= 1: the first
- *                           candidate is the argmax by construction); the caller reads it back once per batch and carries
- *                           on from m_done + accepted.
+ *                           (d_scale[0] d_rows - L L[cand]^T, one pass over them), then the in-batch steps in pivot
+ *                           order: column m_done + b = panel row of the step's pivot / sqrt(pivot) (zero if the pivot is
+ *                           <= tol_abs), residual diagonal updated.  Which candidate a step takes is the argmax of the
+ *                           updated diagonal (the sequential algorithm may take the candidates in another order than
+ *                           their values at the start of the batch suggest).  The steps whose argmax is CERTAIN from the
+ *                           candidates' own entries -- the largest unused candidate still lies above the largest entry
+ *                           outside the batch, which a step can only lower -- are planned on the nb x nb block of the
+ *                           panel and written in ONE pass over the n-vectors ("planned" steps, >= 1).  exact_steps != 0:
+ *                           the remaining candidates are then tried one launch per step, the argmax looked up on the
+ *                           device among them; the batch ends when the argmax is an entry whose kernel row is not in
+ *                           it.  exact_steps == 0: the batch ends with the plan.  d_accepted (device int32 [2]) =
+ *                           {columns written, planned steps}; the caller reads it back once per batch, carries on from
+ *                           m_done + accepted and passes exact_steps = 0 while whole batches come out planned (sparse
+ *                           kernel rows: a column touches few other candidates).
  * d_work: plx_pchol_work_bytes(ld, kp) bytes, the same buffer for the three calls of a batch.
  */
 int64_t plx_pchol_work_bytes(int64_t ld, int kp);
@@ -330,7 +336,7 @@ int plx_pchol_select(const float *d_diag, const uint32_t *d_rank, int64_t n, int
 int plx_pchol_onehot(const int32_t *d_cand, int nb, int64_t n, int t, float *d_rhs, void *stream);
 int plx_pchol_factor_batch(float *d_lt, int64_t ld, int kp, int m_done, const float *d_rows, int t, const float *d_scale,
                            const int32_t *d_cand, int nb, float *d_diag, const uint32_t *d_rank, int64_t n, float tol_abs,
-                           int32_t *d_accepted, void *d_work, void *stream);
+                           int exact_steps, int32_t *d_accepted, void *d_work, void *stream);
 
 /* Copy one structure array to host memory (parity tests, debugging).
  * h_dst must hold `bytes` bytes, which must equal the array's size. */

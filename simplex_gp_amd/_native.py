@@ -77,7 +77,7 @@ _SIGNATURES = {
     "plx_pchol_select": (_i32, [_vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp]),
     "plx_pchol_onehot": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "plx_pchol_factor_batch": (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i64, ctypes.c_float,
-                                      _vp, _vp, _vp]),
+                                      _i32, _vp, _vp, _vp]),
     "plx_export": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "plx_export_bytes": (_i64, [_vp, _i32]),
     "plx_copy_point_perm": (_i32, [_vp, _vp, _vp]),

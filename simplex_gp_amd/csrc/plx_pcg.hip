@@ -418,36 +418,52 @@ __global__ __launch_bounds__(kBlock) void pchol_top_partial_kernel(const float *
 
 // Batch state (device ints, two slots of 8: slot[0] = stop (the argmax is not among the batch's unused candidates),
 // slot[1] = bit mask of the candidates used so far, slot[2] = the candidate (batch column) the step uses, slot[3] = the
-// residual diagonal at its pivot (float bits).  Step b runs under state S_b; S_0 is seeded by plx_pchol_select (the first
-// candidate IS the argmax), S_b (b >= 1) follows from S_(b-1) and the argmax partials step b - 1 left.
+// residual diagonal at its pivot (float bits).  Step b runs under state S_b; S_b (b >= 1) follows from S_(b-1) and the
+// argmax partials step b - 1 left.
 // The candidates are the nb largest diagonal entries when the batch starts, but the ORDER in which the sequential
 // algorithm takes them is only known step by step (an entry touched by an earlier pivot's column falls behind untouched
 // ones): every step looks its true argmax up among the unused candidates, so a batch only ends when the argmax is an
 // entry whose kernel row was not computed.
+
+// cand[0..nsel-1) = the nsel - 1 largest keys' entries, *knext = the nsel-th largest key (0: none) -- a bound on every
+// entry that is NOT a candidate.  Every part's list is sorted (largest first): a `parts`-way merge by ONE wave, every lane
+// in charge of 16 lists whose first kDepth keys sit in LDS (a deeper list is read from memory: the largest entries of a
+// diagonal are spread over the parts).  (One list head per thread of a 1024-thread workgroup and a workgroup argmax per
+// output: 27 us for 12 outputs; scanning all parts * nsel keys per output: 47 us.)
+constexpr int kTopDepth = 4;
 __global__ __launch_bounds__(1024) void pchol_top_final_kernel(const uint64_t *__restrict__ pkey, const int *__restrict__ pidx,
-                                                               int parts, int nb, int *__restrict__ cand,
-                                                               int *__restrict__ state)
+                                                               int parts, int nsel, int *__restrict__ cand,
+                                                               uint64_t *__restrict__ knext)
 {
-    // every part's list is sorted (largest first): a `parts`-way merge, one list head per thread (parts <= 1024), one
-    // workgroup argmax per output instead of a scan of all parts * nb keys
-    __shared__ uint64_t skey[1024 / 64];
-    __shared__ int sidx[1024 / 64];
-    __shared__ int s_win;
-    const int p = threadIdx.x;
-    int head = 0;
-    for (int r = 0; r < nb; ++r) {
-        uint64_t best = (p < parts && head < nb) ? pkey[(size_t)p * nb + head] : 0;
-        int who = p;
-        block_argmax(best, who, skey, sidx);
-        if (threadIdx.x == 0) {
-            s_win = best ? who : -1;
-            if (!best) cand[r] = -1;
-            if (r == 0) { state[0] = 0; state[1] = 1; state[2] = 0; state[3] = (int)(uint32_t)(best >> 32); }
-        }
-        __syncthreads();
-        if (p == s_win) { cand[r] = pidx[(size_t)p * nb + head]; ++head; }     // keys are distinct (the rank is part of the key)
-        __syncthreads();
+    __shared__ uint64_t keys[1024 * kTopDepth];
+    __shared__ unsigned char head[1024];
+    __shared__ int win_part[kPcholMaxBatch + 1], win_depth[kPcholMaxBatch + 1];
+    for (int x = threadIdx.x; x < 1024 * kTopDepth; x += 1024) {
+        const int p = x / kTopDepth, h = x % kTopDepth;
+        keys[x] = (p < parts && h < nsel) ? pkey[(size_t)p * nsel + h] : 0;
     }
+    head[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    for (int r = 0; r < nsel; ++r) {
+        uint64_t best = 0;
+        int who = -1;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int p = lane * 16 + u, h = head[p];
+            const uint64_t key = h < kTopDepth ? keys[p * kTopDepth + h] : ((p < parts && h < nsel) ? pkey[(size_t)p * nsel + h] : 0);
+            if (key > best) { best = key; who = p; }
+        }
+        wave_argmax(best, who);                    // (every lane ends up with the maximum)
+        if (lane == 0) {
+            win_part[r] = best ? who : -1;
+            win_depth[r] = best ? head[who] : 0;
+            if (r == nsel - 1) *knext = best;
+        }
+        if (best && (who >> 4) == lane) head[who] += 1;          // keys are distinct (the rank is part of the key)
+    }
+    if (lane < nsel - 1) cand[lane] = win_part[lane] >= 0 ? pidx[(size_t)win_part[lane] * nsel + win_depth[lane]] : -1;
 }
 
 __global__ void pchol_onehot_kernel(const int *__restrict__ cand, int nb, int t, float *__restrict__ rhs)
@@ -466,57 +482,194 @@ __global__ __launch_bounds__(kBlock) void pchol_gather_kernel(const float *__res
     W[x] = (b < nb && cand[b] >= 0) ? lt[(int64_t)j * ld + cand[b]] : 0.f;
 }
 
-// in-batch step b: column m + b of the factor from the panel row of the candidate the step uses, corrected by the
-// in-batch columns before it; the residual diagonal is updated in place and every workgroup leaves the argmax of its part
-// of the updated diagonal.  Which candidate step b uses is decided at the START of its launch, by every workgroup for
-// itself from the partials step b - 1 left (1024 keys: a few microseconds, against a launch of a single-workgroup kernel
-// between every two steps -- 5 us per step, a third of the step); workgroup 0 records the decision for step b + 1 in
-// the state slot no workgroup of this launch reads, and the partials alternate between two halves of their buffer for
-// the same reason.  Nothing is read that was written earlier in the same launch.
+// ---- a batch in one pass ---------------------------------------------------------------------------------------------
+// Which candidates the sequential algorithm takes, in which order, can be decided WITHOUT touching the n-vectors as long
+// as one bound holds.  The candidates are the nb largest entries of the residual diagonal when the batch starts and
+// K_next is the largest key outside them; a step only ever LOWERS diagonal entries, so K_next bounds every non-candidate
+// for the whole batch.  The candidates' own entries after each step follow from the nb x nb block of the panel at the
+// candidate rows alone (a small pivoted Cholesky, pchol_plan_kernel).  While the largest unused candidate's key stays
+// above K_next it IS the global argmax -- the sequential algorithm's next pivot; the first step where it does not ends
+// the plan (the true argmax may still be a candidate: the exact step kernels below take over from there when asked to).
+// On a lattice whose kernel rows are sparse (the regime where a factor column touches few of the other candidates) whole
+// batches are planned, and pchol_multi_step_kernel writes all their columns in ONE pass over the n-vectors: nb panel
+// rows in, nb columns out, the diagonal once -- against nb passes that each re-read the columns before them.
+// Arithmetic: the column formula is written with explicit fmaf in the three kernels that evaluate it (plan, multi-step,
+// step), so the plan sees bit for bit the values the n-vector passes store.
+struct PcholPlan {
+    int a;                                     // planned steps (>= 1: the first candidate is the argmax by construction)
+    int used;                                  // bit mask of the candidates they use
+    int order[kPcholMaxBatch];                 // candidate (batch column) of step b
+    float dmax[kPcholMaxBatch];                // residual diagonal at its pivot when the step runs
+    float w[kPcholMaxBatch][kPcholMaxBatch];   // w[b][q] = L[pivot_b][m + q], q < b
+};
+
+__device__ inline float pchol_col(float v, bool ok, float root) { return ok ? v / root : 0.f; }
+__device__ inline float pchol_diag(float d, float col) { return fmaxf(fmaf(-col, col, d), 0.f); }
+
+__global__ __launch_bounds__(kBlock) void pchol_plan_kernel(const float *__restrict__ rowsT, int64_t ld,
+                                                            const int *__restrict__ cand, int nb,
+                                                            const float *__restrict__ diag, const uint32_t *__restrict__ rank,
+                                                            const uint64_t *__restrict__ knext_p, float tol_abs,
+                                                            PcholPlan *__restrict__ plan)
+{
+    __shared__ float P[kPcholMaxBatch][kPcholMaxBatch + 1];
+    {
+        const int c = threadIdx.x / kPcholMaxBatch, c2 = threadIdx.x % kPcholMaxBatch;      // kBlock = 16 * 16
+        float v = 0.f;
+        if (c < nb && c2 < nb && cand[c] >= 0 && cand[c2] >= 0) v = rowsT[(int64_t)c * ld + cand[c2]];
+        P[c][c2] = v;                                                                       // panel row of candidate c at candidate c2's entry
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int c = threadIdx.x;
+    const bool valid = c < nb && cand[c] >= 0;
+    float dv = valid ? diag[cand[c]] : 0.f;
+    const uint32_t rk = valid ? (rank ? rank[cand[c]] : (uint32_t)cand[c]) : 0u;
+    const uint64_t knext = *knext_p;
+    float L[kPcholMaxBatch];
+#pragma unroll
+    for (int q = 0; q < kPcholMaxBatch; ++q) L[q] = 0.f;
+    uint32_t used = 0;
+    int a = 0;
+    bool open = true;                              // (uniform) the plan has not ended
+#pragma unroll
+    for (int b = 0; b < kPcholMaxBatch; ++b) {
+        uint64_t key = (open && b < nb && valid && !((used >> c) & 1)) ? pchol_key(dv, rk) : 0;
+        int cs = c;
+        wave_argmax(key, cs);                      // every lane: the largest unused candidate
+        open = open && b < nb && key != 0 && (b == 0 || key > knext);
+        if (open) {
+            const float dmax = __uint_as_float((uint32_t)(key >> 32));
+            const bool ok = dmax > tol_abs;
+            const float root = sqrtf(fmaxf(dmax, 1e-30f));
+            float v = P[cs][c < kPcholMaxBatch ? c : 0];
+#pragma unroll
+            for (int q = 0; q < b; ++q) {
+                const float wq = __shfl(L[q], cs, 64);       // L[pivot][m + q]
+                v = fmaf(-L[q], wq, v);
+                if (c == 0) plan->w[b][q] = wq;
+            }
+            const float col = pchol_col(v, ok, root);
+            L[b] = col;
+            dv = c == cs ? 0.f : pchol_diag(dv, col);
+            used |= 1u << cs;
+            if (c == 0) { plan->order[b] = cs; plan->dmax[b] = dmax; }
+            a = b + 1;
+        }
+    }
+    if (c == 0) { plan->a = a; plan->used = (int)used; }
+}
+
+// steps 0 .. a - 1 of the plan in one pass; leaves the state and the argmax partials step a - 1 would have left, so that
+// pchol_step_kernel launches for b = a .. nb - 1 can carry on
+__global__ __launch_bounds__(kBlock) void pchol_multi_step_kernel(float *__restrict__ lt, int64_t ld, int m,
+                                                                  const float *__restrict__ rowsT, float *__restrict__ diag,
+                                                                  const uint32_t *__restrict__ rank, int64_t n,
+                                                                  const int *__restrict__ cand, const PcholPlan *__restrict__ plan,
+                                                                  float tol_abs, uint64_t *__restrict__ pkey,
+                                                                  int *__restrict__ pidx, int *__restrict__ state,
+                                                                  int *__restrict__ accepted)
+{
+    __shared__ uint64_t skey[kBlock / 64];
+    __shared__ int sidx[kBlock / 64];
+    __shared__ PcholPlan sp;
+    __shared__ float s_root[kPcholMaxBatch];
+    __shared__ int s_piv[kPcholMaxBatch], s_ok[kPcholMaxBatch];
+    for (int x = threadIdx.x; x < (int)(sizeof(PcholPlan) / 4); x += kBlock) reinterpret_cast<int *>(&sp)[x] = reinterpret_cast<const int *>(plan)[x];
+    __syncthreads();
+    const int a = sp.a;
+    if ((int)threadIdx.x < a) {
+        s_root[threadIdx.x] = sqrtf(fmaxf(sp.dmax[threadIdx.x], 1e-30f));
+        s_ok[threadIdx.x] = sp.dmax[threadIdx.x] > tol_abs;
+        s_piv[threadIdx.x] = cand[sp.order[threadIdx.x]];
+    }
+    __syncthreads();
+    uint64_t best = 0;
+    int bi = -1;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        float col[kPcholMaxBatch], row[kPcholMaxBatch];
+        float dn = diag[i];
+#pragma unroll
+        for (int b = 0; b < kPcholMaxBatch; ++b) row[b] = b < a ? rowsT[(int64_t)sp.order[b] * ld + i] : 0.f;    // (all loads in flight before the first column)
+#pragma unroll
+        for (int b = 0; b < kPcholMaxBatch; ++b) {
+            col[b] = 0.f;
+            if (b < a) {
+                float v = row[b];
+#pragma unroll
+                for (int q = 0; q < kPcholMaxBatch; ++q)
+                    if (q < b) v = fmaf(-col[q], sp.w[b][q], v);
+                const float cb = pchol_col(v, s_ok[b] != 0, s_root[b]);
+                col[b] = cb;
+                lt[(int64_t)(m + b) * ld + i] = cb;
+                dn = i == s_piv[b] ? 0.f : pchol_diag(dn, cb);
+            }
+        }
+        diag[i] = dn;
+        const uint64_t key = pchol_key(dn, rank ? rank[i] : (uint32_t)i);
+        if (key > best) { best = key; bi = (int)i; }
+    }
+    block_argmax(best, bi, skey, sidx);
+    if (threadIdx.x == 0) {
+        pkey[(size_t)((a - 1) & 1) * kPcholParts + blockIdx.x] = best;
+        pidx[(size_t)((a - 1) & 1) * kPcholParts + blockIdx.x] = bi;
+        if (blockIdx.x == 0) {
+            accepted[0] = a;
+            accepted[1] = a;
+            int *slot = state + 8 * ((a - 1) & 1);
+            slot[0] = 0; slot[1] = sp.used; slot[2] = sp.order[a - 1]; slot[3] = __float_as_int(sp.dmax[a - 1]);
+        }
+    }
+}
+
+// in-batch step b >= 1 (after the planned steps): column m + b of the factor from the panel row of the candidate the
+// step uses, corrected by the in-batch columns before it; the residual diagonal is updated in place and every workgroup
+// leaves the argmax of its part of the updated diagonal.  Which candidate step b uses is decided at the START of its
+// launch, by every workgroup for itself from the partials step b - 1 left (1024 keys: a few microseconds, against a launch
+// of a single-workgroup kernel between every two steps -- 5 us per step, a third of the step); workgroup 0 records the
+// decision for step b + 1 in the state slot no workgroup of this launch reads, and the partials alternate between two
+// halves of their buffer for the same reason.  Nothing is read that was written earlier in the same launch.
 __global__ __launch_bounds__(kBlock) void pchol_step_kernel(float *__restrict__ lt, int64_t ld, int m, int b, int nb,
                                                             const float *__restrict__ rowsT, float *__restrict__ diag,
                                                             const uint32_t *__restrict__ rank, int64_t n,
                                                             const int *__restrict__ cand, int *__restrict__ state,
                                                             float tol_abs, uint64_t *__restrict__ pkey, int *__restrict__ pidx,
-                                                            int *__restrict__ accepted)
+                                                            const PcholPlan *__restrict__ plan, int *__restrict__ accepted)
 {
     __shared__ uint64_t skey[kBlock / 64];
     __shared__ int sidx[kBlock / 64];
     __shared__ int s_stop, s_col;
     __shared__ float s_dmax, s_w[kPcholMaxBatch];
+    if (b < plan->a) return;                       // (uniform) the plan's pass wrote this column
     uint64_t best = 0;
     int bi = -1;
-    if (b == 0) {
-        if (threadIdx.x == 0) { s_stop = state[0]; s_col = state[2]; s_dmax = __int_as_float(state[3]); }
-    } else {
-        const int *prev = state + 8 * ((b - 1) & 1);
-        int *cur = state + 8 * (b & 1);
-        if (prev[0]) {                             // (uniform) the batch ended at an earlier step
-            if (blockIdx.x == 0 && threadIdx.x == 0) cur[0] = 1;
-            return;
-        }
-        const uint64_t *pk = pkey + (size_t)((b - 1) & 1) * kPcholParts;
-        const int *pi = pidx + (size_t)((b - 1) & 1) * kPcholParts;
-        for (int x = threadIdx.x; x < (int)gridDim.x; x += kBlock) {
-            const uint64_t key = pk[x];
-            if (key > best) { best = key; bi = pi[x]; }
-        }
-        block_argmax(best, bi, skey, sidx);
-        if (threadIdx.x == 0) {
-            // the sequential algorithm's next pivot is the argmax `bi`: is its kernel row in this batch, still unused?
-            const int used = prev[1];
-            int j = -1;
-            for (int q = 0; q < nb; ++q)
-                if (!((used >> q) & 1) && cand[q] == bi) { j = q; break; }
-            s_stop = j < 0;
-            s_col = j;
-            s_dmax = __uint_as_float((uint32_t)(best >> 32));
-            if (blockIdx.x == 0) { cur[0] = j < 0; cur[1] = used | (j < 0 ? 0 : 1 << j); cur[2] = j; cur[3] = (int)(uint32_t)(best >> 32); }
-        }
+    const int *prev = state + 8 * ((b - 1) & 1);
+    int *cur = state + 8 * (b & 1);
+    if (prev[0]) {                                 // (uniform) the batch ended at an earlier step
+        if (blockIdx.x == 0 && threadIdx.x == 0) cur[0] = 1;
+        return;
+    }
+    const uint64_t *pk = pkey + (size_t)((b - 1) & 1) * kPcholParts;
+    const int *pi = pidx + (size_t)((b - 1) & 1) * kPcholParts;
+    for (int x = threadIdx.x; x < (int)gridDim.x; x += kBlock) {
+        const uint64_t key = pk[x];
+        if (key > best) { best = key; bi = pi[x]; }
+    }
+    block_argmax(best, bi, skey, sidx);
+    if (threadIdx.x == 0) {
+        // the sequential algorithm's next pivot is the argmax `bi`: is its kernel row in this batch, still unused?
+        const int used = prev[1];
+        int j = -1;
+        for (int q = 0; q < nb; ++q)
+            if (!((used >> q) & 1) && cand[q] == bi) { j = q; break; }
+        s_stop = j < 0;
+        s_col = j;
+        s_dmax = __uint_as_float((uint32_t)(best >> 32));
+        if (blockIdx.x == 0) { cur[0] = j < 0; cur[1] = used | (j < 0 ? 0 : 1 << j); cur[2] = j; cur[3] = (int)(uint32_t)(best >> 32); }
     }
     __syncthreads();
     if (s_stop) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *accepted = b + 1;       // what the host reads back after the batch
+    if (blockIdx.x == 0 && threadIdx.x == 0) accepted[0] = b + 1;     // what the host reads back after the batch
     const float dmax = s_dmax;
     const bool ok = dmax > tol_abs;
     const float root = sqrtf(fmaxf(dmax, 1e-30f));
@@ -533,11 +686,10 @@ __global__ __launch_bounds__(kBlock) void pchol_step_kernel(float *__restrict__ 
         float v = rowsT[(int64_t)col_b * ld + i];
 #pragma unroll
         for (int q = 0; q < kPcholMaxBatch; ++q)
-            if (q < b) v -= lt[(int64_t)(m + q) * ld + i] * w[q];
-        const float col = ok ? v / root : 0.f;
+            if (q < b) v = fmaf(-lt[(int64_t)(m + q) * ld + i], w[q], v);
+        const float col = pchol_col(v, ok, root);
         lt[(int64_t)(m + b) * ld + i] = col;
-        float dn = fmaxf(diag[i] - col * col, 0.f);
-        if (i == piv) dn = 0.f;
+        const float dn = i == piv ? 0.f : pchol_diag(diag[i], col);
         diag[i] = dn;
         const uint64_t key = pchol_key(dn, rank ? rank[i] : (uint32_t)i);
         if (key > best) { best = key; bi = (int)i; }
@@ -604,19 +756,21 @@ static size_t pcg_gram_floats(int kp) { return (size_t)kGramBlocksMax * kPcgCols
 
 // work layout of the pchol calls (bytes)
 struct PcholWork {
-    float *rowsT; float *W; uint64_t *pkey; int *pidx; int *state;
+    float *rowsT; float *W; uint64_t *pkey; int *pidx; int *state; uint64_t *knext; PcholPlan *plan;
     static size_t bytes(int64_t ld, int kp)
     {
-        return (size_t)kPcgCols * ld * 4 + (size_t)kp * kPcgCols * 4 + (size_t)kPcholParts * kPcholMaxBatch * 12 + 512;
+        return (size_t)kPcgCols * ld * 4 + (size_t)kp * kPcgCols * 4 + (size_t)kPcholParts * (kPcholMaxBatch + 1) * 12 + 512 + sizeof(PcholPlan);
     }
     PcholWork(void *base, int64_t ld, int kp)
     {
         char *p = (char *)base;
         rowsT = (float *)p; p += (size_t)kPcgCols * ld * 4;
         W = (float *)p; p += (size_t)kp * kPcgCols * 4;
-        pkey = (uint64_t *)p; p += (size_t)kPcholParts * kPcholMaxBatch * 8;
-        pidx = (int *)p; p += (size_t)kPcholParts * kPcholMaxBatch * 4;
-        state = (int *)p;
+        pkey = (uint64_t *)p; p += (size_t)kPcholParts * (kPcholMaxBatch + 1) * 8;
+        pidx = (int *)p; p += (size_t)kPcholParts * (kPcholMaxBatch + 1) * 4;
+        state = (int *)p; p += 128;
+        knext = (uint64_t *)p; p += 128;
+        plan = (PcholPlan *)p;
     }
 };
 
@@ -722,8 +876,9 @@ extern "C" int plx_pchol_select(const float *d_diag, const uint32_t *d_rank, int
     PcholWork w(d_work, ld, kp);
     hipStream_t s = (hipStream_t)stream;
     const int parts = std::min<int64_t>(kPcholParts, ceil_div(n, kBlock));
-    pchol_top_partial_kernel<<<parts, kBlock, 0, s>>>(d_diag, d_rank, n, nb, w.pkey, w.pidx);
-    pchol_top_final_kernel<<<1, 1024, 0, s>>>(w.pkey, w.pidx, parts, nb, d_cand, w.state);
+    // one key more than the batch: the largest entry that is NOT a candidate bounds what the batch's plan may assume
+    pchol_top_partial_kernel<<<parts, kBlock, 0, s>>>(d_diag, d_rank, n, nb + 1, w.pkey, w.pidx);
+    pchol_top_final_kernel<<<1, 1024, 0, s>>>(w.pkey, w.pidx, parts, nb + 1, d_cand, w.knext);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }
@@ -741,8 +896,8 @@ extern "C" int plx_pchol_onehot(const int32_t *d_cand, int nb, int64_t n, int t,
 
 extern "C" int plx_pchol_factor_batch(float *d_lt, int64_t ld, int kp, int m_done, const float *d_rows, int t,
                                       const float *d_scale, const int32_t *d_cand, int nb, float *d_diag,
-                                      const uint32_t *d_rank, int64_t n, float tol_abs, int32_t *d_accepted, void *d_work,
-                                      void *stream)
+                                      const uint32_t *d_rank, int64_t n, float tol_abs, int exact_steps, int32_t *d_accepted,
+                                      void *d_work, void *stream)
 {
     if (!factor_shape_ok("plx_pchol_factor_batch", d_lt, ld, kp, n, t)) return PLX_ERR_INVALID;
     if (!d_rows || !d_scale || !d_cand || !d_diag || !d_accepted || !d_work) { set_error("plx_pchol_factor_batch: NULL argument"); return PLX_ERR_INVALID; }
@@ -756,9 +911,13 @@ extern "C" int plx_pchol_factor_batch(float *d_lt, int64_t ld, int kp, int m_don
     // panel: rowsT[b][i] = scale * rows[i][b] - sum_{j < m} L[i][j] L[cand_b][j]
     PLX_TRY((apply_launch<true, false>(d_lt, ld, m_done, d_rows, n, t, w.W, d_scale, w.rowsT, ld, nullptr, s)));
     const int parts = std::min<int64_t>(kPcholParts, ceil_div(n, kBlock));
-    for (int b = 0; b < nb; ++b)
-        pchol_step_kernel<<<parts, kBlock, 0, s>>>(d_lt, ld, m_done, b, nb, w.rowsT, d_diag, d_rank, n, d_cand, w.state, tol_abs,
-                                                   w.pkey, w.pidx, d_accepted);
+    pchol_plan_kernel<<<1, kBlock, 0, s>>>(w.rowsT, ld, d_cand, nb, d_diag, d_rank, w.knext, tol_abs, w.plan);
+    pchol_multi_step_kernel<<<parts, kBlock, 0, s>>>(d_lt, ld, m_done, w.rowsT, d_diag, d_rank, n, d_cand, w.plan, tol_abs, w.pkey,
+                                                     w.pidx, w.state, d_accepted);
+    if (exact_steps)
+        for (int b = 1; b < nb; ++b)
+            pchol_step_kernel<<<parts, kBlock, 0, s>>>(d_lt, ld, m_done, b, nb, w.rowsT, d_diag, d_rank, n, d_cand, w.state, tol_abs,
+                                                       w.pkey, w.pidx, w.plan, d_accepted);
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }

@@ -258,14 +258,18 @@ class LatticePreconditioner:
             nv.check(lib.plx_copy_point_perm(lat._h, _vp(row_rank), stream), "plx_copy_point_perm")
             work = torch.empty(int(lib.plx_pchol_work_bytes(ld, kp)), dtype=torch.uint8, device=dev)
             cand = torch.empty(16, dtype=torch.int32, device=dev)
-            status = torch.zeros(2, dtype=torch.int32, device=dev)    # [pivots the batch accepted, vertex rows its filter worked on]
-            accepted, frontier = status[0:1], status[1:2]
+            status = torch.zeros(3, dtype=torch.int32, device=dev)    # [pivots the batch accepted, of them planned, vertex rows its filter worked on]
+            accepted, frontier = status[0:2], status[2:3]
             scale = torch.tensor([s, 1.0], dtype=torch.float32, device=dev)
             was_lattice = lat.lattice_rows
             lat.set_lattice_row_order(True)
             bufs = {}
-            m, B, self.batches, self.sparse_batches = 0, max(1, min(int(batch), 16)), 0, 0
+            m, B, self.batches, self.sparse_batches, self.planned_batches = 0, max(1, min(int(batch), 16)), 0, 0, 0
             sparse = bool(sparse_rows)
+            # one launch per step behind the planned ones (plx_pchol_factor_batch): tried when a batch came out partly
+            # planned, kept while those launches add pivots, left alone for a few batches when they did not
+            exact, cooldown = False, 0
+            selected = 0         # candidates the work buffer already holds for the coming batch (selected ahead of the read-back)
             try:
                 while m < k:
                     nb = min(B, k - m, n)
@@ -273,20 +277,37 @@ class LatticePreconditioner:
                     if t not in bufs:
                         bufs[t] = (torch.empty(n, t, dtype=torch.float32, device=dev), lat.new_values(t), lat.new_values(t))
                     rows, vals, scratch = bufs[t]
-                    nv.check(lib.plx_pchol_select(_vp(diag), _vp(row_rank), n, nb, ld, kp, _vp(cand), _vp(work), stream),
-                             "plx_pchol_select")
+                    if selected != nb:
+                        nv.check(lib.plx_pchol_select(_vp(diag), _vp(row_rank), n, nb, ld, kp, _vp(cand), _vp(work), stream),
+                                 "plx_pchol_select")
                     # K e_p for the nb candidates: splat, blur and slice of one-hot columns, on the frontier of their
                     # non-zero vertex rows while that is a small part of the lattice (plx_filter_onehot)
                     lat.filter_onehot(cand, nb, vals, scratch, rows, vd=t, sparse=sparse, frontier=frontier)
                     nv.check(lib.plx_pchol_factor_batch(_vp(self.Lt), ld, kp, m, _vp(rows), t, _vp(scale), _vp(cand), nb, _vp(diag),
-                                                        _vp(row_rank), n, float(rel_tol * s), _vp(accepted), _vp(work), stream),
+                                                        _vp(row_rank), n, float(rel_tol * s), int(exact), _vp(accepted), _vp(work),
+                                                        stream),
                              "plx_pchol_factor_batch")
-                    a, front = status.tolist()                 # the one host read-back of the batch
+                    # the next batch's candidates, selected while the host waits for this one's counts -- for the batch size
+                    # that follows if every candidate is accepted (the selection only depends on the diagonal this batch leaves,
+                    # so it also serves whenever the next batch turns out to have that size; any other size selects again)
+                    selected = min(B, k - m - nb, n)
+                    if selected > 0:
+                        nv.check(lib.plx_pchol_select(_vp(diag), _vp(row_rank), n, selected, ld, kp, _vp(cand), _vp(work), stream),
+                                 "plx_pchol_select")
+                    a, planned, front = status.tolist()        # the one host read-back of the batch
                     if not 1 <= a <= nb:               # (an assert would vanish under python -O and a == 0 would spin forever)
                         raise RuntimeError(f"plx_pchol_factor_batch accepted {a} of {nb} speculated pivots")
                     m += a
                     self.batches += 1
                     self.sparse_batches += int(sparse)
+                    self.planned_batches += int(planned == nb)
+                    if exact:
+                        if a == planned:               # the step launches added nothing
+                            exact, cooldown = False, 4
+                    elif planned < nb:
+                        if cooldown == 0:
+                            exact = True
+                        cooldown = max(0, cooldown - 1)
                     # on a coarse lattice every kernel row touches most vertices: the dense passes are the cheaper ones there
                     if sparse and front > self.SPARSE_ROWS_MAX_FRACTION * lat.m:
                         sparse = False

@@ -43,7 +43,8 @@ def loop(lat, s, k, do_sync, sparse=True, batch=12, rel_tol=1e-6):
     nv.check(lib.plx_copy_point_perm(lat._h, _vp(row_rank), stream), "perm")
     work = torch.empty(int(lib.plx_pchol_work_bytes(ld, kp)), dtype=torch.uint8, device=dev)
     cand = torch.empty(16, dtype=torch.int32, device=dev)
-    accepted = torch.zeros(1, dtype=torch.int32, device=dev)
+    accepted = torch.zeros(2, dtype=torch.int32, device=dev)
+    exact = False
     frontier = torch.zeros(1, dtype=torch.int32, device=dev)
     fronts = []
     scale = torch.tensor([s, 1.0], dtype=torch.float32, device=dev)
@@ -72,9 +73,10 @@ def loop(lat, s, k, do_sync, sparse=True, batch=12, rel_tol=1e-6):
             lat.filter_onehot(cand, nb, vals, scratch, rows, vd=tt, sparse=sparse, frontier=frontier)
             t = tick("filter_onehot", t)
         nv.check(lib.plx_pchol_factor_batch(_vp(Lt), ld, kp, m, _vp(rows), tt, _vp(scale), _vp(cand), nb, _vp(diag), _vp(row_rank), nn,
-                                            float(rel_tol * s), _vp(accepted), _vp(work), stream), "factor_batch")
+                                            float(rel_tol * s), int(exact), _vp(accepted), _vp(work), stream), "factor_batch")
         t = tick("factor_batch", t)
-        a = int(accepted.item())
+        a, planned = accepted.tolist()
+        exact = planned < nb
         fronts.append(int(frontier.item()))
         t = tick("readback", t)
         m += a
