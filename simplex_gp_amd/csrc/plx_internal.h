@@ -354,6 +354,7 @@ int filter_onehot_impl(plx_lattice *L, const int *d_cand, int nb, int vd, float 
 int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *result_in_scratch,
               hipStream_t stream);
 int build_blur_pairs(plx_lattice *L, hipStream_t stream);   // composite neighbour tables of the two-axes-per-launch blur
+int ensure_blur_pairs(plx_lattice *L, hipStream_t stream);  // ... built on first use (multi-column blurs, plx_filter_onehot)
 int slice_impl(plx_lattice *L, const float *d_values, int vd, float *d_out, hipStream_t stream,
                const float *d_affine = nullptr, const float *d_src = nullptr, float *d_dot_partial = nullptr);
 // plx_linalg.hip: out[c] = sum over nblocks of partial[k * vd + c], fixed order

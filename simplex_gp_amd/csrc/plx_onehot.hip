@@ -24,28 +24,92 @@
 
 namespace plx {
 
-// counters (int32, device): n0 = cnt[0] vertices listed by the splat, cnt[1 + a] = vertices appended by the expansion
-// along axis a.  Frontier before pass a: n0 + sum_{i < a} cnt[1 + i]; frontier of pass a: that + cnt[1 + a].
+// counters (int32, device): n0 = cnt[0] vertices listed by the splat, cnt[1 + p] = vertices appended by the expansion
+// for PASS p (a pass = one blur axis, or two where the lattice has the composite tables of plx_blur.hip).  Frontier
+// before pass p: n0 + sum_{i < p} cnt[1 + i]; frontier of pass p: that + cnt[1 + p].
 constexpr int kOhCounters = PLX_MAX_DIM + 8;
 constexpr int kSliceMaxD1Onehot = 17;   // d + 1 compiled into the slice up to here (all loads issued before the sums)
 
-__device__ inline int oh_claim(int *pos, int w)
+// What the NEXT pass can make non-zero from frontier vertex u (the neighbour relation is symmetric, so "the vertices
+// whose gather reads u" are u's own neighbours): mode 1 -- the 2 r neighbours along one axis (planes pa); mode 2 -- a pass
+// over the axis pair (i, j): out[v] = sum_b c_b tmp[nbr_j(v, b)], tmp[w] = sum_a c_a old[nbr_i(w, a)] reads u at every
+// v = nbr_j(nbr_i(u, a), b) whose intermediate vertex nbr_i(u, a) exists (order 1: pa = planes of axis i, pb = of axis j).
+struct OhNext { int mode; const int *pa; const int *pb; int order; int64_t mstride; };
+
+constexpr int kOhTargets = 16;      // 2 * PLX_MAX_ORDER single-axis neighbours, or the 8 composites of a pair
+
+// all loads of a level are issued together: the expansion is a chain of dependent memory round trips (list -> neighbour
+// -> (neighbour) -> pos -> claim), and walking the targets one after the other made a pass over a 100-vertex frontier
+// take 30 us
+__device__ inline void oh_targets(const OhNext &nx, int u, int (&t)[kOhTargets])
 {
-    // -1 -> -2 (claimed, position not yet known) -> k; a plain read first: most neighbours are listed already
-    if (__hip_atomic_load(&pos[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != -1) return 0;
-    return atomicCAS(&pos[w], -1, -2) == -1;
+#pragma unroll
+    for (int s = 0; s < kOhTargets; ++s) t[s] = -1;
+    if (nx.mode == 1) {
+#pragma unroll
+        for (int s = 0; s < kOhTargets; ++s)
+            if (s < 2 * nx.order) t[s] = nx.pa[(size_t)s * nx.mstride + u];
+    } else {
+        const int um = nx.pa[u], up = nx.pa[nx.mstride + u];
+        t[0] = um;
+        t[1] = up;
+        t[2] = nx.pb[u];
+        t[3] = nx.pb[nx.mstride + u];
+        const int um0 = um >= 0 ? nx.pb[um] : -1, um1 = um >= 0 ? nx.pb[nx.mstride + um] : -1;
+        const int up0 = up >= 0 ? nx.pb[up] : -1, up1 = up >= 0 ? nx.pb[nx.mstride + up] : -1;
+        t[4] = um0; t[5] = um1; t[6] = up0; t[7] = up1;
+    }
 }
 
-// splat of the one-hot columns + the expansion along axis 0: nb (d + 1) <= 16 * 33 numbers, one workgroup
+// Expansion: every frontier vertex claims its unlisted targets (pos -1 -> -2); a workgroup's claims of one round take
+// their list positions with ONE device atomic (a per-claim atomicAdd on the one counter would serialise ~ 2e5 appends
+// of the late passes at the L2).  All threads of the workgroup call it (barriers inside).
+__device__ inline void oh_expand(const OhNext &nx, int *__restrict__ pos, int *__restrict__ list, int cnew, int *__restrict__ ext,
+                                 int *s_count, int *s_base)
+{
+    for (int base = blockIdx.x * blockDim.x; base < cnew; base += gridDim.x * blockDim.x) {     // (uniform)
+        const int idx = base + threadIdx.x;
+        if (threadIdx.x == 0) *s_count = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        int t[kOhTargets];
+#pragma unroll
+        for (int s = 0; s < kOhTargets; ++s) t[s] = -1;
+        if (idx < cnew) {
+            oh_targets(nx, list[idx], t);
+            int pv[kOhTargets];
+#pragma unroll
+            for (int s = 0; s < kOhTargets; ++s)
+                pv[s] = t[s] >= 0 ? __hip_atomic_load(&pos[t[s]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+            for (int s = 0; s < kOhTargets; ++s)                         // -1 -> -2 (claimed, position not yet known) -> k
+                if (t[s] >= 0 && pv[s] == -1 && atomicCAS(&pos[t[s]], -1, -2) == -1) mine |= 1u << s;
+        }
+        int at = mine ? atomicAdd(s_count, __popc(mine)) : 0;
+        __syncthreads();
+        if (threadIdx.x == 0 && *s_count) *s_base = cnew + atomicAdd(ext, *s_count);
+        __syncthreads();
+        at += *s_base;
+#pragma unroll
+        for (int s = 0; s < kOhTargets; ++s) {
+            if ((mine >> s) & 1) {
+                list[at] = t[s];
+                __hip_atomic_store(&pos[t[s]], at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++at;
+            }
+        }
+    }
+}
+
+// splat of the one-hot columns + the expansion for the first pass: nb (d + 1) <= 16 * 33 numbers, one workgroup
 __global__ __launch_bounds__(1024) void onehot_seed_kernel(const int *__restrict__ evid, const float *__restrict__ ew,
                                                            const int *__restrict__ cand, int nb, int d1, int n, int stride,
                                                            int *__restrict__ pos, int *__restrict__ list, int *__restrict__ cnt,
-                                                           float *__restrict__ val, const int *__restrict__ nbr0, int taps2,
-                                                           int64_t mstride)
+                                                           float *__restrict__ val, OhNext nx)
 {
-    __shared__ int s_n0, s_n1;
+    __shared__ int s_n0, s_count, s_base;
     const int x = threadIdx.x;
-    if (x == 0) { s_n0 = 0; s_n1 = 0; }
+    if (x == 0) s_n0 = 0;
     if (x < kOhCounters) cnt[x] = 0;
     __syncthreads();
     int v = -1, b = 0;
@@ -65,31 +129,27 @@ __global__ __launch_bounds__(1024) void onehot_seed_kernel(const int *__restrict
     // the corners of ONE point are distinct vertices: (vertex, column) pairs are written once
     if (v >= 0) val[(size_t)__hip_atomic_load(&pos[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * stride + b] = w;
     const int n0 = s_n0;
-    for (int e = x; e < n0 * taps2; e += 1024) {
-        const int u = list[e / taps2], nbv = nbr0[(size_t)(e % taps2) * mstride + u];
-        if (nbv >= 0 && oh_claim(pos, nbv)) {
-            const int k = n0 + atomicAdd(&s_n1, 1);
-            list[k] = nbv;
-            __hip_atomic_store(&pos[nbv], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    if (x == 0) { cnt[0] = n0; cnt[1] = s_n1; }
+    if (x == 0) cnt[0] = n0;
+    oh_expand(nx, pos, list, n0, cnt + 1, &s_count, &s_base);
 }
 
-// pass `axis` on the frontier + the expansion along the next axis (nb_next; nullptr after the last pass)
+__device__ inline int oh_before(const int *cnt, int pass)
+{
+    int c = cnt[0];
+    for (int i = 0; i < pass; ++i) c += cnt[1 + i];
+    return c;
+}
+
+// one blur axis on the frontier (pass index `pass`) + the expansion for the next pass
 template <class V>
 __global__ __launch_bounds__(kBlock) void onehot_axis_kernel(const V *__restrict__ in, V *__restrict__ out,
-                                                             const int *__restrict__ nb_a, const int *__restrict__ nb_next,
-                                                             int order, int64_t mstride, int rowlen, TapArgs taps,
-                                                             int *__restrict__ pos, int *__restrict__ list,
-                                                             int *__restrict__ cnt, int axis)
+                                                             const int *__restrict__ nb_a, int order, int64_t mstride,
+                                                             int rowlen, TapArgs taps, int *__restrict__ pos,
+                                                             int *__restrict__ list, int *__restrict__ cnt, int pass, OhNext nx)
 {
     using O = VecOps<V>;
-    int cprev = cnt[0];
-    for (int i = 0; i < axis; ++i) cprev += cnt[1 + i];
-    const int cnew = cprev + cnt[1 + axis];
-    int *ext = cnt + 2 + axis;
+    __shared__ int s_count, s_base;
+    const int cprev = oh_before(cnt, pass), cnew = cprev + cnt[1 + pass];
     const int64_t total = (int64_t)cnew * rowlen;
     for (int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x; item < total; item += (int64_t)gridDim.x * kBlock) {
         const int idx = (int)(item / rowlen), ch = (int)(item - (int64_t)idx * rowlen);
@@ -112,38 +172,51 @@ __global__ __launch_bounds__(kBlock) void onehot_axis_kernel(const V *__restrict
         }
         out[item] = acc;
     }
-    if (!nb_next) return;
-    // expansion along the next axis: every frontier vertex claims its unlisted neighbours (pos -1 -> -2); a workgroup's
-    // claims of one round take their list positions with ONE device atomic (a per-claim atomicAdd on the one counter
-    // would serialise ~ 2e5 appends of the late passes at the L2)
+    if (nx.mode) oh_expand(nx, pos, list, cnew, cnt + 2 + pass, &s_count, &s_base);
+}
+
+// two blur axes in one pass (order 1, the composite neighbour table pn of the pair: plx_blur.hip pair_nbr_kernel):
+// blur_pair_narrow_kernel's operations in its order -- which are two single passes' operations in their order
+template <class V>
+__global__ __launch_bounds__(kBlock) void onehot_pair_kernel(const V *__restrict__ in, V *__restrict__ out,
+                                                             const int *__restrict__ pn, int64_t mstride, int rowlen,
+                                                             TapArgs taps, int *__restrict__ pos, int *__restrict__ list,
+                                                             int *__restrict__ cnt, int pass, OhNext nx)
+{
+    using O = VecOps<V>;
     __shared__ int s_count, s_base;
-    for (int base = blockIdx.x * kBlock; base < cnew; base += gridDim.x * kBlock) {     // (uniform: barriers inside)
-        const int idx = base + threadIdx.x;
-        if (threadIdx.x == 0) s_count = 0;
-        __syncthreads();
-        uint32_t mine = 0;
-        int u = 0;
-        if (idx < cnew) {
-            u = list[idx];
-            for (int s = 0; s < 2 * order; ++s) {
-                const int w = nb_next[(size_t)s * mstride + u];
-                if (w >= 0 && oh_claim(pos, w)) mine |= 1u << s;
-            }
+    const int cprev = oh_before(cnt, pass), cnew = cprev + cnt[1 + pass];
+    const int64_t total = (int64_t)cnew * rowlen;
+    for (int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x; item < total; item += (int64_t)gridDim.x * kBlock) {
+        const int idx = (int)(item / rowlen), ch = (int)(item - (int64_t)idx * rowlen);
+        const int u = list[idx];
+        int id[8];
+        V g[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) id[s] = pn[(size_t)s * mstride + u];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int pw = id[s] >= 0 ? pos[id[s]] : -1;
+            g[s] = (unsigned)pw < (unsigned)cprev ? in[(size_t)pw * rowlen + ch] : O::zero();
         }
-        int at = mine ? atomicAdd(&s_count, __popc(mine)) : 0;
-        __syncthreads();
-        if (threadIdx.x == 0 && s_count) s_base = cnew + atomicAdd(ext, s_count);
-        __syncthreads();
-        at += s_base;
-        while (mine) {
-            const int s = __ffs(mine) - 1;
-            mine &= mine - 1;
-            const int w = nb_next[(size_t)s * mstride + u];
-            list[at] = w;
-            __hip_atomic_store(&pos[w], at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ++at;
-        }
+        const V c = idx < cprev ? in[item] : O::zero();
+        V tm = O::zero(), t0 = O::zero(), tp = O::zero();
+        tm = O::sel(id[0] >= 0, O::add(tm, O::scale(taps.c[0], g[0])), tm);
+        tm = O::add(tm, O::scale(taps.c[1], g[1]));
+        tm = O::sel(id[2] >= 0, O::add(tm, O::scale(taps.c[2], g[2])), tm);
+        t0 = O::sel(id[3] >= 0, O::add(t0, O::scale(taps.c[0], g[3])), t0);
+        t0 = O::add(t0, O::scale(taps.c[1], c));
+        t0 = O::sel(id[4] >= 0, O::add(t0, O::scale(taps.c[2], g[4])), t0);
+        tp = O::sel(id[5] >= 0, O::add(tp, O::scale(taps.c[0], g[5])), tp);
+        tp = O::add(tp, O::scale(taps.c[1], g[6]));
+        tp = O::sel(id[7] >= 0, O::add(tp, O::scale(taps.c[2], g[7])), tp);
+        V acc = O::zero();
+        acc = O::sel(id[1] >= 0, O::add(acc, O::scale(taps.c[0], tm)), acc);
+        acc = O::add(acc, O::scale(taps.c[1], t0));
+        acc = O::sel(id[6] >= 0, O::add(acc, O::scale(taps.c[2], tp)), acc);
+        out[item] = acc;
     }
+    if (nx.mode) oh_expand(nx, pos, list, cnew, cnt + 2 + pass, &s_count, &s_base);
 }
 
 // slice_vec_kernel / slice_v1_kernel's arithmetic, vertex rows read through pos (absent = zero row)
@@ -152,11 +225,10 @@ __global__ __launch_bounds__(kBlock) void onehot_slice_kernel(const int *__restr
                                                               const uint32_t *__restrict__ perm, int n, int d1,
                                                               const V *__restrict__ val, int rowlen, float rden,
                                                               V *__restrict__ out, const int *__restrict__ pos,
-                                                              const int *__restrict__ cnt, int *__restrict__ frontier_out)
+                                                              const int *__restrict__ cnt, int npass, int *__restrict__ frontier_out)
 {
     using O = VecOps<V>;
-    int cfin = cnt[0];
-    for (int i = 0; i < d1; ++i) cfin += cnt[1 + i];
+    const int cfin = oh_before(cnt, npass);
     if (frontier_out && blockIdx.x == 0 && threadIdx.x == 0) *frontier_out = cfin;
     const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (item >= (int64_t)n * rowlen) return;
@@ -207,16 +279,41 @@ static int onehot_frontier_launch(plx_lattice *L, const int *d_cand, int nb, int
     int *pos = L->oh_pos.as<int>(), *list = L->oh_list.as<int>(), *cnt = L->oh_cnt.as<int>();
     const int *nbr = L->nbr.as<int>();
     const size_t plane = (size_t)2 * order * L->mstride;
+    // passes: two axes at a time where the lattice has (or may build) the composite tables of the dense two-axis blur --
+    // the same numbers either way (plx_blur.hip), half the launches of a chain that is latency-bound until its last links
+    const bool pairs = order == 1 && d1 >= 2 && g_blur_fuse_vec != 0 && !(L->single_use && !L->pairs_ready) &&
+                       (int64_t)8 * L->mstride < (1ll << 32);
+    if (pairs) PLX_TRY(ensure_blur_pairs(L, stream));
+    struct Pass { int kind, first_axis; };      // kind 2: axes (first_axis, first_axis + 1); kind 1: first_axis alone
+    Pass passes[PLX_MAX_DIM + 2];
+    int npass = 0;
+    for (int axis = 0; axis < d1;) {
+        if (pairs && axis + 1 < d1) { passes[npass++] = {2, axis}; axis += 2; }
+        else { passes[npass++] = {1, axis}; axis += 1; }
+    }
+    auto next_of = [&](int k) {
+        OhNext nx{0, nullptr, nullptr, order, L->mstride};
+        if (k < npass) {
+            nx.mode = passes[k].kind;
+            nx.pa = nbr + passes[k].first_axis * plane;
+            nx.pb = passes[k].kind == 2 ? nbr + (passes[k].first_axis + 1) * plane : nullptr;
+        }
+        return nx;
+    };
     PLX_HIP_TRY(hipMemsetAsync(pos, 0xFF, (size_t)m * 4, stream));
     onehot_seed_kernel<<<1, 1024, 0, stream>>>(L->evid.as<int>(), L->ew.as<float>(), d_cand, nb, d1, n, stride, pos, list, cnt,
-                                               d_values, nbr, 2 * order, L->mstride);
+                                               d_values, next_of(0));
     // the frontier's size is only known on the device: a fixed grid walks it (grid-stride); early passes leave most
     // workgroups without work
     const int grid = (int)std::min<int64_t>(2048, std::max<int64_t>(1, ceil_div(m * rowlen, kBlock)));
     V *cur = reinterpret_cast<V *>(d_values), *nxt = reinterpret_cast<V *>(d_scratch);
-    for (int axis = 0; axis < d1; ++axis) {
-        onehot_axis_kernel<V><<<grid, kBlock, 0, stream>>>(cur, nxt, nbr + axis * plane, axis + 1 < d1 ? nbr + (axis + 1) * plane : nullptr,
-                                                          order, L->mstride, rowlen, L->taps, pos, list, cnt, axis);
+    for (int k = 0; k < npass; ++k) {
+        if (passes[k].kind == 2)
+            onehot_pair_kernel<V><<<grid, kBlock, 0, stream>>>(cur, nxt, L->pair_nbr.as<int>() + (size_t)(passes[k].first_axis / 2) * 8 * L->mstride,
+                                                              L->mstride, rowlen, L->taps, pos, list, cnt, k, next_of(k + 1));
+        else
+            onehot_axis_kernel<V><<<grid, kBlock, 0, stream>>>(cur, nxt, nbr + passes[k].first_axis * plane, order, L->mstride, rowlen,
+                                                              L->taps, pos, list, cnt, k, next_of(k + 1));
         V *t = cur; cur = nxt; nxt = t;
     }
     const uint32_t *perm = L->lattice_rows ? nullptr : L->perm.as<uint32_t>();
@@ -224,15 +321,15 @@ static int onehot_frontier_launch(plx_lattice *L, const int *d_cand, int nb, int
     const int sgrid = ceil_div((int64_t)n * rowlen, kBlock);
     V *o = reinterpret_cast<V *>(d_out);
     switch (d1 <= kSliceMaxD1Onehot ? d1 : 0) {
-#define PLX_CASE(D1) case D1: onehot_slice_kernel<V, D1><<<sgrid, kBlock, 0, stream>>>(L->evid.as<int>(), L->ew.as<float>(), perm, n, d1, cur, rowlen, rden, o, pos, cnt, d_frontier); break;
+#define PLX_CASE(D1) case D1: onehot_slice_kernel<V, D1><<<sgrid, kBlock, 0, stream>>>(L->evid.as<int>(), L->ew.as<float>(), perm, n, d1, cur, rowlen, rden, o, pos, cnt, npass, d_frontier); break;
         PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9) PLX_CASE(10)
         PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17)
 #undef PLX_CASE
-    default: onehot_slice_kernel<V, 0><<<sgrid, kBlock, 0, stream>>>(L->evid.as<int>(), L->ew.as<float>(), perm, n, d1, cur, rowlen, rden, o, pos, cnt, d_frontier); break;
+    default: onehot_slice_kernel<V, 0><<<sgrid, kBlock, 0, stream>>>(L->evid.as<int>(), L->ew.as<float>(), perm, n, d1, cur, rowlen, rden, o, pos, cnt, npass, d_frontier); break;
     }
     PLX_HIP_TRY(hipGetLastError());
     L->kn_splat = "onehot_seed_kernel";
-    L->kn_blur = "onehot_axis_kernel";
+    L->kn_blur = pairs ? "onehot_pair_kernel" : "onehot_axis_kernel";
     L->kn_slice = "onehot_slice_kernel";
     return PLX_OK;
 }

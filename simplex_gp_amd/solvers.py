@@ -231,7 +231,8 @@ class LatticePreconditioner:
     MAX_RANK = 1024          # factor columns the native passes hold (plx_pcg.hip: factor_shape_ok)
     SPARSE_ROWS_MAX_FRACTION = 0.5    # kernel rows are computed on the frontier of their non-zero vertex rows while a batch's frontier stays under this share of the lattice
 
-    def __init__(self, lat, outputscale, noise, rank, rel_tol=1e-6, batch=12, factor_dtype=torch.float16, sparse_rows=True):
+    def __init__(self, lat, outputscale, noise, rank, rel_tol=1e-6, batch=12, factor_dtype=torch.float16, sparse_rows=True,
+                 exact_steps=None):
         import ctypes
         from . import _native as nv
         lib = nv.lib()
@@ -250,7 +251,11 @@ class LatticePreconditioner:
         self.build_id = lat.build_id        # a lattice object is recycled by the cache: the factor belongs to THIS build of it
         self.ref = None
         self.ref_key = None                 # (x.data_ptr, x._version, lengthscale._version, shape) the positions were derived from
-        self.Lt = torch.zeros(kp, ld, dtype=torch.float32, device=dev)
+        self.Lt = torch.empty(kp, ld, dtype=torch.float32, device=dev)      # rows < k, columns < n: every entry is written by a step
+        if kp > k:
+            self.Lt[k:].zero_()
+        if ld > n:
+            self.Lt[:, n:].zero_()
         diag = torch.full((n,), s, dtype=torch.float32, device=dev)
         row_rank = torch.empty(lat.n, dtype=torch.int32, device=dev)          # caller row of every lattice position (uint32 bits)
         with torch.cuda.device(dev):
@@ -268,7 +273,7 @@ class LatticePreconditioner:
             sparse = bool(sparse_rows)
             # one launch per step behind the planned ones (plx_pchol_factor_batch): tried when a batch came out partly
             # planned, kept while those launches add pivots, left alone for a few batches when they did not
-            exact, cooldown = False, 0
+            exact, cooldown = bool(exact_steps), 0        # exact_steps: None = as described, True / False = always / never (A/B, tests)
             selected = 0         # candidates the work buffer already holds for the coming batch (selected ahead of the read-back)
             try:
                 while m < k:
@@ -301,7 +306,9 @@ class LatticePreconditioner:
                     self.batches += 1
                     self.sparse_batches += int(sparse)
                     self.planned_batches += int(planned == nb)
-                    if exact:
+                    if exact_steps is not None:
+                        pass
+                    elif exact:
                         if a == planned:               # the step launches added nothing
                             exact, cooldown = False, 4
                     elif planned < nb:
@@ -322,13 +329,23 @@ class LatticePreconditioner:
             half = torch.empty(kp, ld, dtype=torch.float16, device=dev)
             with torch.cuda.device(dev):
                 nv.check(lib.plx_pcg_factor_to_half(_vp(self.Lt), ld, kp, _vp(half), stream), "plx_pcg_factor_to_half")
-            self.Lt.copy_(half)                                        # the rounded values, for C below
             self._factor, self.factor_type = half, nvc.FACTOR_F16
         else:
             self._factor = self.Lt
-        # C = sigma^2 I + L^T L in fp64 (64 partial products over the n dimension, summed in fp64)
-        A = self.Lt[:k].reshape(k, 64, ld // 64).permute(1, 0, 2)
-        C = torch.bmm(A, A.transpose(1, 2)).double().sum(0) + noise * torch.eye(k, dtype=torch.float64, device=dev)
+        # C = sigma^2 I + L^T L in fp64 (64 partial products over the n dimension, summed in fp64) -- of the STORED factor:
+        # fp16 entries multiply exactly in fp32, so the matrix cores' fp16 x fp16 -> fp32 products are the rounded
+        # factor's own (half the bytes of converting it back first)
+        C32 = None
+        if self._factor is not self.Lt:
+            Ah = half[:k].reshape(k, 64, ld // 64).permute(1, 0, 2)
+            try:
+                C32 = torch.bmm(Ah, Ah.transpose(1, 2), out_dtype=torch.float32)
+            except (NotImplementedError, RuntimeError, TypeError):         # (a torch without bmm(out_dtype=))
+                self.Lt.copy_(half)
+        if C32 is None:
+            A = self.Lt[:k].reshape(k, 64, ld // 64).permute(1, 0, 2)
+            C32 = torch.bmm(A, A.transpose(1, 2))
+        C = C32.double().sum(0) + noise * torch.eye(k, dtype=torch.float64, device=dev)
         # the k x k factorisation and inverse on the host: 80 KB each way, against a dozen ~100 us launches of the device solver
         cap_host_threads()
         self._chol = torch.linalg.cholesky(C.cpu())
@@ -341,7 +358,6 @@ class LatticePreconditioner:
         self._T = torch.zeros(kp, 16, dtype=torch.float32, device=dev)
         self._work = {}
         if self._factor is not self.Lt:
-            del A
             self.Lt = None                                             # only the fp16 copy stays resident
 
     @property

@@ -311,3 +311,33 @@ def test_filter_onehot_on_the_frontier_equals_the_dense_stages(plx, n, d, ell, o
             assert got[:, nb:].abs().max() == 0 if nb < t else True
     lat.set_lattice_row_order(False)
     lat.close()
+
+
+@pytest.mark.parametrize("n,d,ell,rank", [(20000, 3, 0.5, 40), (50000, 6, 0.4, 60), (3000, 2, 2.0, 30)])
+def test_factor_batch_modes_build_the_same_factor(plx, n, d, ell, rank):
+    """The factor does not depend on HOW its batches are run: planned steps only, planned steps + one launch per
+    remaining candidate, the adaptive default; kernel rows on the frontier or by the dense stages; batches of 1
+    (the sequential algorithm itself), 5 or 16 instead of 12 -- same pivots, entries within rounding."""
+    from simplex_gp_amd import solvers
+    g = torch.Generator().manual_seed(n + rank)
+    x = torch.randn(n, d, generator=g).cuda()
+    model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).cuda()
+    with torch.no_grad():
+        model.kernel.lengthscale = ell
+        ref = model.preconditioner(x, rank, factor_dtype=torch.float32)
+        lat, s, noise = ref.lat, float(model.outputscale), float(model.noise)
+        want = ref.L
+        seen = []
+        for kw in (dict(batch=1), dict(exact_steps=True), dict(exact_steps=False), dict(sparse_rows=False),
+                   dict(sparse_rows=False, exact_steps=True, batch=16), dict(batch=5, exact_steps=False)):
+            got = solvers.LatticePreconditioner(lat, s, noise, rank, factor_dtype=torch.float32, **kw)
+            # (batches that end elsewhere split a column's sum differently between the panel update and the in-batch
+            # corrections: same pivots, entries within rounding)
+            assert float((got.L - want).abs().max()) <= 2e-6 * float(want.abs().max()), kw
+            if kw == dict(sparse_rows=False) and got.batches == ref.batches:
+                assert torch.equal(got.L, want)       # same batches, kernel rows by the dense stages: equal bits
+            seen.append((kw, got.batches, got.planned_batches))
+        print(seen)
+        one = seen[0]
+        assert one[1] == min(rank, n)                 # batch = 1: one pivot per batch
+    plx.lattice_cache().clear()

@@ -215,3 +215,38 @@ def test_snelson_mll_matches_exact_gp(cpu_method, golden_dir):
         lattice_mll = float(solvers.marginal_log_likelihood(model, x, y, num_probes=50, cg_tol=1e-5, max_cg_iter=1000, seed=999))
     print("exact", exact_mll, "lattice", lattice_mll)
     assert abs(lattice_mll - exact_mll) < 0.1
+
+
+def test_cap_host_threads_follows_the_cgroup_quota(monkeypatch, tmp_path):
+    """solvers.cap_host_threads: the small host factorisations of a solve run under a thread pool no larger than half the
+    cgroup CPU quota (a 128-thread pool under a 16-CPU quota stalls the whole process for the rest of the scheduler
+    period); an explicit OMP_NUM_THREADS is left alone, and so is a process without a quota."""
+    import builtins
+    import torch
+    from simplex_gp_amd import solvers
+    before = torch.get_num_threads()
+    real_open = builtins.open
+    state = {"text": "400000 100000\n"}
+
+    def fake_open(path, *a, **k):
+        if str(path) == "/sys/fs/cgroup/cpu.max":
+            import io
+            return io.StringIO(state["text"])
+        return real_open(path, *a, **k)
+
+    try:
+        monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+        monkeypatch.delenv("MKL_NUM_THREADS", raising=False)
+        monkeypatch.setattr(builtins, "open", fake_open)
+        torch.set_num_threads(8)
+        assert solvers.cap_host_threads(force=True) == 2            # quota 4 CPUs -> 2 threads
+        torch.set_num_threads(8)
+        state["text"] = "max 100000\n"
+        assert solvers.cap_host_threads(force=True) == 8            # no quota: nothing changes
+        monkeypatch.setenv("OMP_NUM_THREADS", "8")
+        state["text"] = "400000 100000\n"
+        assert solvers.cap_host_threads(force=True) == 8            # the user has decided
+        assert solvers.cap_host_threads() == 8                      # (once per process afterwards)
+    finally:
+        monkeypatch.setattr(builtins, "open", real_open)
+        torch.set_num_threads(before)
