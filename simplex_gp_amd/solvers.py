@@ -231,7 +231,7 @@ class LatticePreconditioner:
     MAX_RANK = 1024          # factor columns the native passes hold (plx_pcg.hip: factor_shape_ok)
     SPARSE_ROWS_MAX_FRACTION = 0.5    # kernel rows are computed on the frontier of their non-zero vertex rows while a batch's frontier stays under this share of the lattice
 
-    def __init__(self, lat, outputscale, noise, rank, rel_tol=1e-6, batch=12, factor_dtype=torch.float16, sparse_rows=True,
+    def __init__(self, lat, outputscale, noise, rank, rel_tol=1e-6, batch=16, factor_dtype=torch.float16, sparse_rows=True,
                  exact_steps=None):
         import ctypes
         from . import _native as nv
