@@ -39,6 +39,12 @@ def alg_bytes(name, m_fwd, m_bwd):
         return 6 * 4 * N * 12, "X, R, P, AP in; X, R out"
     if "step_direction4_kernel" in name:
         return 3 * 4 * N * 12, "P, R (or Z) in; P out"
+    if "pchol_multi_step_kernel" in name:
+        return 4 * N * (2 * 16 + 3), "16 panel rows in, 16 factor columns out, diagonal in / out, tie-break ranks in"
+    if "pcg_apply_kernel<16, true, false>" in name:
+        return 4 * N * (16 + 16 + 50), "kernel rows [N][16] in, panel [16][N] out, on average 50 finished factor columns in"
+    if "onehot_slice_kernel" in name:
+        return 8 * N * (d + 1) + 4 * N * 16, "vertex ids + weights of every corner in, kernel rows [N][16] out (the vertex rows through the position map: mostly absent)"
     return None
 
 
