@@ -341,3 +341,53 @@ def test_factor_batch_modes_build_the_same_factor(plx, n, d, ell, rank):
         one = seen[0]
         assert one[1] == min(rank, n)                 # batch = 1: one pivot per batch
     plx.lattice_cache().clear()
+
+
+def test_filter_onehot_argument_checks_and_replay_fallback(plx):
+    """plx_filter_onehot refuses what it cannot do (aliased work buffers, more than 16 columns, NULL output) and, on a
+    lattice built under plx_tune("reference_growth", 1) -- whose patched neighbour table is not symmetric --, runs the
+    dense stages whatever `sparse` says (frontier = m) with the result of plx_apply."""
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    g = torch.Generator().manual_seed(5)
+    n, d = 6000, 5
+    x = (torch.randn(n, d, generator=g) * 2).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lat = plx.Lattice().build(x, taps)
+    pts = torch.arange(4, dtype=torch.int32, device="cuda")
+    vals, scratch = lat.new_values(4), lat.new_values(4)
+    out = torch.empty(n, 4, device="cuda")
+    # (PLX_ERR_INVALID = 1)
+    assert lib.plx_filter_onehot(lat._h, _vp(pts), 4, 4, _vp(vals), _vp(vals), _vp(out), 1, None, stream) == 1
+    assert lib.plx_filter_onehot(lat._h, _vp(pts), 4, 4, _vp(vals), _vp(scratch), None, 1, None, stream) == 1
+    assert lib.plx_filter_onehot(lat._h, _vp(pts), 5, 4, _vp(vals), _vp(scratch), _vp(out), 1, None, stream) == 1
+    big_v, big_s = lat.new_values(20), lat.new_values(20)
+    big_o = torch.empty(n, 20, device="cuda")
+    many = torch.arange(17, dtype=torch.int32, device="cuda")
+    assert lib.plx_filter_onehot(lat._h, _vp(many), 17, 20, _vp(big_v), _vp(big_s), _vp(big_o), 1, None, stream) == 1
+    # vd = 3 (neither 1 nor a multiple of 4): the dense stages, silently
+    v3, s3, o3 = lat.new_values(3), lat.new_values(3), torch.empty(n, 3, device="cuda")
+    frontier = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lat.filter_onehot(pts, 3, v3, s3, o3, vd=3, sparse=True, frontier=frontier)
+    assert int(frontier.item()) == lat.m
+    lat.close()
+    nv.check(lib.plx_tune(b"reference_growth", 1), "plx_tune")
+    try:
+        # a cloud whose reference table grows (the quirk needs > 2^14 vertices)
+        xg = (torch.randn(4000, 8, generator=g) * 3).cuda()
+        lat = plx.Lattice().build(xg, taps)
+        info = lat.reference_growth_info()
+        assert info["replayed"]
+        vals, scratch = lat.new_values(4), lat.new_values(4)
+        got = torch.empty(4000, 4, device="cuda")
+        lat.filter_onehot(pts, 4, vals, scratch, got, vd=4, sparse=True, frontier=frontier)
+        assert int(frontier.item()) == lat.m
+        rhs = torch.zeros(4000, 4, device="cuda")
+        perm = torch.from_numpy(lat.export(nv.ARRAY_POINT_PERM).astype(np.int64)).cuda()
+        rhs[perm[pts.long()], torch.arange(4, device="cuda")] = 1.0
+        want = lat.apply(rhs)
+        assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+        lat.close()
+    finally:
+        nv.check(lib.plx_tune(b"reference_growth", 0), "plx_tune")
