@@ -217,9 +217,12 @@ class LatticePreconditioner:
       * everything lives in LATTICE row order (L^T is [kp][ld], its n dimension ordered like the lattice's points), so a
         preconditioned CG iteration permutes nothing;
       * the factor is built in batches of speculated pivots (plx_pchol_*): up to `batch` kernel rows per MVM instead of
-        one, each in-batch step checked on the device against the true argmax of the updated residual diagonal -- the
-        factor is the sequential algorithm's, pivot for pivot (ties broken by the caller's row number, like torch.argmax
-        on the caller-order diagonal), at one host read-back per batch;
+        one -- computed on the frontier of their non-zero vertex rows (plx_filter_onehot; sparse_rows) --, the pivots the
+        sequential algorithm takes among them decided on the device (planned on the candidates' own block of the panel
+        while a bound on the other entries vouches for them, then, if asked, step by step against the true argmax of
+        the updated residual diagonal: exact_steps, None = when it pays) -- the factor is the sequential algorithm's,
+        pivot for pivot (ties broken by the caller's row number, like torch.argmax on the caller-order diagonal), at
+        one host read-back per batch;
       * solve() = plx_pcg_project (L^T R on the matrix cores, C^-1 in fp64) + plx_pcg_apply;
       * the finished factor is kept in fp16 (factor_dtype; fp32 on request): both passes of an application stream the
         factor and nothing else of size, so its width is their time.  The factor is BUILT in fp32 and rounded once;
@@ -306,15 +309,14 @@ class LatticePreconditioner:
                     self.batches += 1
                     self.sparse_batches += int(sparse)
                     self.planned_batches += int(planned == nb)
-                    if exact_steps is not None:
-                        pass
-                    elif exact:
-                        if a == planned:               # the step launches added nothing
-                            exact, cooldown = False, 4
-                    elif planned < nb:
-                        if cooldown == 0:
-                            exact = True
-                        cooldown = max(0, cooldown - 1)
+                    if exact_steps is None:
+                        if exact:
+                            if a == planned:           # the step launches added nothing
+                                exact, cooldown = False, 4
+                        elif planned < nb:
+                            if cooldown == 0:
+                                exact = True
+                            cooldown = max(0, cooldown - 1)
                     # on a coarse lattice every kernel row touches most vertices: the dense passes are the cheaper ones there
                     if sparse and front > self.SPARSE_ROWS_MAX_FRACTION * lat.m:
                         sparse = False
