@@ -311,7 +311,9 @@ int plx_pcg_step_direction(float *d_p, const float *d_z, const float *d_rz_new, 
  * kernel row = one single-column MVM per pivot) is reproduced exactly, but nb <= 16 pivots share ONE nb-column MVM:
  *   plx_pchol_select        d_cand[0..nb) = the nb largest entries of the residual diagonal d_diag [n], ties by LOWER
  *                           d_rank[i] (NULL: by lower i) -- pass the lattice's point permutation so that ties fall as
- *                           torch.argmax breaks them on the caller-order vector; seeds the batch state in d_work;
+ *                           torch.argmax breaks them on the caller-order vector; the largest entry that is NOT a
+ *                           candidate is kept in d_work (it bounds every non-candidate for the whole batch: steps only
+ *                           lower entries).  May run as soon as the previous batch's plx_pchol_factor_batch is enqueued;
  *   plx_pchol_onehot        d_rhs [n][t] = the nb one-hot columns (t >= nb; the caller runs the MVM on it);
  *   plx_pchol_factor_batch  d_rows [n][t] = K d_rhs.  Panel update against the m_done finished columns
  *                           (d_scale[0] d_rows - L L[cand]^T, one pass over them), then the in-batch steps in pivot

@@ -273,6 +273,16 @@ static int onehot_frontier_launch(plx_lattice *L, const int *d_cand, int nb, int
     const int d1 = L->d + 1, order = L->order, n = (int)L->n, stride = values_stride(vd);
     const int rowlen = stride == 1 ? 1 : stride / 4;
     const int64_t m = L->m;
+    {   // the lists are sized on first use and the axis-pair tables may have to be built: not while the stream is being captured
+        const bool pairs_wanted = order == 1 && d1 >= 2 && g_blur_fuse_vec != 0 && !(L->single_use && !L->pairs_ready);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if ((L->oh_pos.cap < (size_t)m * 4 || L->oh_list.cap < (size_t)m * 4 || L->oh_cnt.cap == 0 || (pairs_wanted && !L->pairs_ready)) &&
+            hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+            set_error("plx_filter_onehot: its work lists / axis-pair tables have to be built and the stream is being captured: "
+                      "run the call once on this lattice before the capture");
+            return PLX_ERR_STATE;
+        }
+    }
     PLX_TRY(ensure(L->oh_pos, (size_t)m * 4));
     PLX_TRY(ensure(L->oh_list, (size_t)m * 4));
     PLX_TRY(ensure(L->oh_cnt, (size_t)kOhCounters * 4));

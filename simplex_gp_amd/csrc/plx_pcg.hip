@@ -495,6 +495,8 @@ __global__ __launch_bounds__(kBlock) void pchol_gather_kernel(const float *__res
 // rows in, nb columns out, the diagonal once -- against nb passes that each re-read the columns before them.
 // Arithmetic: the column formula is written with explicit fmaf in the three kernels that evaluate it (plan, multi-step,
 // step), so the plan sees bit for bit the values the n-vector passes store.
+static_assert(kBlock == kPcholMaxBatch * kPcholMaxBatch, "pchol_plan_kernel gathers the candidates' panel block with one thread per entry");
+
 struct PcholPlan {
     int a;                                     // planned steps (>= 1: the first candidate is the argmax by construction)
     int used;                                  // bit mask of the candidates they use
