@@ -455,7 +455,17 @@ __global__ __launch_bounds__(1024) void pchol_top_final_kernel(const uint64_t *_
             const uint64_t key = h < kTopDepth ? keys[p * kTopDepth + h] : ((p < parts && h < nsel) ? pkey[(size_t)p * nsel + h] : 0);
             if (key > best) { best = key; who = p; }
         }
-        wave_argmax(best, who);                    // (every lane ends up with the maximum)
+        // the maximum key by a butterfly over the KEY alone (two shuffles a stage instead of three), its owner from a
+        // ballot: keys are distinct (the rank is part of the key), so at most one lane holds it
+        uint64_t top = best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t other = ((uint64_t)__shfl_xor((uint32_t)(top >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((uint32_t)top, o, 64);
+            top = other > top ? other : top;
+        }
+        const uint64_t holders = __ballot(best == top && top != 0);
+        who = holders ? __shfl(who, __ffsll((long long)holders) - 1, 64) : -1;
+        best = top;
         if (lane == 0) {
             win_part[r] = best ? who : -1;
             win_depth[r] = best ? head[who] : 0;
