@@ -461,7 +461,8 @@ def train_step_leg(ctx, n, d, make_kernel, pre_sizes=(0, 100), steps=3, min_nois
     out = {}
     for pre in pre_sizes:
         model = solvers.LatticeGP(make_kernel(), min_noise=min_noise).to(ctx.dev)
-        opt = torch.optim.Adam(model.parameters(), lr=0.1)
+        from simplex_gp_amd import training
+        opt = training.make_optimizer(model, lr=0.1)
         start = {k: v.detach().clone() for k, v in model.state_dict().items()}
 
         def step(seed, prof=None):

@@ -490,7 +490,7 @@ def _batched_pcg_native(matmul, B, precond, max_iter, tol, want_tridiag, check_e
                 break
     info = {"iterations": it, "residual": (rr.sqrt() / b_norm), "rz0": rz0}
     if want_tridiag:
-        info["tridiag"] = _tridiag_from_cg(list(alphas[:it]), list(betas[:it]), B)
+        info["tridiag"] = _tridiag_from_cg(alphas[:it], betas[:it], B, info)
     return X, info
 
 
@@ -624,20 +624,29 @@ def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matm
                 break
     info = {"iterations": it, "residual": (rs.sqrt() / b_norm)}
     if want_tridiag:
-        info["tridiag"] = _tridiag_from_cg(list(alphas[:it]), list(betas[:it]), B)
+        info["tridiag"] = _tridiag_from_cg(alphas[:it], betas[:it], B, info)
     return X, info
 
 
-def _tridiag_from_cg(alphas, betas, B):
+def _tridiag_from_cg(alphas, betas, B, info=None):
     """[t, k, k] Lanczos tridiagonals from the CG coefficients of k iterations (mBCG): T[i, i] = 1 / a_i + b_{i-1} / a_{i-1},
     T[i, i+1] = sqrt(b_i) / a_i; a column that converged early has alpha = 0 afterwards and its tridiagonal is frozen there
-    (identity rows).  Whole-array expressions: a loop over the k iterations was 4 k small launches (0.4 ms at k = 20)."""
-    k = len(alphas)
-    a = torch.stack(alphas, 0).double()           # [k, t]
-    b = torch.stack(betas, 0).double()
+    (identity rows).  Whole-array expressions: a loop over the k iterations was 4 k small launches (0.4 ms at k = 20).
+    Coefficients that live on the GPU as two [k, t] arrays (the native solves) are copied to the host in ONE transfer and
+    the same expressions run there: fifteen launches of kilobyte-sized kernels kept the GPU idle for 0.2 ms while the host
+    issued them, and the quadrature that consumes the tridiagonals runs on the host anyway -- `info` (optional) receives the
+    host copy as info["tridiag_host"]."""
+    on_gpu = torch.is_tensor(alphas) and alphas.is_cuda
+    if on_gpu:
+        dev = alphas.device
+        ab = torch.stack([alphas, betas], 0).cpu().double()          # [2, k, t]: one copy, one synchronisation
+        a, b = ab[0], ab[1]
+    else:
+        a = (alphas if torch.is_tensor(alphas) else torch.stack(alphas, 0)).double()           # [k, t]
+        b = (betas if torch.is_tensor(betas) else torch.stack(betas, 0)).double()
+    k = a.shape[0]
     valid = a > 0
     inv_a = torch.where(valid, 1.0 / a.clamp_min(1e-300), torch.zeros_like(a))
-    t = B.shape[1]
     diag = inv_a.clone()
     diag[1:] += b[:-1] * inv_a[:-1]
     diag = torch.where(valid, diag, torch.ones_like(diag))
@@ -645,6 +654,10 @@ def _tridiag_from_cg(alphas, betas, B):
     if k > 1:
         off = torch.where(valid[1:], b[:-1].clamp_min(0).sqrt() * inv_a[:-1], torch.zeros_like(inv_a[:-1]))      # [k - 1, t]
         T = T + torch.diag_embed(off.t(), offset=1) + torch.diag_embed(off.t(), offset=-1)
+    if on_gpu:
+        if info is not None:
+            info["tridiag_host"] = T
+        return T.to(dev)
     return T
 
 
@@ -685,14 +698,15 @@ def _batched_pcg(matmul, B, precond, max_iter, tol, reduce, want_tridiag, check_
 def slq_terms(tridiag):
     """e1^T log(T_i) e1 per column of a [t, k, k] stack of Lanczos tridiagonals (the quadrature of slq_logdet).  The
     eigen-decompositions of a few dozen k x k matrices run on the HOST (the device solver takes ~1 ms in a dozen small
-    launches for eleven 20 x 20 problems; the copy is a few KB and the solve has just synchronised anyway)."""
+    launches for eleven 20 x 20 problems; the copy is a few KB and the solve has just synchronised anyway); a tridiagonal
+    stack that already is a host tensor (info["tridiag_host"] of the native solves) gives host terms."""
     dev = tridiag.device
-    small = dev.type == "cuda" and tridiag.shape[0] * tridiag.shape[-1] ** 2 <= 1 << 18
+    small = tridiag.shape[0] * tridiag.shape[-1] ** 2 <= 1 << 18
     if small:
         cap_host_threads()
-    evals, evecs = torch.linalg.eigh(tridiag.cpu() if small else tridiag)
+    evals, evecs = torch.linalg.eigh(tridiag.cpu() if small and dev.type == "cuda" else tridiag)
     terms = ((evecs[:, 0, :] ** 2) * evals.clamp_min(1e-30).log()).sum(-1)
-    return terms.to(dev) if small else terms
+    return terms.to(dev) if small and dev.type == "cuda" else terms
 
 
 def slq_logdet(tridiag, n, weights=None):
@@ -701,7 +715,7 @@ def slq_logdet(tridiag, n, weights=None):
     quad = slq_terms(tridiag)
     if weights is None:
         return float(n) * quad.mean()
-    return (weights.double() * quad).mean()
+    return (weights.double() * quad.to(weights.device)).mean()
 
 
 class LatticeGP(nn.Module):
@@ -779,6 +793,8 @@ class LatticeGP(nn.Module):
                     info = dict(info, residual=info["residual"][:t])
                     if "tridiag" in info:
                         info["tridiag"] = info["tridiag"][:t]
+                    if "tridiag_host" in info:
+                        info["tridiag_host"] = info["tridiag_host"][:t]
                     if "rz0" in info:
                         info["rz0"] = info["rz0"][:t]
             finally:
@@ -874,19 +890,25 @@ def marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol
         ph.mark("solve")
         u, W = sol[:, :1], sol[:, 1:]
         quad = _colsum(r.detach(), u).sum()
-        if precond is None:
-            logdet = slq_logdet(info["tridiag"][1:], n)
-        else:
-            logdet = precond.logdet() + slq_logdet(info["tridiag"][1:], n, weights=info["rz0"][1:])
+        if precond is not None:
             Z = precond.solve(Z)
-        value = -0.5 * quad - 0.5 * logdet - 0.5 * n * math.log(2 * math.pi)
-    ph.mark("slq")
-    KV = mm(torch.cat([u, Z], 1))                                # differentiable MVM
+    # the differentiable MVM is enqueued BEFORE the host-side quadrature (eigen-decompositions of the Lanczos tridiagonals,
+    # a few hundred microseconds of LAPACK): the GPU works on the one while the host does the other
+    KV = mm(torch.cat([u, Z], 1))
     s_quad = -(u * r).sum() + 0.5 * (u * KV[:, :1]).sum()
     s_logdet = -0.5 * (W * KV[:, 1:]).sum() / num_probes
     surrogate = s_quad + s_logdet
-    out = (value.to(surrogate.dtype) + (surrogate - surrogate.detach())) / n
     ph.mark("mvm_forward")
+    with torch.no_grad():
+        tri = info.get("tridiag_host", info["tridiag"])
+        if precond is None:
+            logdet = slq_logdet(tri[1:], n)
+        else:
+            logdet = precond.logdet() + slq_logdet(tri[1:], n, weights=info["rz0"][1:])
+        logdet = logdet.to(quad.device) if torch.is_tensor(logdet) else logdet
+        value = -0.5 * quad - 0.5 * logdet - 0.5 * n * math.log(2 * math.pi)
+    ph.mark("slq")
+    out = (value.to(surrogate.dtype) + (surrogate - surrogate.detach())) / n
     out.cg_info = info
     return out
 

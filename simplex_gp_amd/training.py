@@ -133,6 +133,19 @@ class EarlyStopper:
             self._misses += 1
 
 
+def make_optimizer(model, lr=0.1):
+    """torch.optim.Adam(model.parameters(), lr) as the reference builds it (train_simplexgp.py:84), with the update of all
+    parameters in ONE launch when they live on the GPU (Adam's `fused` implementation: the same update rule; the default
+    per-parameter loop is a dozen launches and a third of a millisecond of Python for five scalars)."""
+    params = list(model.parameters())
+    if params and all(p.is_cuda and p.is_floating_point() for p in params):
+        try:
+            return torch.optim.Adam(params, lr=lr, fused=True)
+        except (RuntimeError, TypeError, ValueError):
+            pass
+    return torch.optim.Adam(params, lr=lr)
+
+
 def fit(model, train, val=None, test=None, epochs=100, lr=0.1, patience=200, log_every=1, num_probes=10,
         cg_iter=1000, cg_tol=1.0, cg_eval_tol=1e-2, lanc_iter=100, pre_size=100, checkpoint=None, log=None):
     """Adam on -MLL; every `log_every` epochs evaluate on val/test, keep the state
@@ -142,7 +155,7 @@ def fit(model, train, val=None, test=None, epochs=100, lr=0.1, patience=200, log
     preconditioner (train_simplexgp.py:36; on the HIP path it is built and applied natively, solvers.LatticePreconditioner;
     0 = plain CG)."""
     x, y = train
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    opt = make_optimizer(model, lr=lr)
     stopper = EarlyStopper(patience=patience)
     history = []
     for epoch in range(epochs):

@@ -27,7 +27,8 @@ def sync(): torch.cuda.synchronize(); return time.perf_counter()
 for pre in args.pre:
     kern = plx.MaternLattice(nu=1.5, order=3, ard_num_dims=d) if args.matern else plx.RBFLattice(order=1, ard_num_dims=d)
     model = solvers.LatticeGP(kern).cuda()
-    opt = torch.optim.Adam(model.parameters(), lr=0.1)
+    from simplex_gp_amd import training
+    opt = training.make_optimizer(model, lr=0.1)
     for step in range(args.steps):
         opt.zero_grad()
         prof = None if args.no_profile else {}
