@@ -24,6 +24,13 @@ g = torch.Generator().manual_seed(1234)
 x = torch.randn(n, d, generator=g).cuda()
 y = (torch.sin(x[:, 0]) + 0.1 * torch.randn(n, generator=g).cuda())
 def sync(): torch.cuda.synchronize(); return time.perf_counter()
+def throttled():
+    """(periods throttled, microseconds throttled) of this container's CPU quota so far (cgroup v2), or None"""
+    try:
+        st = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(st["nr_throttled"]), int(st["throttled_usec"])
+    except (OSError, KeyError, ValueError):
+        return None
 for pre in args.pre:
     kern = plx.MaternLattice(nu=1.5, order=3, ard_num_dims=d) if args.matern else plx.RBFLattice(order=1, ard_num_dims=d)
     model = solvers.LatticeGP(kern).cuda()
@@ -32,6 +39,8 @@ for pre in args.pre:
     for step in range(args.steps):
         opt.zero_grad()
         prof = None if args.no_profile else {}
+        th0 = throttled()
+        rs0 = torch.cuda.memory_reserved()
         t0 = sync()
         mll = solvers.marginal_log_likelihood(model, x, y, num_probes=10, cg_tol=1.0, max_cg_iter=args.max_cg, seed=step,
                                               pre_size=pre, profile=prof)
@@ -46,6 +55,10 @@ for pre in args.pre:
                "peak_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}
         if prof is not None:
             row["phases_ms"] = {k: round(v, 2) for k, v in prof.items()}
+        th1 = throttled()
+        if th0 and th1:
+            row["cpu_throttled"] = {"periods": th1[0] - th0[0], "ms": round((th1[1] - th0[1]) / 1e3, 1)}     # the container's CPU quota ran out during the step
+        row["reserved_grew_MB"] = round((torch.cuda.memory_reserved() - rs0) / 1e6, 1)                     # torch's allocator asked the driver for memory
         row["lattices_m"] = [lat.m for lat, _ in plx.lattice_cache()._entries.values()][-2:]      # forward taps, derivative taps
         print(json.dumps(row), flush=True)
     plx.lattice_cache().clear()
