@@ -824,6 +824,9 @@ def main():
     world, rank, dist = ctx.world, ctx.rank, ctx.dist
 
     import simplex_gp_amd as plx
+    from simplex_gp_amd import solvers
+    # the host-side BLAS pool under the container's CPU quota (every rank of a multi-GPU run: 8 x 128 threads otherwise)
+    host_threads = solvers.cap_host_threads()
 
     d, vd, r = args.d, args.vd, 1
     multi = ctx.dist is not None                 # several ranks (or the single-rank RCCL rehearsal): the sharded code path
@@ -883,6 +886,7 @@ def main():
             "value_definition": "MVMs/s of the n_total-point operator (never scaled by the problem size)",
         },
         "mvms_per_s": round(mvms_per_s, 2),
+        "host_threads": host_threads,      # torch's BLAS pool after solvers.cap_host_threads() (half the cgroup CPU quota)
     }
 
     if multi:
