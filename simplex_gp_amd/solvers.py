@@ -633,17 +633,34 @@ def _tridiag_from_cg(alphas, betas, B, info=None):
     T[i, i+1] = sqrt(b_i) / a_i; a column that converged early has alpha = 0 afterwards and its tridiagonal is frozen there
     (identity rows).  Whole-array expressions: a loop over the k iterations was 4 k small launches (0.4 ms at k = 20).
     Coefficients that live on the GPU as two [k, t] arrays (the native solves) are copied to the host in ONE transfer and
-    the same expressions run there: fifteen launches of kilobyte-sized kernels kept the GPU idle for 0.2 ms while the host
-    issued them, and the quadrature that consumes the tridiagonals runs on the host anyway -- `info` (optional) receives the
-    host copy as info["tridiag_host"]."""
-    on_gpu = torch.is_tensor(alphas) and alphas.is_cuda
-    if on_gpu:
+    the same expressions run there in numpy: fifteen launches of kilobyte-sized kernels kept the GPU idle for 0.2 ms while
+    the host issued them (and the same fifteen expressions as torch CPU ops cost as much in dispatch), and the quadrature
+    that consumes the tridiagonals runs on the host anyway -- `info` (optional) receives the host copy as
+    info["tridiag_host"]."""
+    if torch.is_tensor(alphas) and alphas.is_cuda:
+        import numpy as np
         dev = alphas.device
-        ab = torch.stack([alphas, betas], 0).cpu().double()          # [2, k, t]: one copy, one synchronisation
+        ab = torch.stack([alphas, betas], 0).cpu().numpy().astype(np.float64)          # [2, k, t]: one copy, one synchronisation
         a, b = ab[0], ab[1]
-    else:
-        a = (alphas if torch.is_tensor(alphas) else torch.stack(alphas, 0)).double()           # [k, t]
-        b = (betas if torch.is_tensor(betas) else torch.stack(betas, 0)).double()
+        k, t = a.shape
+        valid = a > 0
+        inv_a = np.where(valid, 1.0 / np.maximum(a, 1e-300), 0.0)
+        diag = inv_a.copy()
+        diag[1:] += b[:-1] * inv_a[:-1]
+        diag = np.where(valid, diag, 1.0)
+        Tn = np.zeros((t, k, k))
+        idx = np.arange(k)
+        Tn[:, idx, idx] = diag.T
+        if k > 1:
+            off = np.where(valid[1:], np.sqrt(np.maximum(b[:-1], 0.0)) * inv_a[:-1], 0.0)      # [k - 1, t]
+            Tn[:, idx[:-1], idx[1:]] = off.T
+            Tn[:, idx[1:], idx[:-1]] = off.T
+        T = torch.from_numpy(Tn)
+        if info is not None:
+            info["tridiag_host"] = T
+        return T.to(dev)
+    a = (alphas if torch.is_tensor(alphas) else torch.stack(alphas, 0)).double()           # [k, t]
+    b = (betas if torch.is_tensor(betas) else torch.stack(betas, 0)).double()
     k = a.shape[0]
     valid = a > 0
     inv_a = torch.where(valid, 1.0 / a.clamp_min(1e-300), torch.zeros_like(a))
@@ -654,10 +671,6 @@ def _tridiag_from_cg(alphas, betas, B, info=None):
     if k > 1:
         off = torch.where(valid[1:], b[:-1].clamp_min(0).sqrt() * inv_a[:-1], torch.zeros_like(inv_a[:-1]))      # [k - 1, t]
         T = T + torch.diag_embed(off.t(), offset=1) + torch.diag_embed(off.t(), offset=-1)
-    if on_gpu:
-        if info is not None:
-            info["tridiag_host"] = T
-        return T.to(dev)
     return T
 
 
@@ -704,9 +717,13 @@ def slq_terms(tridiag):
     small = tridiag.shape[0] * tridiag.shape[-1] ** 2 <= 1 << 18
     if small:
         cap_host_threads()
-    evals, evecs = torch.linalg.eigh(tridiag.cpu() if small and dev.type == "cuda" else tridiag)
-    terms = ((evecs[:, 0, :] ** 2) * evals.clamp_min(1e-30).log()).sum(-1)
-    return terms.to(dev) if small and dev.type == "cuda" else terms
+        evals, evecs = torch.linalg.eigh(tridiag.cpu() if dev.type == "cuda" else tridiag)
+        ev, first = evals.numpy(), evecs[:, 0, :].numpy()          # (numpy for the rest: a dozen microsecond-sized expressions)
+        import numpy as np
+        terms = torch.from_numpy((first * first * np.log(np.maximum(ev, 1e-30))).sum(-1))
+        return terms.to(dev) if dev.type == "cuda" else terms
+    evals, evecs = torch.linalg.eigh(tridiag)
+    return ((evecs[:, 0, :] ** 2) * evals.clamp_min(1e-30).log()).sum(-1)
 
 
 def slq_logdet(tridiag, n, weights=None):
