@@ -74,11 +74,11 @@ md = f"""# rocprofv3 of the training step ({tag})
 order 1, GPyTorch's default initial hyper-parameters, 10 probes, cg_tolerance 1, max 500 CG iterations
 (experiments/train_simplexgp.py:29-57); one step = marginal likelihood forward (preconditioner, probes, batched CG with
 Lanczos coefficients, SLQ, differentiable MVM) + backward (ONE filter of 2 L (1 + d) = {vd} columns with the derivative
-taps, py:113-123, on its own lattice) + Adam.  Adam moves the lengthscale by 10 % per step, so the steps of one run see
+taps, py:113-123; for the RBF profile these are the forward taps, so it runs on the step's one lattice) + Adam.  Adam moves the lengthscale by 10 % per step, so the steps of one run see
 different lattices; the table is the mean over the run's steps.  Fractions: SURVEY 8(d) algorithmic bytes / mean launch
 time / 8 TB/s.
 
-## pre_size 0 ({len(prof0)} steps under the profiler; lattices of the last step m = {r0.get('lattices_m')}: forward taps, derivative taps)
+## pre_size 0 ({len(prof0)} steps under the profiler; lattices of the last step m = {r0.get('lattices_m')}: the previous step's and this step's)
 
 ```
 {table(stats(dir0), *(r0.get('lattices_m') or [0, 0])[:2], len(prof0))}
