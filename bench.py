@@ -25,7 +25,9 @@ Extra keys on the same JSON line (one GPU):
   fine             the same shape at lengthscale 0.25 (m ~ 8.9e6): the blur streams
                    from HBM there; its roofline fraction is the north-star target
   config3_cg_ms    BASELINE.json configs[2]: N=1e6, d=8, lengthscale 0.6931, 50 CG
-                   iterations on (sK + sigma^2 I) with [y | 10 probes] incl. the build
+                   iterations on (sK + sigma^2 I) with [y | 10 probes] incl. the build;
+                   config3.factor: the rank-100 pivoted-Cholesky factor on that lattice;
+                   config3.train_step: one Adam step of the reference's recipe
   config4          N=4e6 total, d=8, lengthscale 1 (configs[3]) sharded over the ranks
   config5_mvm_us   MaternLattice(nu=1.5, order=3), N=10,623, d=18 stand-in: one MVM
   cpu_baseline     the reference's own CPU extension (oracle/_ref) or the C port,
@@ -436,13 +438,27 @@ def config3_leg(ctx, n=1_000_000, d=8, iters=50):
                 best, best_warm = min(best, dt), min(best_warm, dtw)
             res = float(info["residual"].max())
             m = list(plx.lattice_cache()._entries.values())[-1][0].m
+        # the rank-100 pivoted-Cholesky factor of the reference's recipe (train_simplexgp.py:36) on this lattice, by itself
+        pre = model.preconditioner(x, 100)
+        fbest = float("inf")
+        for _ in range(3):
+            ctx.sync()
+            t0 = time.perf_counter()
+            p2 = solvers.LatticePreconditioner(pre.lat, float(model.outputscale), float(model.noise), 100)
+            ctx.sync()
+            fbest = min(fbest, time.perf_counter() - t0)
+        factor = {"ms": round(fbest * 1e3, 2), "rank": 100, "batches": p2.batches, "planned_batches": p2.planned_batches,
+                  "frontier_batches": p2.sparse_batches, "m_vertices": p2.lat.m,
+                  "what": "solvers.LatticePreconditioner on the built lattice: kernel rows (plx_filter_onehot), batches "
+                          "(plx_pchol_*), fp16 rounding, Gram matrix and its host Cholesky"}
+        del pre, p2
     plx.lattice_cache().clear()
     del x, y, Z, rhs
     train = train_step_leg(ctx, n, d, lambda: plx.RBFLattice(order=1, ard_num_dims=d))
     return {"config3_cg_ms": round(best * 1e3, 2), "config3": {
         "workload": f"N={n}, d={d}, vd=11, lengthscale 0.6931, {iters} CG iterations incl. one lattice build",
         "ms_incl_build": round(best * 1e3, 2), "ms_cg_only": round(best_warm * 1e3, 2), "m_vertices": m,
-        "cg_iterations_per_s": round(iters / best_warm, 1), "final_rel_residual_max": res,
+        "cg_iterations_per_s": round(iters / best_warm, 1), "final_rel_residual_max": res, "factor": factor,
         "train_step_ms": {k: v["step_ms"] for k, v in train.items() if k.startswith("pre_size")}, "train_step": train}}
 
 
