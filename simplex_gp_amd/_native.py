@@ -18,6 +18,7 @@ ARRAY_KEYS, ARRAY_ENTRY_VERTEX, ARRAY_ENTRY_WEIGHT, ARRAY_NEIGHBORS = 0, 1, 2, 3
 ARRAY_ROW_PTR, ARRAY_CSR_POINT, ARRAY_CSR_WEIGHT, ARRAY_POINT_PERM = 4, 5, 6, 7
 MAX_DIM, MAX_ORDER = 32, 8
 FACTOR_F32, FACTOR_F16 = 0, 1
+ABI_VERSION = (0, 6)      # (major, minor) of plx_version() the signatures below belong to
 
 
 class PlxError(RuntimeError):
@@ -110,6 +111,14 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `make -C simplex_gp_amd/csrc` "
                 "(or __graft_entry__.build()). There is no CPU fallback.")
         L = ctypes.CDLL(LIB_PATH)
+        # the argtypes below describe ONE version of the C ABI: a stale library would be called with misaligned
+        # arguments and no diagnostic, so the (major, minor) of plx_version() must be the one this file was written for
+        L.plx_version.restype = ctypes.c_char_p
+        got = L.plx_version().decode()
+        m = re.match(r"libplx (\d+)\.(\d+)\.", got)
+        if m is None or (int(m.group(1)), int(m.group(2))) != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} reports '{got}', these bindings need ABI {ABI_VERSION[0]}.{ABI_VERSION[1]}.x: "
+                              "rebuild it with `make -C simplex_gp_amd/csrc` (or __graft_entry__.build())")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

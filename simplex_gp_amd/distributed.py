@@ -51,6 +51,16 @@ LAST_GATHER = {}          # the most recent all_gather_rows on this rank: {"us",
 TIME_GATHER = False       # bench.py: synchronise the device around all_gather_rows and time it (a measuring mode)
 
 
+def _gather_into_tensor_supported(group=None):
+    """Whether all_gather_rows uses all_gather_into_tensor.  A property of the torch build and of the group's back end
+    (gloo and nccl = RCCL both have it in this torch), the same on every rank of a group: the choice must never depend
+    on whether a collective raised on THIS rank (a one-rank error would pair its list-form all_gather with the peers'
+    tensor form: a mismatch or a deadlock in place of the error)."""
+    if not hasattr(dist, "all_gather_into_tensor"):
+        return False
+    return str(dist.get_backend(group)).lower() in ("nccl", "gloo")
+
+
 def all_gather_rows(t_local, group=None, extra=None):
     """Concatenate every rank's rows (row counts may differ) -> (tensor, counts).
     `extra`: a few integers per rank exchanged in the same small collective as the row counts
@@ -66,11 +76,13 @@ def all_gather_rows(t_local, group=None, extra=None):
     t0 = time.perf_counter()
     world = dist.get_world_size(group)
     meta = torch.tensor([t_local.shape[0]] + [int(e) for e in (extra or [])], dtype=torch.int64, device=t_local.device)
-    metas = torch.empty((world,) + tuple(meta.shape), dtype=meta.dtype, device=meta.device)
-    try:
+    # (outputs in the CONCATENATED form [world * k, ...]: the one shape both gloo and RCCL accept; viewed as [world, k, ...])
+    metas = torch.empty((world * meta.shape[0],), dtype=meta.dtype, device=meta.device)
+    into_tensor = _gather_into_tensor_supported(group)       # decided once, identically on every rank: never per call
+    if into_tensor:
         dist.all_gather_into_tensor(metas, meta, group=group)
-        table = metas.tolist()
-    except (RuntimeError, NotImplementedError, AttributeError):
+        table = metas.view(world, -1).tolist()
+    else:
         lst = [torch.zeros_like(meta) for _ in range(world)]
         dist.all_gather(lst, meta, group=group)
         table = torch.stack(lst, 0).tolist()
@@ -82,10 +94,11 @@ def all_gather_rows(t_local, group=None, extra=None):
         padded = torch.empty((biggest,) + tuple(t_local.shape[1:]), dtype=t_local.dtype, device=t_local.device)
         padded[: t_local.shape[0]] = t_local
         padded[t_local.shape[0]:] = 0
-    gathered = torch.empty((world,) + tuple(padded.shape), dtype=padded.dtype, device=padded.device)
-    try:
+    gathered = torch.empty((world * biggest,) + tuple(padded.shape[1:]), dtype=padded.dtype, device=padded.device)
+    if into_tensor:
         dist.all_gather_into_tensor(gathered, padded, group=group)
-    except (RuntimeError, NotImplementedError, AttributeError):
+        gathered = gathered.view((world,) + tuple(padded.shape))
+    else:
         parts = [torch.empty_like(padded) for _ in range(world)]
         dist.all_gather(parts, padded, group=group)
         gathered = torch.stack(parts, 0)
@@ -408,7 +421,7 @@ def column_sharded_mll(model, x, y, num_probes=10, max_cg_iter=1000, cg_tol=1e-4
             has_y = lo == 0
             p0 = 1 if has_y else 0                                    # first probe column inside the local block
             W = sol[:, p0:]
-            terms = solvers.slq_terms(info["tridiag"][p0:])
+            terms = solvers.slq_terms(info.get("tridiag_host", info["tridiag"])[p0:]).to(stats.device)
             if terms.numel():
                 weights = torch.full_like(terms, float(n)) if precond is None else info["rz0"][p0:].double()
                 stats[1] = (weights * terms).sum()

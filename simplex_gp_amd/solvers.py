@@ -209,6 +209,34 @@ def cap_host_threads(force=False):
     return torch.get_num_threads()
 
 
+_host_cap = None          # the thread count the small host factorisations run under (None: not worked out yet)
+
+
+class _small_host_factorisation:
+    """`with _small_host_factorisation():` around a k x k host Cholesky / a stack of tridiagonal eigen-problems: the
+    BLAS pool is capped (cap_host_threads' rule) for the duration and RESTORED afterwards -- the library never changes
+    the host application's thread count for good; a process that wants the cap everywhere calls cap_host_threads()
+    itself (bench.py does)."""
+
+    def __enter__(self):
+        global _host_cap, _host_threads_checked
+        self.before = torch.get_num_threads()
+        if _host_cap is None:
+            checked = _host_threads_checked
+            _host_cap = cap_host_threads(force=True)
+            _host_threads_checked = checked
+        if _host_cap < self.before:
+            torch.set_num_threads(_host_cap)
+        elif torch.get_num_threads() != self.before:
+            torch.set_num_threads(self.before)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.before:
+            torch.set_num_threads(self.before)
+        return False
+
+
 class LatticePreconditioner:
     """The same preconditioner, P = L L^T + sigma^2 I with L the rank-k pivoted Cholesky factor of s K, on the HIP path
     (experiments/train_simplexgp.py:36: the reference trains with max_preconditioner_size(100)).
@@ -253,7 +281,7 @@ class LatticePreconditioner:
         self.lat, self.n, self.rank, self.kp, self.ld, self.noise, self.outputscale = lat, n, k, kp, ld, noise, s
         self.build_id = lat.build_id        # a lattice object is recycled by the cache: the factor belongs to THIS build of it
         self.ref = None
-        self.ref_key = None                 # (x.data_ptr, x._version, lengthscale._version, shape) the positions were derived from
+        self.ref_key = None                 # LatticeGP._positions_key(x): identity + version of x and of the raw lengthscale
         self.Lt = torch.empty(kp, ld, dtype=torch.float32, device=dev)      # rows < k, columns < n: every entry is written by a step
         if kp > k:
             self.Lt[k:].zero_()
@@ -349,10 +377,11 @@ class LatticePreconditioner:
             C32 = torch.bmm(A, A.transpose(1, 2))
         C = C32.double().sum(0) + noise * torch.eye(k, dtype=torch.float64, device=dev)
         # the k x k factorisation and inverse on the host: 80 KB each way, against a dozen ~100 us launches of the device solver
-        cap_host_threads()
-        self._chol = torch.linalg.cholesky(C.cpu())
-        cinv = torch.eye(kp, dtype=torch.float64) / noise
-        cinv[:k, :k] = torch.cholesky_inverse(self._chol)
+        C_host = C.cpu()
+        with _small_host_factorisation():
+            self._chol = torch.linalg.cholesky(C_host)
+            cinv = torch.eye(kp, dtype=torch.float64) / noise
+            cinv[:k, :k] = torch.cholesky_inverse(self._chol)
         self._cinv = cinv.contiguous().to(dev)
         self._logdet = float(2.0 * self._chol.diagonal().log().sum()) + (n - k) * math.log(noise)
         self._scale_solve = torch.tensor([1.0, 1.0 / noise], dtype=torch.float32, device=dev)
@@ -715,9 +744,10 @@ def slq_terms(tridiag):
     stack that already is a host tensor (info["tridiag_host"] of the native solves) gives host terms."""
     dev = tridiag.device
     small = tridiag.shape[0] * tridiag.shape[-1] ** 2 <= 1 << 18
-    if small:
-        cap_host_threads()
-        evals, evecs = torch.linalg.eigh(tridiag.cpu() if dev.type == "cuda" else tridiag)
+    if small and not tridiag.requires_grad:                        # (a tridiagonal that carries a graph keeps the torch path)
+        host = tridiag.detach().cpu() if dev.type == "cuda" else tridiag.detach()
+        with _small_host_factorisation():
+            evals, evecs = torch.linalg.eigh(host)
         ev, first = evals.numpy(), evecs[:, 0, :].numpy()          # (numpy for the rest: a dozen microsecond-sized expressions)
         import numpy as np
         terms = torch.from_numpy((first * first * np.log(np.maximum(ev, 1e-30))).sum(-1))
@@ -764,6 +794,27 @@ class LatticeGP(nn.Module):
             return self.outputscale * K.matmul(V) + self.noise * V
         return mm
 
+    def _positions_key(self, x):
+        """What x / lengthscale was derived from: x by identity (a weak reference: a freed tensor whose address the
+        caching allocator hands to another one cannot match) and version, the raw lengthscale PARAMETER by identity and
+        version (kernel.lengthscale is a fresh softplus output on every access: its version counter says nothing)."""
+        import weakref
+        raw = getattr(self.kernel, "raw_lengthscale", None)
+        return (weakref.ref(x), x._version, tuple(x.shape), None if raw is None else weakref.ref(raw),
+                None if raw is None else raw._version)
+
+    def _same_positions(self, pre, x):
+        key = pre.ref_key
+        if key is None or len(key) != 5:
+            return False
+        raw = getattr(self.kernel, "raw_lengthscale", None)
+        xr, xv, shape, rr, rv = key
+        if xr() is not x or xv != x._version or shape != tuple(x.shape):
+            return False
+        if raw is None:
+            return rr is None
+        return rr is not None and rr() is raw and rv == raw._version
+
     def khat_solve(self, x, rhs, K=None, **cg_args):
         """(s K + sigma^2 I)^-1 rhs by batched CG, no gradients.  On the HIP path the
         iteration runs in lattice row order: the right-hand side is permuted once, every
@@ -778,11 +829,12 @@ class LatticeGP(nn.Module):
             ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
             ref = ref if ref.is_contiguous() else ref.contiguous()
             pre = cg_args.get("precond")
-            if isinstance(pre, LatticePreconditioner) and pre.ref is not None and pre.ref is not ref and pre.ref_key is not None \
-                    and pre.ref_key == (x.data_ptr(), x._version, self.kernel.lengthscale._version, tuple(x.shape)):
+            if isinstance(pre, LatticePreconditioner) and pre.ref is not None and pre.ref is not ref \
+                    and self._same_positions(pre, x):
                 # the same x and lengthscale the preconditioner was built from, as a fresh tensor (no K handed over): solve
-                # on the preconditioner's lattice.  (Decided from the tensors' identities and version counters: comparing
-                # the n x d positions on the device cost a pass and a host synchronisation per solve.)
+                # on the preconditioner's lattice.  (Decided from the identities and version counters of x ITSELF -- held
+                # through a weak reference, a recycled address cannot pass for it -- and of the raw lengthscale PARAMETER;
+                # comparing the n x d positions on the device cost a pass and a host synchronisation per solve.)
                 ref = pre.ref
             lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
             s, noise = self.outputscale, self.noise
@@ -831,7 +883,7 @@ class LatticeGP(nn.Module):
                 lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
                 pre = LatticePreconditioner(lat, self.outputscale, self.noise, rank, factor_dtype=factor_dtype)
                 pre.ref = ref          # the positions its lattice was built on (kept alive: the lattice-cache key)
-                pre.ref_key = (x.data_ptr(), x._version, self.kernel.lengthscale._version, tuple(x.shape))
+                pre.ref_key = self._positions_key(x)
                 return pre
             K = self.kernel(x, x) if K is None else K
             return PivotedCholeskyPreconditioner(K.matmul, x.shape[0], self.outputscale, self.noise, rank,

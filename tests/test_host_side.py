@@ -188,6 +188,20 @@ def test_c_abi_exports_every_declared_symbol():
             assert lib.plx_tune(key, 1) == 1, key
 
 
+def test_stale_library_is_refused(monkeypatch):
+    """_native.lib() checks plx_version() against the ABI its ctypes signatures describe: a libplx.so left over from
+    another release (an argument added in the middle of a signature) must fail at import, not with misaligned pointers."""
+    lib = _native.lib()
+    major, minor = (int(v) for v in lib.plx_version().decode().split()[1].split(".")[:2])
+    assert (major, minor) == _native.ABI_VERSION
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "ABI_VERSION", (major, minor + 1))
+    with pytest.raises(ImportError, match="rebuild"):
+        _native.lib()
+    monkeypatch.setattr(_native, "ABI_VERSION", (major, minor))
+    assert _native.lib() is not None
+
+
 def test_gp_compat_fallback_is_explicit():
     assert gp_compat.HAVE_GPYTORCH in (True, False)
     if not gp_compat.HAVE_GPYTORCH:

@@ -250,3 +250,55 @@ def test_cap_host_threads_follows_the_cgroup_quota(monkeypatch, tmp_path):
     finally:
         monkeypatch.setattr(builtins, "open", real_open)
         torch.set_num_threads(before)
+
+
+def test_preconditioner_positions_key_notices_lengthscale_and_x_changes():
+    """LatticeGP._positions_key / _same_positions (what lets khat_solve reuse the preconditioner's lattice): the key is
+    the identity + version of x and of the raw lengthscale PARAMETER.  kernel.lengthscale is a fresh softplus output per
+    access (version always 0), so a key built on it would keep matching after an optimizer step and CG would silently
+    solve the old system."""
+    import types
+    model = solvers.LatticeGP(plx.RBFLattice(order=1))
+    x = torch.randn(32, 2)
+    pre = types.SimpleNamespace(ref_key=model._positions_key(x))
+    assert model._same_positions(pre, x)
+    assert model.kernel.lengthscale._version == 0
+    model.kernel.lengthscale = 0.5                                   # in place on the raw parameter
+    assert model.kernel.lengthscale._version == 0                    # ... which the softplus output does not show
+    assert not model._same_positions(pre, x)
+    pre.ref_key = model._positions_key(x)
+    assert model._same_positions(pre, x)
+    with torch.no_grad():
+        model.kernel.raw_lengthscale.add_(0.1)                       # what an optimizer step does
+    assert not model._same_positions(pre, x)
+    pre.ref_key = model._positions_key(x)
+    x2 = x.clone()
+    assert not model._same_positions(pre, x2)                        # equal values, another tensor: not proven equal
+    x.mul_(2.0)
+    assert not model._same_positions(pre, x)                         # same tensor, changed in place
+    pre.ref_key = model._positions_key(x)
+    del x
+    assert not model._same_positions(pre, x2)                        # the original is gone: nothing can match it
+    pre.ref_key = None
+    assert not model._same_positions(pre, x2)
+
+
+def test_small_host_factorisations_restore_the_thread_count(monkeypatch):
+    """The BLAS-pool cap applies for the duration of a small host factorisation and is undone afterwards: the library
+    must not lower the host application's thread count for good (slq_terms / the preconditioner's k x k Cholesky)."""
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(4)
+        monkeypatch.setattr(solvers, "_host_cap", 2)
+        with solvers._small_host_factorisation():
+            assert torch.get_num_threads() == 2
+        assert torch.get_num_threads() == 4
+        T = torch.diag_embed(torch.rand(3, 5) + 1.0)
+        terms = solvers.slq_terms(T)
+        assert torch.get_num_threads() == 4
+        assert torch.allclose(terms.double(), T[:, 0, 0].log().double(), atol=1e-6)
+        Tg = T.clone().requires_grad_(True)                           # a tridiagonal with a graph keeps the torch path
+        solvers.slq_terms(Tg).sum().backward()
+        assert Tg.grad is not None
+    finally:
+        torch.set_num_threads(before)
