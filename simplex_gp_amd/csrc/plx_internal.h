@@ -80,12 +80,13 @@ struct Tune {
     int insert_xcd = 2;   // XCD-aware tile order (each XCD one contiguous eighth of the points): bit 0 the point-per-thread insert (measured slower), bit 1 the id lookup
     int order_sample = 8;   // point-order key layout from the coordinate ranges of every k-th point (1: of all points); from 65,536 points up
     int embed_vrange = 0;   // 1: the embedding finds the range of the vertices' blur-axis coordinates (Morton renumbering) itself -- no pass over the vertex keys, no read-back of its own; measured: saves 22 us there, costs the embedding 30 (l = 1) to 70 us (l = 0.25): off
-    int reference_growth = 0;   // 1: replay the reference CPU path's hash-table-growth quirk (plx_replay.hip): literal parity with cpp/permutohedral.h where its table doubles; plain single-process builds only, O(N (d+1)) host work per build
+    int reference_growth = 0;   // 1: replay the reference CPU path's hash-table-growth quirk (plx_replay.hip): literal parity with cpp/permutohedral.h where its table doubles; plain single-process builds only, O(m) host work per build (the event form); 2: the lookup-by-lookup form, O(N (d+1)) (the checker of 1)
     int blk_sort = 15;   // per-block LDS sort of the block tables: 0 = (vertex, corner) pairs, 4 bits per pass; 4 / 5 / 6 = corner index packed under the vertex id, keys only, that many bits per pass, 256 threads; 15 = 5 bits with 512 threads
     int insert_v = 2;   // hashed insert: 1 = one thread per corner over the packed corner keys (ekeys); 2 = one thread per point over the point records, several probe chains in flight per thread
     int flag_own = 1;   // first-touch flags without table gathers: the insert marks who claimed / lowered a slot (top bit of eslot) and who was displaced
     int assign_evid = 1;   // the numbering pass stores the vertex id of every first-touch corner itself when the numbering is final; the id lookup then serves the other corners only
     int nbr_seed = 1;   // sliced neighbour lookups: the +1 neighbour that is a corner of the vertex's own first-touch simplex comes from the embedding, no lookup
+    int contract_v = 1;   // fused backward, slice + contraction: 1 = corner count compiled in (all rows in flight, all-lane contraction), 0 = the run-time form
     int splat_first = 1;   // vd = 1 splat on lattices where almost every corner owns its vertex: first-touch corners store, the rest add (0 never, 1 when m >= 0.9 nnz, 2 whenever representable, 3 = 2 without the contiguous-range store)
     // diagnostic ablations: the members always exist (one layout for both libraries), but only libplx_diag.so knows
     // their names and compiles the branches behind them (PLX_DIAG_VALUE)
@@ -139,6 +140,7 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_hash_v (plx::tl_tune->hash_v)
 #define g_table_fp (plx::tl_tune->table_fp)
 #define g_nbr_sliced (plx::tl_tune->nbr_sliced)
+#define g_contract_v (plx::tl_tune->contract_v)
 #define g_splat_ablate (plx::tl_tune->splat_ablate)
 #define g_blur_ablate (plx::tl_tune->blur_ablate)
 #define g_block_ablate (plx::tl_tune->block_ablate)
@@ -273,6 +275,7 @@ struct plx_lattice {
     } replay;
     plx::DevBuf ew_splat;         // float [d+1][n]  the splat's copy of ew with the dropped lookups zeroed (replay mode)
     plx::DevBuf replay_vat, replay_list, replay_invisible;   // int32 scratch / lists of the replay
+    plx::DevBuf replay_keys;      // the event form's sort buffers: uint32 [4][m] (first lookup, vertex; ping-pong) + uint64 [m] hashes + a counter
 
     // plx_filter_onehot (plx_onehot.hip): frontier of the non-zero vertex rows
     plx::DevBuf oh_pos, oh_list, oh_cnt;      // int32 [m] position of a vertex in the list or -1; int32 [m] the list; int32 counters

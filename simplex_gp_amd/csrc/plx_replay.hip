@@ -27,13 +27,27 @@
 // result is a short list of dropped corners, invisible vertices and at most one missed neighbour, which three small
 // kernels apply to the device structure: a copy of the barycentric weights for the SPLAT side with the dropped corners
 // zeroed, -1 in the neighbour rows that point to an invisible vertex, and a centre-tap correction after each blur axis.
-// Product code: nothing here touches oracle/.  O(N (d+1)) host work per build (about a second at N = 1e6): an opt-in
-// parity mode, off by default -- the default lattice is the duplicate-free one, which is also what the reference's CUDA
-// path builds (its table never grows, cu:61).
+// Product code: nothing here touches oracle/.  An opt-in parity mode, off by default -- the default lattice is the
+// duplicate-free one, which is also what the reference's CUDA path builds (its table never grows, cu:61).
+//
+// Cost (round 6).  The table's layout changes only when an entry is CREATED; a lookup that finds its entry leaves no trace.
+// A key that was never touched by a stale probe has exactly one entry, placed by regular probing, and regular probing
+// finds it for ever (linear probing without deletions; grow() re-places it regularly): its lookups need not be run.  So
+// reference_growth = 1 replays EVENTS instead of lookups: the m first-touch creations in caller order (the GPU finds every
+// vertex's first lookup with one atomicMin pass and sorts the vertices by it), the ONE lookup behind each creation that
+// fills the table to its growth threshold (the stale probe, h:58-63), and from then on every lookup of the few keys a stale
+// probe has touched ("affected" keys: they may own a misplaced or a second entry, so each of their lookups is run against
+// the table as it stands at that moment -- it may create yet another entry).  O(m) host work with the probe targets
+// prefetched, instead of O(N (d+1)) dependent cache misses: N = 1e6, d = 8, l = 0.6931: about a second -> tens of
+// milliseconds.  reference_growth = 2 keeps the full lookup-by-lookup replay (the checker of the event form:
+// tests/test_hip_parity.py::test_reference_growth_event_replay_equals_full_replay).
 
 #include "plx_internal.h"
 #include "plx_kernels.h"
 
+#include <algorithm>
+#include <queue>
+#include <unordered_map>
 #include <vector>
 
 namespace plx {
@@ -46,6 +60,32 @@ __global__ __launch_bounds__(kBlock) void replay_vat_kernel(const int *__restric
     if (p >= n) return;
     const size_t row = perm[p];
     for (int r = 0; r < d1; ++r) vat[row * d1 + r] = evid[(size_t)r * n + p];
+}
+
+// the same, and first[v] = the smallest lookup index e that names vertex v (first preset to 0xFFFFFFFF)
+__global__ __launch_bounds__(kBlock) void replay_vat_first_kernel(const int *__restrict__ evid, const uint32_t *__restrict__ perm, int n,
+                                                                  int d1, int *__restrict__ vat, uint32_t *__restrict__ first,
+                                                                  uint32_t *__restrict__ ids, int m)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p < m) ids[p] = (uint32_t)p;
+    if (p >= n) return;
+    const size_t row = perm[p];
+    for (int r = 0; r < d1; ++r) {
+        const int v = evid[(size_t)r * n + p];
+        vat[row * d1 + r] = v;
+        atomicMin(&first[v], (uint32_t)(row * d1 + r));
+    }
+}
+
+// every lookup index e with vat[e] == v, in any order (the host sorts the handful); count may exceed cap: the caller retries
+__global__ __launch_bounds__(kBlock) void replay_match_kernel(const int *__restrict__ vat, int64_t E, int v, int *__restrict__ out,
+                                                              int cap, int *__restrict__ count)
+{
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= E || vat[e] != v) return;
+    const int k = atomicAdd(count, 1);
+    if (k < cap) out[k] = (int)e;
 }
 
 // ew_splat[r][p] = 0 for the dropped lookups (given by their caller-order index e)
@@ -144,12 +184,261 @@ uint64_t ref_hash(const int16_t *key, int d)       // h:114-121 (size_t arithmet
 
 }  // namespace
 
-// Runs between the structure build (vertex ids of every corner, vertex keys) and the gather tables.  Leaves the dropped
-// lookups / invisible vertices / missed neighbour in the lattice (host side) and ew_splat on the device.
-int replay_simulate(plx_lattice *L, hipStream_t stream)
+// ---- reference_growth = 1: the event form (header comment, "Cost") ---------------------------------------------------
+
+// hk[v] = the reference's hash of vertex v's key (h:114-121), from the packed device keys
+__global__ __launch_bounds__(kBlock) void replay_hash_kernel(const uint32_t *__restrict__ vkeys, int m, int d, int dw,
+                                                             unsigned long long *__restrict__ hk)
 {
-    L->replay = plx_lattice::Replay();
-    if (L->n_shards != 1 || L->for_merge || L->partial_cover) return PLX_OK;      // (plain single-process builds only)
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= m) return;
+    unsigned long long k = 0;
+    for (int c = 0; c < d; ++c) {
+        const int16_t kc = (int16_t)((vkeys[(size_t)v * dw + (c >> 1)] >> ((c & 1) * 16)) & 0xFFFFu);
+        k += (unsigned long long)(long long)kc;
+        k *= 2531011ull;
+    }
+    hk[v] = k;
+}
+
+namespace {
+
+// The same table model holding LABELS instead of entry ids: label v < m = the first entry created for vertex v, label
+// m + x = a further entry of vertex extra[x] (only keys a stale probe has touched ever own one).  Same hash, probing,
+// growth condition and migration order as RefTable; entry ids are not needed because only the affected keys' lookups are
+// compared entry by entry, and their entries are told apart by label.
+struct EventTable {
+    uint64_t cap = 1ull << 15;                     // h:35
+    std::vector<int32_t> tab;                      // position -> label or -1
+    std::vector<int32_t> extra;                    // label - m -> vertex
+    std::vector<uint8_t> made;                     // vertex -> its first entry exists
+    const uint64_t *hk = nullptr;
+    int64_t m = 0, filled = 0;
+    int grows = 0;
+
+    EventTable(int64_t m_, const uint64_t *hk_) : tab(cap, -1), made((size_t)m_, 0), hk(hk_), m(m_) {}
+    int32_t vertex_of(int32_t label) const { return label < m ? label : extra[(size_t)(label - m)]; }
+    bool due() const { return (uint64_t)filled >= cap / 2 - 1; }       // h:61 (size_t arithmetic)
+
+    void grow()                                    // h:125-161: re-place every entry in old-position order
+    {
+        std::vector<int32_t> old;
+        old.swap(tab);
+        cap *= 2;
+        tab.assign(cap, -1);
+        const size_t n_old = old.size();
+        for (size_t pos = 0; pos < n_old; ++pos) {
+            if (pos + 32 < n_old && old[pos + 32] >= 0) __builtin_prefetch(&hk[vertex_of(old[pos + 32])]);
+            const int32_t l = old[pos];
+            if (l < 0) continue;
+            uint64_t h = hk[vertex_of(l)] % cap;   // (old-position order visits the new homes in two rising runs: cache friendly)
+            while (tab[h] != -1) { if (++h == cap) h = 0; }
+            tab[h] = l;
+        }
+        ++grows;
+    }
+
+    // h:104-106 + h:58-95, as RefTable::lookup; *created tells whether the probe ended on an empty slot and made an entry
+    int32_t lookup(int32_t v, bool create, bool *created)
+    {
+        uint64_t h = hk[v] % cap;
+        if (due()) grow();
+        for (;;) {
+            const int32_t l = tab[h];
+            if (l == -1) {
+                if (!create) return -1;
+                int32_t label = v;
+                if (made[v]) { label = (int32_t)(m + (int64_t)extra.size()); extra.push_back(v); }
+                made[v] = 1;
+                tab[h] = label;
+                ++filled;
+                if (created) *created = true;
+                return label;
+            }
+            if (l == v || (l >= m && extra[(size_t)(l - m)] == v)) return l;
+            if (++h == cap) h = 0;
+        }
+    }
+};
+
+}  // namespace
+
+static int replay_events(plx_lattice *L, hipStream_t stream, std::vector<int> &dropped, std::vector<int> &invisible)
+{
+    const int n = (int)L->n, d = L->d, d1 = d + 1, dw = (d + 1) / 2, order = L->order;
+    const int64_t m = L->m, E = (int64_t)n * d1;
+    if (E >= (1ll << 31)) { set_error("reference_growth: %lld lookups exceed the replay's 31-bit index", (long long)E); return PLX_ERR_TOO_LARGE; }
+    // ---- device: lookup -> vertex in caller order, every vertex's first lookup, the vertices sorted by it, their hashes
+    PLX_TRY(ensure(L->replay_vat, (size_t)E * 4));
+    PLX_TRY(ensure(L->replay_keys, (size_t)m * 4 * 4 + (size_t)m * 8 + 64));
+    PLX_TRY(ensure(L->sort_temp, radix_temp_bytes(m)));
+    uint32_t *first_a = L->replay_keys.as<uint32_t>(), *first_b = first_a + m, *ids_a = first_b + m, *ids_b = ids_a + m;
+    unsigned long long *d_hk = reinterpret_cast<unsigned long long *>(ids_b + m);     // (16 m bytes in: 8-byte aligned)
+    int *d_count = reinterpret_cast<int *>(d_hk + m);
+    PLX_HIP_TRY(hipMemsetAsync(first_a, 0xFF, (size_t)m * 4, stream));
+    replay_vat_first_kernel<<<ceil_div(n > m ? (int64_t)n : m, kBlock), kBlock, 0, stream>>>(
+        L->evid.as<int>(), L->perm.as<uint32_t>(), n, d1, L->replay_vat.as<int>(), first_a, ids_a, (int)m);
+    replay_hash_kernel<<<ceil_div(m, kBlock), kBlock, 0, stream>>>(L->vkeys.as<uint32_t>(), (int)m, d, dw, d_hk);
+    int ebits = 1;
+    while ((1ll << ebits) < E) ++ebits;
+    int second = 0;
+    PLX_TRY(radix_sort_pairs32(L->sort_temp.p, first_a, first_b, ids_a, ids_b, m, ebits, &second, stream));
+    std::vector<uint32_t> ce((size_t)m), cv((size_t)m);          // creation order: vertex cv[i] is first looked up at lookup ce[i]
+    std::vector<uint64_t> hk((size_t)m);
+    PLX_HIP_TRY(hipMemcpyAsync(ce.data(), second ? first_b : first_a, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
+    PLX_HIP_TRY(hipMemcpyAsync(cv.data(), second ? ids_b : ids_a, (size_t)m * 4, hipMemcpyDeviceToHost, stream));
+    PLX_HIP_TRY(hipMemcpyAsync(hk.data(), d_hk, (size_t)m * 8, hipMemcpyDeviceToHost, stream));
+    PLX_HIP_TRY(hipStreamSynchronize(stream));
+    if (ce[0] != 0u || ce[(size_t)m - 1] == 0xFFFFFFFFu) {
+        set_error("reference_growth: a vertex without a lookup (first = %u .. %u)", ce[0], ce[(size_t)m - 1]);
+        return PLX_ERR_STATE;
+    }
+
+    // small device reads the event loop needs now and then (each synchronises: a handful per build)
+    int rc_dev = PLX_OK;
+    auto vat_at = [&](int64_t e) -> int32_t {
+        int32_t v = -1;
+        if (hipMemcpyAsync(&v, L->replay_vat.as<int>() + e, 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) rc_dev = PLX_ERR_HIP;
+        return v;
+    };
+    auto lookups_of = [&](int32_t v, std::vector<int32_t> &out) {
+        size_t cap = L->replay_list.cap / 4;
+        if (cap < (1u << 16)) { if (ensure(L->replay_list, (size_t)4 << 16) != PLX_OK) { rc_dev = PLX_ERR_HIP; return; } cap = L->replay_list.cap / 4; }
+        for (;;) {
+            int count = 0;
+            if (hipMemsetAsync(d_count, 0, 4, stream) != hipSuccess) { rc_dev = PLX_ERR_HIP; return; }
+            replay_match_kernel<<<ceil_div(E, kBlock), kBlock, 0, stream>>>(L->replay_vat.as<int>(), E, v, L->replay_list.as<int>(), (int)cap, d_count);
+            if (hipMemcpyAsync(&count, d_count, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { rc_dev = PLX_ERR_HIP; return; }
+            if ((size_t)count <= cap) {
+                out.resize((size_t)count);
+                if (count > 0 && (hipMemcpyAsync(out.data(), L->replay_list.p, (size_t)count * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                                  hipStreamSynchronize(stream) != hipSuccess)) { rc_dev = PLX_ERR_HIP; return; }
+                std::sort(out.begin(), out.end());
+                return;
+            }
+            if (ensure(L->replay_list, (size_t)count * 4 + 64) != PLX_OK) { rc_dev = PLX_ERR_HIP; return; }
+            cap = L->replay_list.cap / 4;
+        }
+    };
+    auto key_of = [&](int32_t v, int16_t *key) {
+        uint32_t w[(PLX_MAX_DIM + 1) / 2];
+        if (hipMemcpyAsync(w, L->vkeys.as<uint32_t>() + (size_t)v * dw, (size_t)dw * 4, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) { rc_dev = PLX_ERR_HIP; return; }
+        for (int c = 0; c < d; ++c) key[c] = (int16_t)((w[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu);
+    };
+
+    // ---- splat(): creations in caller order + every lookup of the keys a stale probe has touched
+    EventTable T(m, hk.data());
+    std::vector<uint8_t> affected((size_t)m, 0);
+    std::vector<int32_t> aff_list;                                              // the affected vertices, in the order they became so
+    std::unordered_map<int32_t, std::vector<std::pair<int32_t, int32_t>>> hist;   // affected vertex -> (lookup, label it returned)
+    using Ev = std::pair<int32_t, int32_t>;                                     // (lookup index, vertex)
+    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> pq;
+    std::vector<int32_t> tmp;
+    auto make_affected = [&](int32_t v, int64_t now) {      // from lookup `now` on, every lookup of v is run
+        if (affected[v]) return;
+        affected[v] = 1;
+        aff_list.push_back(v);
+        lookups_of(v, tmp);
+        auto &h = hist[v];
+        for (int32_t e : tmp) {
+            if (e < now) h.emplace_back(e, v);              // earlier lookups found its one regular entry (label v)
+            else pq.emplace(e, v);
+        }
+    };
+    auto after_create = [&](int64_t e) {                    // the table is at its growth threshold: lookup e + 1 probes stale
+        if (T.due() && e + 1 < E) make_affected(vat_at(e + 1), e + 1);
+    };
+    int64_t i = 0;
+    constexpr int64_t kAhead = 24;
+    for (;;) {
+        while (i < m && affected[cv[i]]) ++i;               // an affected vertex's creation comes off the queue
+        const int64_t tc = i < m ? (int64_t)ce[i] : INT64_MAX, th = pq.empty() ? INT64_MAX : (int64_t)pq.top().first;
+        if (tc == INT64_MAX && th == INT64_MAX) break;
+        bool created = false;
+        if (tc < th) {
+            if (i + kAhead < m) __builtin_prefetch(&T.tab[hk[cv[i + kAhead]] % T.cap]);
+            if (i + 2 * kAhead < m) __builtin_prefetch(&hk[cv[i + 2 * kAhead]]);
+            const int32_t v = (int32_t)cv[i++];
+            T.lookup(v, true, &created);
+            if (created) after_create(tc);
+        } else {
+            const Ev ev = pq.top();
+            pq.pop();
+            const int32_t label = T.lookup(ev.second, true, &created);
+            hist[ev.second].emplace_back(ev.first, label);
+            if (created) after_create(ev.first);
+        }
+        if (rc_dev != PLX_OK) { set_error("reference_growth: a device read of the replay failed"); return rc_dev; }
+    }
+    auto &rp = L->replay;
+    rp.active = true;
+    rp.m_reference = T.filled;
+    rp.grows = T.grows;
+
+    // ---- blur(): its first lookup is entry 0's neighbour on axis 0 at tap nid = -order (h:526-545); if the table doubles
+    // there, that lookup is the stale one (as in replay_full; keys of the few entries on the probe path come from the device)
+    const int32_t v0 = (int32_t)cv[0];
+    const int grows_before = T.grows;
+    if (order >= 1) {
+        int16_t key[PLX_MAX_DIM + 1], nk[PLX_MAX_DIM + 1], uk[PLX_MAX_DIM + 1];
+        key_of(v0, key);
+        const int nid = -order;
+        bool in_range = true;
+        for (int c = 0; c < d; ++c) {
+            const int val = (int)key[c] - nid + (c == 0 ? nid * d1 : 0);
+            in_range = in_range && val >= -32768 && val <= 32767;
+            nk[c] = (int16_t)val;
+        }
+        const uint64_t hn = ref_hash(nk, d);
+        auto find_by_key = [&](bool stale_first) -> int32_t {
+            uint64_t h = hn % T.cap;
+            if (stale_first && T.due()) T.grow();
+            for (;;) {
+                const int32_t l = T.tab[h];
+                if (l == -1) return -1;
+                key_of(T.vertex_of(l), uk);
+                bool same = true;
+                for (int c = 0; c < d && same; ++c) same = uk[c] == nk[c];
+                if (same) return l;
+                if (++h == T.cap) h = 0;
+            }
+        };
+        const int32_t first = find_by_key(true);
+        if (T.grows != grows_before && first < 0) {
+            const int32_t again = find_by_key(false);
+            if (again >= 0 && in_range) { rp.blur_miss = true; rp.blur_miss_vertex = v0; }
+        }
+    } else if (T.due()) {
+        T.grow();
+        rp.inexact = true;
+    }
+    if (rc_dev != PLX_OK) { set_error("reference_growth: a device read of the replay failed"); return rc_dev; }
+
+    // ---- what blur-time lookups resolve the affected keys to (every other key: its one entry, always found)
+    for (int32_t v : aff_list) {
+        const int32_t F = T.lookup(v, false, nullptr);
+        if (F < 0) invisible.push_back((int)v);
+        for (const auto &el : hist[v])
+            if (el.second != F) dropped.push_back((int)el.first);
+    }
+    std::sort(invisible.begin(), invisible.end());
+    std::sort(dropped.begin(), dropped.end());
+    if (rp.blur_miss && T.filled != m) {
+        int copies = 1;
+        for (int32_t u : T.extra) copies += (u == v0);
+        if (copies > 1) rp.inexact = true;
+    }
+    rp.n_dropped = (int)dropped.size();
+    rp.n_invisible = (int)invisible.size();
+    return PLX_OK;
+}
+
+// reference_growth = 2: every one of the N (d+1) lookups of splat() run against the model, in the caller's order.  About a
+// second at N = 1e6 (one dependent cache miss per lookup); kept as the checker of the event form below.
+static int replay_full(plx_lattice *L, hipStream_t stream, std::vector<int> &dropped, std::vector<int> &invisible)
+{
     const int n = (int)L->n, d = L->d, d1 = d + 1, dw = (d + 1) / 2, order = L->order;
     const int64_t m = L->m, E = (int64_t)n * d1;
     if (m <= 0 || E <= 0) return PLX_OK;
@@ -223,12 +512,10 @@ int replay_simulate(plx_lattice *L, hipStream_t stream)
 
     // what blur-time lookups resolve every key to (h:545 with create = false), and from that the dropped lookups
     std::vector<int32_t> F((size_t)m);
-    std::vector<int> invisible;
     for (int64_t v = 0; v < m; ++v) {
         F[v] = T.lookup(hk[v], (int32_t)v, false);
         if (F[v] < 0) invisible.push_back((int)v);
     }
-    std::vector<int> dropped;
     for (int64_t e = 0; e < E; ++e)
         if (R[e] != F[vat[e]]) dropped.push_back((int)e);
     if (rp.blur_miss && (int64_t)T.ekey.size() != m) {
@@ -239,8 +526,14 @@ int replay_simulate(plx_lattice *L, hipStream_t stream)
     }
     rp.n_dropped = (int)dropped.size();
     rp.n_invisible = (int)invisible.size();
+    return PLX_OK;
+}
 
-    // device side: the splat's own copy of the weights, with the dropped lookups zeroed
+// device side of both forms: the splat's own copy of the weights with the dropped lookups zeroed, the invisible list
+static int replay_finish(plx_lattice *L, hipStream_t stream, const std::vector<int> &dropped, const std::vector<int> &invisible)
+{
+    const int n = (int)L->n, d1 = L->d + 1;
+    const int64_t E = (int64_t)n * d1;
     PLX_TRY(ensure(L->ew_splat, (size_t)E * 4));
     PLX_HIP_TRY(hipMemcpyAsync(L->ew_splat.p, L->ew.p, (size_t)E * 4, hipMemcpyDeviceToDevice, stream));
     if (!dropped.empty()) {
@@ -259,6 +552,19 @@ int replay_simulate(plx_lattice *L, hipStream_t stream)
     L->flags_valid = false;      // (the first-touch splat reads the slice's weights: not in this mode)
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
+}
+
+// Runs between the structure build (vertex ids of every corner, vertex keys) and the gather tables.  Leaves the dropped
+// lookups / invisible vertices / missed neighbour in the lattice (host side) and ew_splat on the device.
+int replay_simulate(plx_lattice *L, hipStream_t stream)
+{
+    L->replay = plx_lattice::Replay();
+    if (L->n_shards != 1 || L->for_merge || L->partial_cover) return PLX_OK;      // (plain single-process builds only)
+    if (L->m <= 0 || L->n <= 0) return PLX_OK;
+    std::vector<int> dropped, invisible;
+    if (g_reference_growth == 2) PLX_TRY(replay_full(L, stream, dropped, invisible));
+    else PLX_TRY(replay_events(L, stream, dropped, invisible));
+    return replay_finish(L, stream, dropped, invisible);
 }
 
 // after the neighbour table is built, before anything is derived from it (axis pairs, compacted copy)

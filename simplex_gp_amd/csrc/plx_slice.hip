@@ -298,6 +298,139 @@ __global__ __launch_bounds__(kBlock) void slice_contract_kernel(const int *__res
         for (int l = lane; l < L; l += 64) grad_src[row * L + l] = f[l];
 }
 
+// The same with the corner count compiled in (round 6).  What the run-time form above leaves on the table: its d+1
+// row gathers go out three at a time from a loop the compiler cannot pipeline (a wave waits three memory latencies
+// per point), and its contraction runs on d lanes for 4 L serial LDS reads.  Here
+//   * all d+1 rows (up to kContractLoads 16-byte loads per lane) are requested before the first is used, the row
+//     bases in scalar registers (compile-time lane of v_readlane);
+//   * the contraction uses all 64 lanes: lane = (l-group, k), each lane sums its l's, one xor-butterfly over the
+//     l-groups.  The slice sums are formed in corner order exactly as above (bit-identical f); the contraction's
+//     sum over l is associated differently (within rounding of the run-time form).
+// One point per wave stays (PPW = 1): walking 2 / 4 / 8 / 16 points per wave with the next point's corner ids, weights
+// and record fetched behind the current point's rows was measured SLOWER (N = 1e6, d = 8, L = 11, m = 1.73e6 / 1.1e6,
+// us: run-time form 932 / 853; PPW 1 / 2 / 4 / 8 / 16 = 686 / 749 / 758 / 802 / 860 and 617 / 638 / 673 / 703 / 748):
+// the launch's parallelism is waves, and a wave that loops holds its registers while it waits.
+constexpr int kContractLoads = 12;
+constexpr int kContractPoints = 1;
+
+template <int D1, int MAXCH, int PPW = kContractPoints>
+__global__ __launch_bounds__(kBlock) void slice_contract_d_kernel(const int *__restrict__ evid, const float *__restrict__ ew,
+                                                                  const uint32_t *__restrict__ perm, int n, int own_begin,
+                                                                  int n_own, const float4 *__restrict__ values, int nch,
+                                                                  const float *__restrict__ rec, int recw, int L, float rden,
+                                                                  float *__restrict__ grad_x, float *__restrict__ grad_src,
+                                                                  int ntiles, int remap)
+{
+    constexpr int d = D1 - 1;
+    constexpr int DK = d <= 1 ? 1 : d <= 2 ? 2 : d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : 32;   // lanes per l-group
+    constexpr int G = 64 / DK;                                                                  // l-groups per wave
+    constexpr int RB = (kContractLoads / MAXCH) < D1 ? (kContractLoads / MAXCH) : D1;           // rows in flight
+    __shared__ float4 f4s[kBlock / 64][64 * MAXCH];
+    __shared__ float recs[kBlock / 64][64];
+    const int tile = tile_index(ntiles, remap);
+    if (tile < 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pl0 = tile * (kBlock / 64) * PPW + wave;
+    if (pl0 >= n_own) return;                      // whole waves leave together; no workgroup barrier below
+    const int half = L * (1 + d);
+    const int k = lane & (DK - 1), lg = lane / DK;
+    const int kk = k < d ? k : d - 1;
+    const float *f = reinterpret_cast<const float *>(f4s[wave]);
+    const float *rc = recs[wave];
+
+    int n_v = 0;
+    float n_w = 0.f, n_rec = 0.f;
+    auto fetch = [&](int pl) {
+        const int p = own_begin + pl;
+        n_v = 0; n_w = 0.f; n_rec = 0.f;
+        if (pl < n_own) {
+            if (lane < D1) { n_v = evid[(size_t)lane * n + p]; n_w = ew[(size_t)lane * n + p]; }
+            if (lane < recw) n_rec = rec[(size_t)pl * recw + lane];
+        }
+    };
+    fetch(pl0);
+#pragma unroll 1
+    for (int it = 0; it < PPW; ++it) {
+        const int pl = pl0 + it * (kBlock / 64);
+        if (pl >= n_own) break;                    // wave-uniform
+        const int my_v = n_v;
+        const float my_w = n_w, my_rec = n_rec;
+        if constexpr (PPW > 1) fetch(pl + (kBlock / 64));   // the next point's ids / weights / record, behind this point's rows
+        float4 acc[MAXCH];
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) acc[q] = f4_zero();
+        // a batch of C rows: every load of the batch before its first sum (C compile-time, the first row in a scalar register)
+        auto batch = [&](int r0, auto cnt) {
+            constexpr int C = decltype(cnt)::value;
+            float4 gq[C][MAXCH];
+            float w[C];
+#pragma unroll
+            for (int u = 0; u < C; ++u) {
+                const int v = __builtin_amdgcn_readlane(my_v, r0 + u);
+                w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), r0 + u));
+                const float4 *row = values + (size_t)v * nch;
+#pragma unroll
+                for (int q = 0; q < MAXCH; ++q) gq[u][q] = (lane + 64 * q < nch) ? row[lane + 64 * q] : f4_zero();
+            }
+#pragma unroll
+            for (int u = 0; u < C; ++u)
+#pragma unroll
+                for (int q = 0; q < MAXCH; ++q) {
+                    acc[q].x += w[u] * gq[u][q].x * rden; acc[q].y += w[u] * gq[u][q].y * rden;
+                    acc[q].z += w[u] * gq[u][q].z * rden; acc[q].w += w[u] * gq[u][q].w * rden;
+                }
+        };
+        constexpr int NB = D1 / RB, REM = D1 % RB;
+        if constexpr (NB == 1) batch(0, std::integral_constant<int, RB>{});
+        else {
+#pragma unroll 1
+            for (int bq = 0; bq < NB; ++bq) batch(bq * RB, std::integral_constant<int, RB>{});   // (a real loop: the register budget is one batch)
+        }
+        if constexpr (REM > 0) batch(NB * RB, std::integral_constant<int, REM>{});
+        __builtin_amdgcn_wave_barrier();           // the previous point's LDS reads are done (one wave: in order)
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) f4s[wave][lane + 64 * q] = acc[q];
+        recs[wave][lane] = my_rec;
+        __builtin_amdgcn_wave_barrier();           // the LDS rows are private to this wave
+        __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the ds_writes above have landed
+        const size_t row = perm ? (size_t)((int)perm[own_begin + pl] - own_begin) : (size_t)pl;
+        const float xk = rc[2 * L + kk];
+        float a = 0.f;
+        for (int l0 = 0; l0 < L; l0 += G) {        // uniform trip count: every lane takes part in the butterfly below
+            const int l = l0 + lg;
+            const bool on = l < L;
+            const int lc = on ? l : 0;
+            const float gv = rc[lc], sv = rc[L + lc];
+            const float t = sv * xk * f[lc] - sv * f[L + lc * d + kk] + gv * xk * f[half + lc] - gv * f[half + L + lc * d + kk];
+            a += on ? t : 0.f;
+        }
+#pragma unroll
+        for (int off = DK; off < 64; off <<= 1) a += __shfl_xor(a, off);
+        if (lane < d) grad_x[row * d + lane] = -2.0f * a;
+        if (grad_src)
+            for (int l = lane; l < L; l += 64) grad_src[row * L + l] = f[l];
+    }
+}
+
+template <int MAXCH>
+static bool launch_slice_contract_d(plx_lattice *lat, const float4 *res, int nch, const float *rec, int recw, int L,
+                                    float *d_grad_x, float *d_grad_src, hipStream_t stream)
+{
+    const int n_own = (int)(lat->own_end - lat->own_begin);
+    const uint32_t *perm = lat->lattice_rows ? nullptr : lat->perm.as<uint32_t>();
+    const int nt = ceil_div(n_own, (kBlock / 64) * kContractPoints);
+    const int grid = tile_grid(nt, g_xcd_remap);
+    switch (lat->d + 1) {
+#define PLX_CASE(D1) \
+    case D1: slice_contract_d_kernel<D1, MAXCH><<<grid, kBlock, 0, stream>>>(lat->evid.as<int>(), lat->ew.as<float>(), perm, (int)lat->n, (int)lat->own_begin, n_own, res, nch, rec, recw, L, 1.0f / lat->slice_denom, d_grad_x, d_grad_src, nt, g_xcd_remap); return true;
+        PLX_CASE(2) PLX_CASE(3) PLX_CASE(4) PLX_CASE(5) PLX_CASE(6) PLX_CASE(7) PLX_CASE(8) PLX_CASE(9) PLX_CASE(10)
+        PLX_CASE(11) PLX_CASE(12) PLX_CASE(13) PLX_CASE(14) PLX_CASE(15) PLX_CASE(16) PLX_CASE(17) PLX_CASE(18)
+        PLX_CASE(19) PLX_CASE(20) PLX_CASE(21)
+#undef PLX_CASE
+    default: return false;
+    }
+}
+
 int backward_impl(plx_lattice *lat, const float *d_g, const float *d_src, const float *d_x, int L, float *d_grad_x,
                   float *d_grad_src, hipStream_t stream)
 {
@@ -317,7 +450,11 @@ int backward_impl(plx_lattice *lat, const float *d_g, const float *d_src, const 
     const float *rec = lat->rec.as<float>();
     const int nt = ceil_div(n_own, kBlock / 64);
     const int sgrid = tile_grid(nt, g_xcd_remap);
-    if (nch <= 64)
+    const bool compiled = g_contract_v != 0 &&
+                          (nch <= 64 ? launch_slice_contract_d<1>(lat, res, nch, rec, recw, L, d_grad_x, d_grad_src, stream)
+                                     : launch_slice_contract_d<2>(lat, res, nch, rec, recw, L, d_grad_x, d_grad_src, stream));
+    if (compiled) {
+    } else if (nch <= 64)
         slice_contract_kernel<1><<<sgrid, kBlock, 0, stream>>>(lat->evid.as<int>(), lat->ew.as<float>(), perm, (int)lat->n,
                                                               (int)lat->own_begin, n_own, d + 1, res, nch, rec, recw, L, d,
                                                               1.0f / lat->slice_denom, d_grad_x, d_grad_src, nt, g_xcd_remap);

@@ -361,6 +361,13 @@ def test_bench_self_launches_its_ranks(tmp_path):
     assert res["allreduce_bytes"] == res["config"]["m_vertices"] * 4
     assert set(res["stage_us"]) == {"splat", "exchange", "blur", "slice"}
     assert res["exchange"]["bytes"] == res["allreduce_bytes"] and res["exchange"]["us"] > 0 and "all_reduce" in res["exchange"]["kind"]
+    # the prediction beside the measurement: what the rank's own stage times say two GPUs are worth against one
+    exp = res["expected_speedup_vs_1gpu"]
+    st = res["stage_us"]
+    assert abs(exp["t_rank_us"] - sum(st.values())) < 0.5
+    assert abs(exp["t_one_gpu_us"] - (2 * (st["splat"] + st["slice"]) + st["blur"])) < 0.5
+    assert 0 < exp["warm_mvm"] <= 2.0 + 1e-6 and exp["warm_mvm"] <= exp["warm_mvm_if_exchange_were_free"]
+    assert "with_one_build_per_2_mvms" in exp and "6x" in res["expected_speedup_note"]
     check = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "check_bench_dump.py"), dump], env=env,
                            capture_output=True, text=True, timeout=600)
     assert check.returncode == 0 and "OK" in check.stdout, check.stdout + check.stderr
@@ -404,6 +411,10 @@ def test_bench_multi_rank_full_legs_rehearsal():
         assert is_exchange(res[leg]["exchange_vd1"]), leg
         assert res[leg]["mvms_per_s_vd1"] > 0
     assert is_exchange(res["config4"]["exchange_vd11"])
+    assert 0 < res["expected_speedup_vs_1gpu"]["warm_mvm"] <= 4.0 + 1e-6
+    for leg, vd in (("config4", 1), ("config4", 11), ("weak_1e6_per_gpu", 1), ("weak_4e6_per_gpu", 1)):
+        e = res[leg][f"expected_speedup_vs_1gpu_vd{vd}"]
+        assert 0 < e["warm_mvm"] <= 4.0 + 1e-6 and 0 <= e["replicated_share_of_rank_time"] <= 1, (leg, vd, e)
     assert "columns_mode" in res and "config3_cg" in res and "grid_vd11" in res["config4"]
     for mode in ("points", "columns"):
         assert is_exchange(res["config3_cg"][mode]["exchange"]), mode

@@ -389,3 +389,20 @@ def test_column_sharded_training_step_equals_single_process(tmp_path, world, pre
     assert abs(float(np.load(tmp_path / "value.npy")) - float(want.detach())) <= 1e-5 * (1 + abs(float(want.detach())))
     got = np.load(tmp_path / "grads.npy")
     assert np.allclose(got, grads, rtol=2e-4, atol=1e-6), (got, grads)
+
+
+def test_bench_expected_speedup_model():
+    """bench.expected_speedup: the prediction a multi-rank bench line carries next to its measurement (DESIGN.md 5's model:
+    splat and slice shard by points, the blur is replicated, the exchange exists only between ranks)."""
+    import bench
+    st = {"splat": 40.0, "exchange": 50.0, "blur": 44.0, "slice": 30.0}           # the config-4 figures of DESIGN.md 5, us
+    e = bench.expected_speedup(st, 8)
+    assert e["t_rank_us"] == 164.0 and e["t_one_gpu_us"] == 8 * 70.0 + 44.0
+    assert abs(e["warm_mvm"] - 604.0 / 164.0) < 0.01 and abs(e["warm_mvm_if_exchange_were_free"] - 604.0 / 114.0) < 0.01
+    assert abs(e["replicated_share_of_rank_time"] - 94.0 / 164.0) < 1e-3
+    # no replicated work and a free exchange: the model's ceiling is the rank count
+    assert bench.expected_speedup({"splat": 10.0, "exchange": 0.0, "blur": 0.0, "slice": 10.0}, 8)["warm_mvm"] == 8.0
+    # the cadence with a build that does not shard: one build of 1 ms per 20 MVMs
+    b = bench.expected_speedup(st, 8, build=(1.0, 20))
+    assert abs(b["with_one_build_per_20_mvms"] - (604.0 + 50.0) / (164.0 + 50.0)) < 0.01
+    assert bench.expected_speedup({}, 8) is None

@@ -321,6 +321,52 @@ def test_reference_growth_replay_quirk_survey(plx, reference_growth, seed):
     print(f"seed {seed}: worst rel-L2 vs the reference with the replay on {worst:.2e}; inputs where the quirk alone exceeds 1e-4: {hit}")
 
 
+def test_reference_growth_event_replay_equals_full_replay(plx):
+    """plx_tune("reference_growth", 1) replays EVENTS (the m first-touch creations, the stale probe behind each doubling and
+    every lookup of the keys such a probe has touched: O(m) host work); 2 runs all N (d+1) lookups against the table model
+    (the round-5 form).  Same findings -- the reference's entry count, dropped lookups, invisible vertices, the blur-time
+    miss -- and bit-identical outputs on the quirk survey's shapes and on the BASELINE lengthscale where the quirk exceeds
+    1e-4 (N = 1e6, d = 8, l = 0.6931); the event form's wall time is printed beside the full form's."""
+    import time
+    import bench
+    from simplex_gp_amd import _native as nv
+    shapes = [(n, d, ell, 7) for n, d, ell in QUIRK_SURVEY_SHAPES] + [(1_000_000, 8, 0.6931, 1234), (1_000_000, 8, 1.0, 1234)]
+    try:
+        for n, d, ell, seed in shapes:
+            g = torch.Generator().manual_seed(seed + n % 997 + d)
+            x = torch.randn(n, d, generator=g)
+            v = torch.randn(n, 1, generator=g).cuda()
+            ref = (x / ell).contiguous().cuda()
+            res = {}
+            for mode in (2, 1):
+                nv.check(nv.lib().plx_tune(b"reference_growth", mode), "plx_tune")
+                lat = plx.Lattice().build(ref, bench.RBF1)                  # (sizes the buffers; the timed build follows)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                lat.build(ref, bench.RBF1)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3
+                res[mode] = (lat.reference_growth_info(), lat.apply(v).clone(), ms, lat.m)
+                lat.close()
+            nv.check(nv.lib().plx_tune(b"reference_growth", 0), "plx_tune")
+            lat = plx.Lattice().build(ref, bench.RBF1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lat.build(ref, bench.RBF1)
+            torch.cuda.synchronize()
+            plain_ms = (time.perf_counter() - t0) * 1e3
+            lat.close()
+            (full, out_full, ms_full, m), (ev, out_ev, ms_ev, _) = res[2], res[1]
+            print(f"n={n} d={d} l={ell} m={m}: build {plain_ms:.2f} ms plain, +{ms_ev - plain_ms:.1f} ms event replay, "
+                  f"+{ms_full - plain_ms:.1f} ms full replay; {ev}")
+            assert ev == full, (n, d, ell, ev, full)
+            assert torch.equal(out_ev, out_full), (n, d, ell)
+            if n == 1_000_000 and ell < 1.0:
+                assert ms_ev - plain_ms <= 60.0, (ms_ev, plain_ms)            # the round-5 verdict's bar for a usable exact mode
+    finally:
+        nv.check(nv.lib().plx_tune(b"reference_growth", 0), "plx_tune")
+
+
 @pytest.mark.parametrize("name", ["n1e5_d4_ell1.0", "n1e5_d4_ell0.25", "n1e5_d4_vd11_ell1.0",
                                   "n1e6_d8_ell1.0", "n1e6_d8_ell0.6931"])
 def test_large_vs_reference_probes(plx, golden_dir, name):
