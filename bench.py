@@ -407,6 +407,52 @@ class Ctx:
         return float(t.item())
 
 
+def graph_launches(fn):
+    """What capturing fn() into a HIP graph records: {"kernels": kernel nodes, "nodes": all nodes (memsets and copies
+    too)} -- the launch count of a piece of the hot loop without a profiler.  None when the capture is not possible
+    (fn synchronises or allocates outside torch's graph pool)."""
+    import ctypes
+    import torch
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        g = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(g):
+            fn()
+        graph = ctypes.c_void_p(g.raw_cuda_graph())
+        cnt = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(graph, None, ctypes.byref(cnt)) != 0:
+            return None
+        nodes = (ctypes.c_void_p * max(cnt.value, 1))()
+        if hip.hipGraphGetNodes(graph, nodes, ctypes.byref(cnt)) != 0:
+            return None
+        kernels = 0
+        for i in range(cnt.value):
+            kind = ctypes.c_int(-1)
+            hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(kind))
+            kernels += kind.value == 0                      # hipGraphNodeTypeKernel
+        return {"kernels": int(kernels), "nodes": int(cnt.value)}
+    except Exception as e:                                   # noqa: BLE001  (a measuring aid: never fails the bench line)
+        log(f"bench.py: graph_launches: {type(e).__name__}: {e}")
+        return None
+
+
+def cg_launch_count(model, x, rhs):
+    """Launches per CG iteration of khat_solve on the cached lattice: the difference between the captured graphs of a
+    6- and a 2-iteration solve (tol = 0: no convergence read-back inside), divided by 4."""
+    import torch
+    torch.cuda.synchronize()
+    for it in (2, 6):
+        model.khat_solve(x, rhs, max_iter=it, tol=0.0)          # sizes every buffer both captures will ask for
+    torch.cuda.synchronize()
+    a = graph_launches(lambda: model.khat_solve(x, rhs, max_iter=2, tol=0.0))
+    b = graph_launches(lambda: model.khat_solve(x, rhs, max_iter=6, tol=0.0))
+    torch.cuda.synchronize()
+    if not a or not b:
+        return None
+    return {"kernels": (b["kernels"] - a["kernels"]) / 4.0, "graph_nodes": (b["nodes"] - a["nodes"]) / 4.0,
+            "how": "HIP-graph capture of khat_solve at 6 and at 2 iterations, difference / 4 (kernel nodes; all nodes)"}
+
+
 def config3_leg(ctx, n=1_000_000, d=8, iters=50):
     """BASELINE.json configs[2] as the reference's training loop runs it (experiments/train_simplexgp.py:29-57):
     50 CG iterations on (s K + sigma^2 I) with right-hand side [y | 10 Rademacher probes] (vd = 11), GPyTorch default
@@ -421,9 +467,12 @@ def config3_leg(ctx, n=1_000_000, d=8, iters=50):
     Z = (torch.randint(0, 2, (n, 10), generator=g).float() * 2 - 1).to(ctx.dev)
     rhs = torch.cat([y[:, None], Z], 1)
     model = solvers.LatticeGP(plx.RBFLattice(order=1, ard_num_dims=d)).to(ctx.dev)
-    best, best_warm, res, m = float("inf"), float("inf"), None, None
+    best, best_warm, best_rebuild, res, m = float("inf"), float("inf"), float("inf"), None, None
     with torch.no_grad():
         for trial in range(4):
+            # a COLD build: nothing of an earlier lattice on these points is reused (the cache is emptied, so the lattice is
+            # a fresh object and its point order is computed from the positions) -- the figure of rounds 1-5
+            plx.lattice_cache().clear()
             model.kernel.lengthscale = 0.6931 * (1 + 1e-5 * trial)
             ctx.sync()
             t0 = time.perf_counter()
@@ -434,10 +483,19 @@ def config3_leg(ctx, n=1_000_000, d=8, iters=50):
             _, info = model.khat_solve(x, rhs, max_iter=iters, tol=0.0)      # lattice cached: CG only
             ctx.sync()
             dtw = time.perf_counter() - t1
+            # the rebuild a training step pays: the same data under a lengthscale that moved -- the cache rebuilds the
+            # lattice in place with the point order kept (round 6: Lattice.build(reuse_order=True))
+            model.kernel.lengthscale = 0.6931 * (1 + 1e-5 * trial + 5e-6)
+            ctx.sync()
+            t2 = time.perf_counter()
+            _, info = model.khat_solve(x, rhs, max_iter=iters, tol=0.0)
+            ctx.sync()
+            dtr = time.perf_counter() - t2
             if trial > 0:
-                best, best_warm = min(best, dt), min(best_warm, dtw)
+                best, best_warm, best_rebuild = min(best, dt), min(best_warm, dtw), min(best_rebuild, dtr)
             res = float(info["residual"].max())
             m = list(plx.lattice_cache()._entries.values())[-1][0].m
+        launches = cg_launch_count(model, x, rhs)
         # the rank-100 pivoted-Cholesky factor of the reference's recipe (train_simplexgp.py:36) on this lattice, by itself
         pre = model.preconditioner(x, 100)
         fbest = float("inf")
@@ -457,8 +515,11 @@ def config3_leg(ctx, n=1_000_000, d=8, iters=50):
     train = train_step_leg(ctx, n, d, lambda: plx.RBFLattice(order=1, ard_num_dims=d))
     return {"config3_cg_ms": round(best * 1e3, 2), "config3": {
         "workload": f"N={n}, d={d}, vd=11, lengthscale 0.6931, {iters} CG iterations incl. one lattice build",
-        "ms_incl_build": round(best * 1e3, 2), "ms_cg_only": round(best_warm * 1e3, 2), "m_vertices": m,
+        "ms_incl_build": round(best * 1e3, 2), "ms_cg_only": round(best_warm * 1e3, 2),
+        "ms_incl_warm_rebuild": round(best_rebuild * 1e3, 2),       # the lattice of a moved lengthscale, point order kept
+        "m_vertices": m,
         "cg_iterations_per_s": round(iters / best_warm, 1), "final_rel_residual_max": res, "factor": factor,
+        "launches_per_cg_iteration": launches,
         "train_step_ms": {k: v["step_ms"] for k, v in train.items() if k.startswith("pre_size")}, "train_step": train}}
 
 

@@ -49,7 +49,7 @@ def main():
               else plx.RBFLattice(order=args.order, ard_num_dims=args.d))
     model = solvers.LatticeGP(kernel, min_noise=args.min_noise).to(dev)
     t0 = time.perf_counter()
-    history, best = training.fit(model, tr, val=va, test=te, epochs=args.epochs, lr=args.lr, pre_size=args.pre_size, checkpoint=args.out,
+    history, best = training.fit(model, tr, val=va, test=te, epochs=args.epochs, lr=args.lr, pre_size=args.pre_size, checkpoint=args.out, cap_host_threads=True,
                                  log=lambda row: print(json.dumps({k: round(v, 4) if isinstance(v, float) else v
                                                                    for k, v in row.items()}), flush=True))
     torch.cuda.synchronize()

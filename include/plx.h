@@ -140,8 +140,10 @@ int64_t plx_num_vertices(const plx_lattice *lat);  /* m = hashTable.size(), h:44
  * lookup that triggers each doubling probes from a stale bucket: a duplicate entry for a key that exists, or a key that
  * later lookups do not find; grow() (:125-161) then re-places entries in old-position order.  The default build is the
  * duplicate-free lattice (which is also what the reference's CUDA path builds: its table never grows).  With the switch
- * on, plx_build / plx_filter replay the reference's table LAYOUT on the host (entry positions only, O(N (d+1)) work, about
- * a second at N = 1e6) and patch the built structure so that every MVM equals the reference's filter(): the splat
+ * on, plx_build / plx_filter replay the reference's table LAYOUT on the host (entry positions only; the EVENTS that shape it
+ * -- the m first-touch creations, the stale probe behind each doubling, every lookup of the few keys such a probe touched:
+ * O(m) host work, 45-60 ms at N = 1e6, d = 8, m = 1.7e6; value 2 = all N (d+1) lookups one by one, the checker of the
+ * event form, 250 ms there) and patch the built structure so that every MVM equals the reference's filter(): the splat
  * contributions the reference loses are dropped, keys its blur-time lookups cannot find read as absent.  Plain
  * single-process builds only (ignored by plx_build_local / plx_build_merge).  h_out6 = {replayed (0/1), entries the
  * reference's table holds (= plx_num_vertices when nothing was replayed or nothing went wrong), dropped (point, corner)
@@ -157,6 +159,17 @@ int plx_order(const plx_lattice *lat);             /* (ntaps-1)/2               
  * work per MVM.  A CG solve permutes its right-hand side once, iterates in
  * lattice order and permutes the solution back once. */
 int plx_set_row_order(plx_lattice *lat, int lattice_order);
+
+/* Warm start of the point order (round 6).  on != 0: the NEXT plx_build on this lattice keeps the lattice order of its
+ * points from the previous build instead of computing it (coordinate ranges + read-back, sort keys, four radix passes:
+ * 0.15 ms of a 1.8 ms build at N = 1e6, d = 8).  For a caller who KNOWS that the positions are the previous build's,
+ * re-scaled a little -- a GP training loop whose lengthscale moved: the order is a locality device only (which points sit
+ * next to each other in memory), no vertex, weight or neighbour depends on it, so the result is the cold build's up to
+ * the order of the fp32 sums inside a vertex row; an order computed for other positions would merely be a slow one.
+ * One shot (cleared by the build); ignored unless the row count, dimension and shard are those of the order at hand.
+ * plx_order_age: builds since the order was computed from the positions themselves (0 = by the last build, -1 = none). */
+int plx_set_reuse_order(plx_lattice *lat, int on);
+int plx_order_age(const plx_lattice *lat);
 
 /* Floats per vertex row of a values buffer for vd value columns: 1 for vd = 1,
  * otherwise vd rounded up to a multiple of 4 (rows are whole 16-byte vectors;
@@ -253,6 +266,9 @@ int plx_apply_affine(plx_lattice *lat, const float *d_src, int vd, float *d_out,
 int64_t plx_affine_dot_work_floats(const plx_lattice *lat, int vd);
 int plx_apply_affine_dot(plx_lattice *lat, const float *d_src, int vd, float *d_out, const float *d_scale_shift,
                          float *d_dot, float *d_work, void *stream);
+/* d_dot may be NULL: the slice kernel's per-tile partial sums are then left in d_work -- plx_affine_dot_tiles(lat, vd) rows
+ * of plx_values_stride(vd) floats -- for plx_cg_step_update_fused, which adds them up itself (one launch less). */
+int plx_affine_dot_tiles(const plx_lattice *lat, int vd);
 /* One batched-CG iteration's vector work with the coefficients formed on the device (all small arrays are float [vd],
  * `active` holds 1.0 / 0.0):
  *   plx_cg_step_update:    alpha = active ? rs / max(pAp, tiny) : 0;  X += alpha P;  R -= alpha AP;  rs_new = |R|^2
@@ -261,6 +277,21 @@ int plx_apply_affine_dot(plx_lattice *lat, const float *d_src, int vd, float *d_
 int plx_cg_step_update(float *d_x, float *d_r, const float *d_p, const float *d_ap, const float *d_rs, const float *d_pap,
                        const float *d_active, int64_t n, int vd, float *d_rs_new, float *d_alpha, float *d_work,
                        void *stream);
+/* The same iteration without its two stand-alone reductions (round 6; vd = 4, 8, 12 or 16 -- rows of whole 16-byte chunks,
+ * the widths solvers.khat_solve pads to; every pointer 16-byte aligned):
+ *   plx_cg_step_update_fused     pAp comes as the PARTIAL sums plx_apply_affine_dot(d_dot = NULL) left behind (d_pap_partial:
+ *                                ntiles = plx_affine_dot_tiles rows of vd floats); every workgroup adds them up itself, in
+ *                                a fixed order.  |R|^2 leaves as partial sums in d_work (plx_cg_fused_work_floats(vd) floats).
+ *   plx_cg_step_direction_fused  adds those up (every workgroup, fixed order), stores rs_new (d_rs_new != d_rs), beta and
+ *                                active_out, and updates P.
+ * Same arithmetic as the pair above except for the association of the column sums; deterministic. */
+int64_t plx_cg_fused_work_floats(int vd);
+int plx_cg_step_update_fused(float *d_x, float *d_r, const float *d_p, const float *d_ap, const float *d_rs,
+                             const float *d_pap_partial, int ntiles, const float *d_active, int64_t n, int vd,
+                             float *d_alpha, float *d_work, void *stream);
+int plx_cg_step_direction_fused(float *d_p, const float *d_r, const float *d_work, const float *d_rs, const float *d_active,
+                                const float *d_b_norm, float tol, int64_t n, int vd, float *d_rs_new, float *d_beta,
+                                float *d_active_out, void *stream);
 int plx_cg_step_direction(float *d_p, const float *d_r, const float *d_rs_new, const float *d_rs, const float *d_active,
                           const float *d_b_norm, float tol, int64_t n, int vd, float *d_beta, float *d_active_out,
                           void *stream);
@@ -377,9 +408,13 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  *   slot-occupancy bitmap before the hash table when m >= 2^22; 0 never, 2 always), "splat_first" (1 = single-column splat by
  *   first-touch stores + a short extras list when m >= 0.9 nnz; 0 never, 2 whenever representable, 3 = 2 with scattered
  *   stores), "perm_rows" (1 = multi-column row permutations by 16-byte chunks / LDS-transposed whole-line stores; 0 = the
- *   per-float forms), "reference_growth" (0; 1 = replay the reference CPU path's table-growth quirk: plx_reference_growth_info),
- *   and the round-5 build switches "hash_v" (2), "table_fp" (1), "nbr_sliced" (1), "nbr_seed" (1), "flag_own" (1),
- *   "assign_evid" (1), "insert_v" (2), "insert_xcd" (2), "order_sample" (8), "embed_vrange" (0), "blk_sort" (15): DESIGN.md 2.
+ *   per-float forms), "reference_growth" (0; 1 = replay the reference CPU path's table-growth quirk: plx_reference_growth_info; 2 = the same by
+ *   running every lookup, the checker of 1), "contract_v" (1 = the fused backward's slice + contraction with the corner count
+ *   compiled in; 0 = the run-time form),
+ *   and the round-5 build switches "nbr_sliced" (1), "nbr_seed" (1), "assign_evid" (1), "insert_xcd" (2), "order_sample" (8),
+ *   "embed_vrange" (0), "blk_sort" (15): DESIGN.md 2.  (Round 6 removed "hash_v", "table_fp", "flag_own" and "insert_v" with the
+ *   measured-loser code paths behind them: the linear hash, fingerprints, own-mark flags and the point-per-thread insert
+ *   are what every build uses.)
  * The diagnostic ablations "splat_ablate" / "blur_ablate" / "block_ablate" exist only in libplx_diag.so (make diag).
  * Unknown keys return PLX_ERR_INVALID. */
 int plx_tune(const char *key, int value);

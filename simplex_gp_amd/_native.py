@@ -18,7 +18,7 @@ ARRAY_KEYS, ARRAY_ENTRY_VERTEX, ARRAY_ENTRY_WEIGHT, ARRAY_NEIGHBORS = 0, 1, 2, 3
 ARRAY_ROW_PTR, ARRAY_CSR_POINT, ARRAY_CSR_WEIGHT, ARRAY_POINT_PERM = 4, 5, 6, 7
 MAX_DIM, MAX_ORDER = 32, 8
 FACTOR_F32, FACTOR_F16 = 0, 1
-ABI_VERSION = (0, 6)      # (major, minor) of plx_version() the signatures below belong to
+ABI_VERSION = (0, 7)      # (major, minor) of plx_version() the signatures below belong to
 
 
 class PlxError(RuntimeError):
@@ -65,6 +65,12 @@ _SIGNATURES = {
     "plx_apply_affine": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp]),
     "plx_affine_dot_work_floats": (_i64, [_vp, _i32]),
     "plx_apply_affine_dot": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "plx_set_reuse_order": (_i32, [_vp, _i32]),
+    "plx_order_age": (_i32, [_vp]),
+    "plx_affine_dot_tiles": (_i32, [_vp, _i32]),
+    "plx_cg_fused_work_floats": (_i64, [_i32]),
+    "plx_cg_step_update_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "plx_cg_step_direction_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp, _vp]),
     "plx_cg_step_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "plx_cg_step_direction": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),

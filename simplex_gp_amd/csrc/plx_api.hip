@@ -77,7 +77,7 @@ void release(DevBuf &b)
 
 static std::vector<DevBuf *> all_bufs(plx_lattice *L)
 {
-    return {&L->ekeys, &L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
+    return {&L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
             &L->sort_keys_in, &L->slotmap, &L->nibmap, &L->prank, &L->vaxis, &L->vs0, &L->vowner, &L->ew_splat, &L->replay_vat, &L->replay_list, &L->replay_invisible, &L->replay_keys, &L->oh_pos, &L->oh_list, &L->oh_cnt, &L->ex_vid, &L->ex_pt, &L->ex_w, &L->ex_keys, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->csr_vid, &L->row_ptr,
             &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
@@ -119,7 +119,7 @@ const char *plx_strerror(int code)
 const char *plx_last_error(void) { return g_err; }
 
 /* minor = the round that last extended the C ABI */
-const char *plx_version(void) { return "libplx 0.6.0 gfx950"; }
+const char *plx_version(void) { return "libplx 0.7.0 gfx950"; }
 
 int plx_create(int device, plx_lattice **out)
 {
@@ -293,6 +293,15 @@ int plx_set_row_order(plx_lattice *L, int lattice_order)
     return PLX_OK;
 }
 
+int plx_set_reuse_order(plx_lattice *L, int on)
+{
+    if (!L) { set_error("plx_set_reuse_order: NULL lattice"); return PLX_ERR_INVALID; }
+    L->reuse_order = on != 0;
+    return PLX_OK;
+}
+
+int plx_order_age(const plx_lattice *L) { return L ? (L->order_n > 0 ? L->order_age : -1) : -1; }
+
 int plx_values_stride(int vd) { return vd >= 1 ? values_stride(vd) : -1; }
 
 int64_t plx_device_bytes(const plx_lattice *L)
@@ -398,7 +407,7 @@ int plx_apply_affine_dot(plx_lattice *L, const float *d_src, int vd, float *d_ou
                          float *d_dot, float *d_work, void *stream)
 {
     EntryScope sc(L, stream);
-    if (!d_scale_shift || !d_dot || !d_work) { set_error("plx_apply_affine_dot: NULL argument"); return PLX_ERR_INVALID; }
+    if (!d_scale_shift || !d_work) { set_error("plx_apply_affine_dot: NULL argument"); return PLX_ERR_INVALID; }
     if (d_src == d_out) { set_error("plx_apply_affine_dot: d_out must not alias d_src"); return PLX_ERR_INVALID; }
     if (vd < 2 || vd > 256) { set_error("plx_apply_affine_dot: vd = %d outside 2..256 (use plx_apply_affine + plx_coldot)", vd); return PLX_ERR_INVALID; }
     PLX_TRY(check_apply(L, d_src, d_out, vd, "plx_apply_affine_dot"));
@@ -413,7 +422,14 @@ int plx_apply_affine_dot(plx_lattice *L, const float *d_src, int vd, float *d_ou
     int in_b = 0;
     PLX_TRY(blur_impl(L, L->val_a.as<float>(), L->val_b.as<float>(), vd, &in_b, s));
     PLX_TRY(slice_impl(L, in_b ? L->val_b.as<float>() : L->val_a.as<float>(), vd, d_out, s, d_scale_shift, d_src, d_work));
+    if (!d_dot) return PLX_OK;          // the per-tile partial sums stay in d_work (plx_cg_step_update_fused adds them up itself)
     return coldot_final(d_work, affine_dot_tiles(L, vd), vdp, d_dot, s);
+}
+
+int plx_affine_dot_tiles(const plx_lattice *L, int vd)
+{
+    if (!L || !L->built || vd < 2 || vd > 256) return -1;
+    return affine_dot_tiles(L, vd);
 }
 
 static int apply_common(plx_lattice *L, const float *d_src, int vd, float *d_out, const float *d_affine, void *stream,

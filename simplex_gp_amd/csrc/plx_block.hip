@@ -87,27 +87,6 @@ __global__ __launch_bounds__(kBlock) void blk_scan_kernel(int *__restrict__ rows
     }
 }
 
-__global__ __launch_bounds__(kBlock) void blk_iota_kernel(const int *__restrict__ brow_vid, int nrows,
-                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
-{
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j < nrows) { keys[j] = (uint32_t)brow_vid[j]; vals[j] = (uint32_t)j; }
-}
-
-// s2_ptr[u] = first k with skeys[k] >= u: the block rows of vertex u are s2_idx[s2_ptr[u] .. s2_ptr[u+1])
-__global__ __launch_bounds__(kBlock) void blk_rowptr_kernel(const uint32_t *__restrict__ skeys, int nrows, int m,
-                                                            int *__restrict__ s2_ptr)
-{
-    const int u = blockIdx.x * kBlock + threadIdx.x;
-    if (u > m) return;
-    int lo = 0, hi = nrows;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (skeys[mid] < (uint32_t)u) lo = mid + 1; else hi = mid;
-    }
-    s2_ptr[u] = lo;
-}
-
 // ----------------------------------------------------------------------------
 // splat, stage 1: one workgroup per block.
 
@@ -306,13 +285,27 @@ __global__ __launch_bounds__(kBlock) void splat_combine_kernel(const int *__rest
     }
 }
 
-// bit 31 of s2_idx = last block row of its vertex; s2_wave[w] = first entry >= w * kCombineRun that starts a vertex row,
-// s2_wave_v[w] = the vertex of that row
-__global__ __launch_bounds__(kBlock) void blk_s2_finish_kernel(int *__restrict__ s2_idx, const int *__restrict__ s2_vid,
-                                                               const int *__restrict__ s2_ptr, int nrows, int nwaves, int m,
+// The three small tables over the vertex-sorted block rows in ONE launch (round 6: they were blk_rowptr_kernel and
+// blk_s2_finish_kernel, 9 + 7 us behind a launch boundary each):
+//   s2_ptr[u] = first k with skeys[k] >= u: the block rows of vertex u are s2_idx[s2_ptr[u] .. s2_ptr[u+1])   (u <= m)
+//   bit 31 of s2_idx[k] = last block row of its vertex                                                      (k < nrows)
+//   s2_wave[w] = first entry >= w * kCombineRun that starts a vertex row, s2_wave_v[w] = the vertex of that row (w <= nwaves)
+__device__ __forceinline__ int s2_lower_bound(const uint32_t *__restrict__ skeys, int nrows, uint32_t u)
+{
+    int lo = 0, hi = nrows;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (skeys[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void blk_s2_tables_kernel(int *__restrict__ s2_idx, const uint32_t *__restrict__ s2_vid,
+                                                               int *__restrict__ s2_ptr, int nrows, int nwaves, int m,
                                                                int *__restrict__ s2_wave, int *__restrict__ s2_wave_v)
 {
     const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k <= m) s2_ptr[k] = s2_lower_bound(s2_vid, nrows, (uint32_t)k);
     if (k < nrows) {
         const bool end = (k + 1 == nrows) || s2_vid[k + 1] != s2_vid[k];
         if (end) s2_idx[k] |= (int)0x80000000u;
@@ -320,9 +313,9 @@ __global__ __launch_bounds__(kBlock) void blk_s2_finish_kernel(int *__restrict__
     if (k <= nwaves) {
         int e = k * kCombineRun;
         if (e >= nrows) e = nrows;
-        else if (e > 0 && s2_vid[e - 1] == s2_vid[e]) e = s2_ptr[s2_vid[e] + 1];   // inside a row: it belongs to the wave before
+        else if (e > 0 && s2_vid[e - 1] == s2_vid[e]) e = s2_lower_bound(s2_vid, nrows, s2_vid[e] + 1u);   // inside a row: it belongs to the wave before
         s2_wave[k] = e;
-        s2_wave_v[k] = e < nrows ? s2_vid[e] : m;
+        s2_wave_v[k] = e < nrows ? (int)s2_vid[e] : m;
     }
 }
 
@@ -702,17 +695,20 @@ int ensure_s2(plx_lattice *L, hipStream_t stream)
     PLX_TRY(ensure(L->sort_temp, radix_temp_bytes(nrows)));
     PLX_TRY(ensure(L->sort_keys_in, (size_t)nrows * 4 + 64));
     PLX_TRY(ensure(L->sort_vals_in, (size_t)nrows * 4 + 64));
-    blk_iota_kernel<<<ceil_div(nrows, kBlock), kBlock, 0, stream>>>(L->brow_vid.as<int>(), (int)nrows,
-                                                                    L->sort_keys_in.as<uint32_t>(),
-                                                                    L->sort_vals_in.as<uint32_t>());
+    // the block rows sorted by vertex: the first pass reads brow_vid itself (which stays as it is: the block kernels
+    // gather through it) with the row numbers implied -- no copy pass in front of the sort
     int second = 0;
     PLX_TRY(radix_sort_pairs32(L->sort_temp.p, L->sort_keys_in.as<uint32_t>(), L->s2_vid.as<uint32_t>(),
-                               L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, &second, stream));
+                               L->sort_vals_in.as<uint32_t>(), L->s2_idx.as<uint32_t>(), nrows, vbits, &second, stream,
+                               nrows > 1 ? L->brow_vid.as<uint32_t>() : nullptr));
+    if (nrows <= 1) {      // (nothing to sort: one row, or none)
+        PLX_HIP_TRY(hipMemcpyAsync(L->s2_vid.p, L->brow_vid.p, (size_t)nrows * 4, hipMemcpyDeviceToDevice, stream));
+        PLX_HIP_TRY(hipMemsetAsync(L->s2_idx.p, 0, (size_t)nrows * 4 + 4, stream));
+        second = 1;
+    }
     if (!second) { std::swap(L->sort_keys_in, L->s2_vid); std::swap(L->sort_vals_in, L->s2_idx); }
-    blk_rowptr_kernel<<<ceil_div(m + 1, kBlock), kBlock, 0, stream>>>(L->s2_vid.as<uint32_t>(), (int)nrows, (int)m,
-                                                                      L->s2_ptr.as<int>());
-    blk_s2_finish_kernel<<<ceil_div(std::max<int64_t>(nrows, L->n_s2waves + 1), kBlock), kBlock, 0, stream>>>(
-        L->s2_idx.as<int>(), L->s2_vid.as<int>(), L->s2_ptr.as<int>(), (int)nrows, (int)L->n_s2waves, (int)m,
+    blk_s2_tables_kernel<<<ceil_div(std::max<int64_t>(std::max<int64_t>(nrows, m + 1), L->n_s2waves + 1), kBlock), kBlock, 0, stream>>>(
+        L->s2_idx.as<int>(), L->s2_vid.as<uint32_t>(), L->s2_ptr.as<int>(), (int)nrows, (int)L->n_s2waves, (int)m,
         L->s2_wave.as<int>(), L->s2_wave_v.as<int>());
     PLX_HIP_TRY(hipGetLastError());
     L->s2_ready = true;

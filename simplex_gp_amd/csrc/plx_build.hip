@@ -16,7 +16,7 @@
 //            what makes the splat / slice / blur gathers hit the same cache lines
 //            (measured: warm MVM 159 -> 118 us at N=1e6, d=8)
 //   embed    per point: elevate, round, rank, barycentric (registers only)
-//            -> packed int16 keys ekeys[r][p][DW], weights ew[r][p]
+//            -> the 32-byte point record prec[p] (vertex coordinates + ranks: any corner key follows), weights ew[r][p]
 //   insert   per corner: open addressing on a uint32 table whose slot value is
 //            the SMALLEST reference entry index e = p*(d+1)+r seen with that
 //            key (CAS to claim, atomicMin to lower)  -> eslot[r][p]
@@ -48,26 +48,14 @@ namespace plx {
 // ----------------------------------------------------------------------------
 // small device helpers
 
-__device__ __forceinline__ uint32_t mix_hash(const uint32_t *k, int dw)
-{
-    uint64_t h = 0x9E3779B97F4A7C15ull;
-    for (int j = 0; j < dw; ++j) {
-        h ^= k[j];
-        h *= 0xff51afd7ed558ccdull;
-        h ^= h >> 32;
-    }
-    h *= 0xc4ceb9fe1a85ec53ull;
-    h ^= h >> 29;
-    return (uint32_t)h;
-}
-
-// ---- hash_v = 2 (round 5): a hash that is LINEAR in the key coordinates before one multiplicative mix.
+// ---- the table hash (round 5; the 64-bit mix of the packed key words it replaced was removed in round 6): LINEAR in the
+// key coordinates before one multiplicative mix.
 //   s(key) = sum_c key[c] * kHashMul[c]  (mod 2^32);   slot bits = top 3 bits of s, then the top bits of (s ^ (s >> 15)) * kHashMix
 // A blur neighbour's key is the vertex's own plus a constant vector (h:541-542), so its s is the vertex's s plus a constant
 // per (axis, tap): one add instead of re-hashing 16 bytes -- which is what lets every XCD look at every lookup and serve
 // only those whose slot falls into its own eighth of the table (neighbor_sliced_kernel): the owning eighth is (s + delta) >> 29.
 // Fingerprint: the top byte of a second product of the same s ^ (s >> 15).  Which slot a key lands in is internal: vertex ids
-// come from first touch (h:73-79), so the structure is the same bit for bit under either hash
+// come from first touch (h:73-79), so the structure does not depend on the hash
 // (tests/test_hip_parity.py::test_structure_bit_exact_round5_build_paths).
 #define PLX_HASH_MULS                                                                                          \
     0x9E3779B1u, 0x85EBCA77u, 0xC2B2AE3Du, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u,    \
@@ -107,17 +95,17 @@ __device__ __forceinline__ uint32_t lin_hash_packed(const uint32_t (&kw)[(D + 1)
     return s;
 }
 
-// what the table kernels need to know about the hash in force: slot = hv2 ? x >> shift : x & mask
-struct HashSel { int v2; uint32_t mask; int shift; };
+// what the table kernels need to know about the table: slot = x >> shift (the top log2(cap) bits), probing wraps with mask
+struct HashSel { uint32_t mask; int shift; };
 
 template <int D>
-__device__ __forceinline__ uint32_t key_hash(const uint32_t (&kw)[(D + 1) / 2], const HashSel &hs)
+__device__ __forceinline__ uint32_t key_hash(const uint32_t (&kw)[(D + 1) / 2], const HashSel &)
 {
-    return hs.v2 ? lin_slotbits(lin_hash_packed<D>(kw)) : mix_hash(kw, (D + 1) / 2);
+    return lin_slotbits(lin_hash_packed<D>(kw));
 }
-__device__ __forceinline__ uint32_t hash_slot(uint32_t x, const HashSel &hs) { return hs.v2 ? (x >> hs.shift) : (x & hs.mask); }
+__device__ __forceinline__ uint32_t hash_slot(uint32_t x, const HashSel &hs) { return x >> hs.shift; }
 
-// table word of a numbered vertex: the id, and (fp_on: hash_v = 2, m < 2^24 - 1) eight fingerprint bits of the key above it.
+// table word of a numbered vertex: the id, and (fp_on: m < 2^24 - 1) eight fingerprint bits of the key above it.
 // An id field of all ones never occurs, so kEmpty stays distinguishable.
 constexpr int kFpShift = 24;
 template <int D>
@@ -418,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void sortkey_kernel(const float *__restrict
 // The point record (round 5): what the embedding knows about one point in a few words -- the first d coordinates of its
 // (fixed-up) nearest zero-colour vertex as packed int16 (DW words) and the rank of every coordinate as one byte each
 // ((d+2)/4... words) -- from which the key of any of its d+1 corners follows with one select and one add per coordinate
-// (h:468-471).  It replaces ekeys, the d+1 packed corner keys per point (144 bytes per point at d = 8 against 32): the
+// (h:468-471).  It replaced the d+1 packed corner keys per point of rounds 1-4 (144 bytes per point at d = 8 against 32): the
 // embedding wrote 172 MB that the insert fetched back (522 MB by the counters) only to hash every key once.
 template <int D> struct Rec {
     static constexpr int D1 = D + 1, DW = (D + 1) / 2, WR = (D1 + 3) / 4;
@@ -460,12 +448,10 @@ __device__ __forceinline__ void rec_key(const int (&gr)[D], const int (&rk)[D + 
 template <int D>
 __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__ x,
                                                        const uint32_t *__restrict__ perm, int n, ScaleArgs sf,
-                                                       uint32_t *__restrict__ ekeys,
                                                        float *__restrict__ ew, int *__restrict__ counters,
                                                        uint32_t *__restrict__ prec, int *__restrict__ vrange)
 {
     constexpr int D1 = D + 1;
-    constexpr int DW = (D + 1) / 2;
     __shared__ int vred[2 * kMaxOrderCoords];
     const bool valid = blockIdx.x * kBlock + threadIdx.x < n;
     const int p = valid ? blockIdx.x * kBlock + threadIdx.x : n - 1;      // (a padding thread repeats the last point and stores nothing)
@@ -600,138 +586,32 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const float *__restrict__
             reinterpret_cast<uint4 *>(prec + (size_t)p * R::W)[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
     }
 
-    // h:468-471: corner r has key greedy + canonical[r][rank]
+    // (the corner keys of h:468-471 -- greedy + canonical[r][rank] -- are rebuilt from the record by whoever needs one: rec_key)
 #pragma unroll
-    for (int r = 0; r < D1; ++r) {
-        uint32_t kw[DW];
-#pragma unroll
-        for (int j = 0; j < DW; ++j) kw[j] = 0;
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            int c = gr[i] + ((rk[i] <= D - r) ? r : (r - D1));
-            kw[i >> 1] |= ((uint32_t)c & 0xFFFFu) << ((i & 1) * 16);
-        }
-        const size_t idx = (size_t)r * n + p;
-        if (ekeys) store_key<DW>(ekeys, idx, kw);
-        ew[idx] = bary[r];
-    }
+    for (int r = 0; r < D1; ++r) ew[(size_t)r * n + p] = bary[r];
 }
 
 // ----------------------------------------------------------------------------
-// insert: one thread per simplex corner.  Slot value = smallest reference entry
-// index e = p*(d+1)+r among the corners that share the slot's key.  Invariant:
-// every value ever stored in a slot belongs to a corner with the same key, so a
-// stale plain load can only cost an extra atomic, never a wrong match.
-// (Round 3 tried a workgroup form: one workgroup per 256 consecutive points de-duplicates its 2,304 corners in an LDS
-// hash table -- ~700 distinct keys at N = 1e6, d = 8 -- and only the distinct keys probe the global table, dealt evenly
-// to the threads.  Structure bit-exact, but N = 1e6 203 -> 194 us, N = 4e6 667 -> 573 us, and the fine regime (every
-// key distinct) 428 -> 591 us: the kernel is bound by the latency of its dependent random accesses -- a wave lives
-// ~17 us for four of them -- and the LDS stage adds a dependent key compare per corner while removing only the cheap
-// duplicate probes that the plane-adjacent dispatch order below already serves from the L2s.  Dropped.)
+// insert.  Slot value = smallest reference entry index e = p*(d+1)+r among the corners that share the slot's key.
+// Invariant: every value ever stored in a slot belongs to a corner with the same key, so a stale plain load can only cost
+// an extra atomic, never a wrong match.  First-touch marks (flag_own): a slot's value only ever decreases, and every
+// value that is replaced is replaced by exactly one atomicMin, whose return value names it.  "own" = this corner put its
+// index into the slot (claimed it empty, or lowered it: bit 31 of eslot); "displaced" = a later atomicMin replaced it (disp).
+// The first touch of a vertex is the one corner that owns and was never displaced: own & ~displaced, without reading the
+// table again (flag_own_kernel).
+// (Rounds 1-5 also carried a one-corner-per-thread form over packed corner keys (144 bytes per point at d = 8): bound by the
+// latency of its dependent accesses (table word -> owner's key -> atomic -> atomic) times the waves the chip holds, 15 %
+// slower than the form below on every lattice measured; removed in round 6.  So was a workgroup form
+// that de-duplicated a block's corners in LDS first: 203 -> 194 us at N = 1e6, 428 -> 591 us in the fine regime.)
 
-template <int D>
-__global__ __launch_bounds__(kBlock) void insert_kernel(const uint32_t *__restrict__ ekeys, int n,
-                                                        uint32_t *__restrict__ table, HashSel hs,
-                                                        uint32_t *__restrict__ eslot, int dedupe, int plane_fast,
-                                                        uint32_t *__restrict__ disp)
-{
-    constexpr int D1 = D + 1;
-    constexpr int DW = (D + 1) / 2;
-    // plane_fast: the d+1 corner planes of one run of 256 points are adjacent in dispatch order, so that the workgroups
-    // run roughly in entry order e = p (d+1) + r and a later corner usually finds the smaller entry already in place
-    const int p = (plane_fast ? blockIdx.y : blockIdx.x) * kBlock + threadIdx.x;
-    const int r = plane_fast ? blockIdx.x : blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const bool valid = p < n;
-    const size_t idx = (size_t)r * n + (valid ? p : 0);
-    const uint32_t e = (uint32_t)p * D1 + r;
-
-    uint32_t k[DW];
-    load_key<DW>(ekeys, idx, k);
-
-    // Points are in lattice order, so the lanes of a wave (64 consecutive points, same corner index r) carry few distinct
-    // keys: 0.47 per lane at N = 1e6, d = 8 (0.85 if only runs of equal NEIGHBOURING lanes are merged, the round-1 form:
-    // dedupe = 1).  dedupe = 2: every lane finds the lowest lane of the wave with its key -- candidates by 10 bits of the
-    // key hash (one ballot per bit), confirmed by comparing the key itself with that lane's -- and only those leaders
-    // probe the table; a leader has the smallest entry index of its group.  A lane whose candidate turns out to hold
-    // another key (a hash collision inside the wave, < 1 %) simply probes for itself.
-    const uint32_t mask = hs.mask;
-    const uint32_t hk = key_hash<D>(k, hs);
-    int leader = lane;
-    if (dedupe == 2) {
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 10; ++b) {
-            const bool bit = (hk >> (22 + b)) & 1u;
-            const unsigned long long mb = __ballot(bit);
-            peers &= bit ? mb : ~mb;
-        }
-        const int cand = valid ? __ffsll((long long)peers) - 1 : lane;
-        bool same = true;
-#pragma unroll
-        for (int j = 0; j < DW; ++j) same = same && (__shfl(k[j], cand) == k[j]);
-        leader = same ? cand : lane;
-    } else if (dedupe) {
-        bool same_as_prev = lane > 0 && valid;
-#pragma unroll
-        for (int j = 0; j < DW; ++j) {
-            const uint32_t prev = __shfl_up(k[j], 1);
-            same_as_prev = same_as_prev && (prev == k[j]);
-        }
-        // slot of the nearest leader at or below this lane
-        const unsigned long long heads = __ballot(valid && !same_as_prev);
-        const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-        leader = below ? 63 - __clzll(below) : lane;
-    }
-
-    // disp != nullptr (flag_own): the slot's value only ever decreases, and every value that is replaced is replaced by
-    // exactly one atomicMin, whose return value names it.  "own" = this corner put its index into the slot (claimed it
-    // empty, or lowered it); "displaced" = a later atomicMin replaced it.  The first touch of a vertex is the one corner
-    // that owns and was never displaced: own & ~displaced, without reading the table again (flag_own_kernel).
-    uint32_t h = 0;
-    bool own = false;
-    if (valid && leader == lane) {
-        h = hash_slot(hk, hs);
-        for (;;) {
-            uint32_t o = table[h];
-            if (o == kEmpty) {
-                o = atomicCAS(&table[h], kEmpty, e);
-                if (o == kEmpty) { own = true; break; }   // claimed an empty slot
-            }
-            if (o == e) break;
-            uint32_t ko[DW];
-            const uint32_t po = o / D1, ro = o - po * D1;
-            load_key<DW>(ekeys, (size_t)ro * n + po, ko);
-            if (key_equal<DW>(k, ko)) {
-                if (e < o) {
-                    if (disp) {
-                        const uint32_t old = atomicMin(&table[h], e);
-                        if (old > e) {
-                            own = true;
-                            const uint32_t pd = old / D1, rd = old - pd * D1;
-                            atomicOr(&disp[2 * (size_t)pd + (rd >> 5)], 1u << (rd & 31));
-                        }
-                    } else {
-                        atomicMin(&table[h], e);
-                    }
-                }
-                break;
-            }
-            h = (h + 1) & mask;
-        }
-    }
-    if (dedupe) h = __shfl(h, leader);
-    if (valid) eslot[idx] = (disp && own) ? (h | 0x80000000u) : h;
-}
-
-// insert_v = 2 (round 5): one thread per POINT, keys from the point records, a fast path and a parked slow path.
-// The one-corner-per-thread kernel above is bound by the latency of its dependent accesses (table word -> owner's key ->
+// One thread per POINT (round 5), keys from the point records, a fast path and a parked slow path.
+// A one-corner-per-thread kernel is bound by the latency of its dependent accesses (table word -> owner's key ->
 // atomic -> atomic) times the waves the chip holds: a wave lives until its SLOWEST lane is through, and with 64 lanes there
 // nearly always is one that has to claim an empty slot or lower an index (two or three dependent atomics, ~10 us), while on
 // a lattice whose corners share vertices 90 % of the lanes only need to see that their key is already in the table under a
 // smaller index -- two plain loads.  Here a thread rebuilds its point's corner keys in registers (one select + add per
 // coordinate; no 144-byte key block per point is written or read), the lanes holding equal keys of the same corner index
-// elect a leader exactly as above, and insert_chains(d) corners go through the FAST path together: table word, owner's
+// elect a leader by ballots over 10 bits of the key hash (confirmed by comparing the key itself), and insert_chains(d) corners go through the FAST path together: table word, owner's
 // record, compare.  Whatever needs an atomic or another probe is PARKED in an LDS queue (leader, its follower lanes, the
 // slot reached) and the workgroup works the queue off at the end with dense lanes; a full queue (lattices where every
 // corner claims a slot) sends the rest through the same loop on the spot.  Same table, same first-touch marks.
@@ -1057,7 +937,6 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restrict__ flagmask,
                                                         const int *__restrict__ blockoff,
                                                         const uint32_t *__restrict__ eslot,
-                                                        const uint32_t *__restrict__ ekeys,
                                                         const uint32_t *__restrict__ prec, int n,
                                                         uint32_t *__restrict__ table,
                                                         uint32_t *__restrict__ vkeys, uint32_t *__restrict__ vslot, int fp_on,
@@ -1082,7 +961,7 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
     int id = base + block_exclusive_scan(__popc(bits) + __popc(bits_hi), &total);
     if (p < n && (bits | bits_hi) != 0) {
         int gr[D], rk[D1];
-        if (prec) rec_load<D>(prec, (size_t)p, gr, rk);
+        rec_load<D>(prec, (size_t)p, gr, rk);
 #pragma unroll
         for (int r = 0; r < D1; ++r) {
             bool first = (r < 32) ? ((bits >> r) & 1u) : ((bits_hi >> (r - 32)) & 1u);
@@ -1090,8 +969,7 @@ __global__ __launch_bounds__(kBlock) void assign_kernel(const uint32_t *__restri
                 const size_t idx = (size_t)r * n + p;
                 const uint32_t slot = eslot[idx] & 0x7FFFFFFFu;
                 uint32_t k[DW];
-                if (prec) rec_key<D>(gr, rk, r, k);
-                else load_key<DW>(ekeys, idx, k);
+                rec_key<D>(gr, rk, r, k);
                 table[slot] = table_word<D>((uint32_t)id, k, fp_on);
                 store_key<DW>(vkeys, (size_t)id, k);
                 if (evid) evid[idx] = id;            // the numbering is final (no renumbering follows): assign_evid
@@ -1935,7 +1813,6 @@ static int renumber_vertices(plx_lattice *L, int64_t corners, hipStream_t stream
 static HashSel hash_sel(const plx_lattice *L)
 {
     HashSel hs;
-    hs.v2 = L->table_hash == 2 ? 1 : 0;
     hs.mask = L->table_mask;
     hs.shift = 32 - L->table_bits;
     return hs;
@@ -1947,14 +1824,13 @@ static void set_table(plx_lattice *L, uint64_t cap)
     L->table_mask = (uint32_t)(cap - 1);
     L->table_bits = 0;
     while ((1ull << L->table_bits) < cap) ++L->table_bits;
-    L->table_hash = g_hash_v == 2 ? 2 : 1;
     L->table_idmask = 0xFFFFFFFFu;
 }
 
 // fingerprints ride in the table words of numbered vertices when the ids leave the top byte free
 static int table_fp_on(plx_lattice *L, int64_t m)
 {
-    const int on = (L->table_hash == 2 && g_table_fp != 0 && m < (1ll << kFpShift) - 1) ? 1 : 0;
+    const int on = m < (1ll << kFpShift) - 1 ? 1 : 0;
     L->table_idmask = on ? ((1u << kFpShift) - 1u) : 0xFFFFFFFFu;
     return on;
 }
@@ -2003,15 +1879,12 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     PLX_TRY(ensure(L->sortkey_out, (size_t)n * 8));
     PLX_TRY(ensure(L->sort_temp, radix_temp_bytes(n)));
 
-    const bool point_insert = g_insert_v == 2;
-    if (!point_insert) PLX_TRY(ensure(L->ekeys, (size_t)E * DW * 4));
     PLX_TRY(ensure(L->ew, (size_t)E * 4));
     PLX_TRY(ensure(L->eslot, (size_t)E * 4));
     PLX_TRY(ensure(L->evid, (size_t)E * 4));
     PLX_TRY(ensure(L->flagmask, (size_t)n * 8));
-    const bool want_rank = g_hash_v == 2 && g_nbr_sliced != 0 && g_nbr_seed != 0;      // the neighbour seeding reads the ranks
-    const bool want_rec = want_rank || point_insert;
-    if (want_rec) PLX_TRY(ensure(L->prank, (size_t)n * Rec<D>::W * 4 + 16));
+    const bool want_rank = g_nbr_seed != 0;      // the neighbour seeding reads the ranks after the build
+    PLX_TRY(ensure(L->prank, (size_t)n * Rec<D>::W * 4 + 16));      // the point records: insert and numbering rebuild keys from them
     L->prank_valid = false;
     PLX_TRY(ensure(L->blockcnt, (size_t)(nblocks + 1) * 4));
     PLX_TRY(ensure(L->table, (size_t)cap * 4));
@@ -2021,7 +1894,15 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     PLX_HIP_TRY(hipMemsetAsync(L->table.p, 0xFF, (size_t)cap * 4, stream));
 
     mark();
-    if (g_sort_points) {
+    // plx_set_reuse_order: the positions are the previous build's, re-scaled (a lengthscale that moved): the point order --
+    // a locality device, nothing in the structure depends on it -- is kept, and the range pass, its read-back, the key pass and
+    // the radix passes over the points are skipped.  Only for the same rows on the same shard; one shot.
+    const bool keep_order = L->reuse_order && g_sort_points && L->order_n == L->n && L->order_d == D &&
+                            L->order_shard == L->shard_index && L->order_shards == L->n_shards;
+    L->reuse_order = false;
+    if (keep_order) {
+        ++L->order_age;
+    } else if (g_sort_points) {
         int key_bits;
         if (g_order_compact) {
             // range of every rounded coordinate -> exactly the key bits it needs (counters[32 ..] preset to a very negative int)
@@ -2046,31 +1927,26 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
         PLX_TRY(radix_sort_pairs64(L->sort_temp.p, L->sortkey_in.as<uint64_t>(), L->sortkey_out.as<uint64_t>(),
                                    L->iota.as<uint32_t>(), L->perm.as<uint32_t>(), n, key_bits, &second, stream));
         if (!second) std::swap(L->iota, L->perm);          // the sorted point ids are wherever the last pass left them
+        L->order_n = L->n; L->order_d = D; L->order_shard = L->shard_index; L->order_shards = L->n_shards; L->order_age = 0;
     } else {
         iota_kernel<<<nblocks, kBlock, 0, stream>>>(L->perm.as<uint32_t>(), n);
+        L->order_n = 0;
     }
     // counters[30] = m, [31] = key-range error flag, [32 .. 63] = range of the vertices' blur-axis coordinates: one read-back
     int *cnt = L->counters.as<int>() + 30;
     const bool embed_range = g_embed_vrange != 0 && !L->for_merge && g_vertex_order != 0;
     if (embed_range) PLX_HIP_TRY(hipMemsetAsync(cnt + 2, 0x80, 2 * kMaxOrderCoords * sizeof(int), stream));
-    embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, L->perm.as<uint32_t>(), n, sf,
-                                                    point_insert ? nullptr : L->ekeys.as<uint32_t>(),
-                                                    L->ew.as<float>(), cnt, want_rec ? L->prank.as<uint32_t>() : nullptr,
-                                                    embed_range ? cnt + 2 : nullptr);
+    embed_kernel<D><<<nblocks, kBlock, 0, stream>>>(d_ref, L->perm.as<uint32_t>(), n, sf, L->ew.as<float>(), cnt,
+                                                    L->prank.as<uint32_t>(), embed_range ? cnt + 2 : nullptr);
     mark();
     // flag_own: the insert marks owners (bit 31 of eslot: the table must not need that bit) and displaced corners (flagmask
-    // doubles as the displaced mask until flag_own_kernel turns it into the first-touch mask in place)
-    const bool flag_own = g_flag_own != 0 && L->table_bits <= 31;
+    // doubles as the displaced mask until flag_own_kernel turns it into the first-touch mask in place); a table of 2^32
+    // slots (more than 2^30 corners) has no bit to spare and takes the table-gather form (flag_kernel)
+    const bool flag_own = L->table_bits <= 31;
     if (flag_own) PLX_HIP_TRY(hipMemsetAsync(L->flagmask.p, 0, (size_t)n * 8, stream));
-    const int plane_fast = (g_insert_plane_fast != 0 && nblocks <= 65535) ? 1 : 0;
-    if (point_insert)
-        insert_point_kernel<D><<<tile_grid(nblocks, g_insert_xcd & 1), kBlock, 0, stream>>>(
-            L->prank.as<uint32_t>(), n, L->table.as<uint32_t>(), hash_sel(L), L->eslot.as<uint32_t>(), g_insert_dedupe,
-            flag_own ? L->flagmask.as<uint32_t>() : nullptr, nblocks, g_insert_xcd & 1);
-    else
-        insert_kernel<D><<<plane_fast ? dim3(D1, nblocks) : dim3(nblocks, D1), kBlock, 0, stream>>>(
-            L->ekeys.as<uint32_t>(), n, L->table.as<uint32_t>(), hash_sel(L), L->eslot.as<uint32_t>(), g_insert_dedupe,
-            plane_fast, flag_own ? L->flagmask.as<uint32_t>() : nullptr);
+    insert_point_kernel<D><<<tile_grid(nblocks, g_insert_xcd & 1), kBlock, 0, stream>>>(
+        L->prank.as<uint32_t>(), n, L->table.as<uint32_t>(), hash_sel(L), L->eslot.as<uint32_t>(), g_insert_dedupe,
+        flag_own ? L->flagmask.as<uint32_t>() : nullptr, nblocks, g_insert_xcd & 1);
     mark();
     L->flags_valid = !L->for_merge;      // the first-touch bits of this build's points stay in flagmask (plx_first.hip reads them)
     if (flag_own)
@@ -2090,7 +1966,7 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     L->m = m;
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));
     PLX_TRY(ensure(L->vslot, (size_t)m * 4 + 16));
-    L->vs0_valid = L->table_hash == 2 && g_nbr_sliced != 0 && !L->for_merge;
+    L->vs0_valid = !L->for_merge;
     if (L->vs0_valid) PLX_TRY(ensure(L->vs0, ((size_t)m + 8) * 4));
     if (want_rank) PLX_TRY(ensure(L->vowner, ((size_t)m + 8) * 4));
     const int fp_on = table_fp_on(L, m);
@@ -2098,8 +1974,7 @@ static int stage_local(plx_lattice *L, const float *d_ref, hipStream_t stream, i
     const bool ids_final = L->for_merge || !will_renumber(L, m, E);
     const bool assign_evid = g_assign_evid != 0 && ids_final;
     assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->flagmask.as<uint32_t>(), L->blockcnt.as<int>(),
-                                                     L->eslot.as<uint32_t>(), point_insert ? nullptr : L->ekeys.as<uint32_t>(),
-                                                     point_insert ? L->prank.as<uint32_t>() : nullptr, n,
+                                                     L->eslot.as<uint32_t>(), L->prank.as<uint32_t>(), n,
                                                      L->table.as<uint32_t>(), L->vkeys.as<uint32_t>(), L->vslot.as<uint32_t>(), fp_on,
                                                      assign_evid ? L->evid.as<int>() : nullptr,
                                                      (L->vs0_valid && ids_final) ? L->vs0.as<uint32_t>() : nullptr,
@@ -2238,7 +2113,7 @@ static int stage_merge(plx_lattice *L, const uint32_t *d_all_keys, const int64_t
     const int m = h_cnt[0];
     PLX_TRY(ensure(L->vkeys, (size_t)m * DW * 4 + 16));   // local keys are no longer needed: all_keys holds them
     PLX_TRY(ensure(L->vslot, (size_t)m * 4 + 16));
-    L->vs0_valid = L->table_hash == 2 && g_nbr_sliced != 0;
+    L->vs0_valid = true;
     if (L->vs0_valid) PLX_TRY(ensure(L->vs0, ((size_t)m + 8) * 4));
     const int fp_on = table_fp_on(L, m);
     merge_assign_kernel<D><<<nblocks, kBlock, 0, stream>>>(L->merge_flags.as<uint32_t>(), L->blockcnt.as<int>(),
@@ -2324,7 +2199,7 @@ static int stage_tables(plx_lattice *L, hipStream_t stream, int *evi)
                 memcpy(nc.pos[c], L->vcode_pos[c], 16);
             }
         }
-        const bool sliced = L->table_hash == 2 && L->vs0_valid && g_nbr_symmetric && ceil_div(m, kBlock) < (1 << 28) &&
+        const bool sliced = L->vs0_valid && g_nbr_symmetric && ceil_div(m, kBlock) < (1 << 28) &&
                             (g_nbr_sliced == 2 || (g_nbr_sliced == 1 && vcode == nullptr && m >= (1 << 20)));
         const uint32_t *slotmap = nullptr;
         if (!sliced && (g_nbr_bitmap == 2 || (g_nbr_bitmap == 1 && m >= (1 << 22)))) {

@@ -74,16 +74,12 @@ struct Tune {
     int perm_rows = 1;   // multi-column row permutations: 1 = 16-byte chunks in, LDS-transposed whole-line stores out; 0 = the round-3 per-float / per-chunk kernels
     int nbr_window = 512;   // Morton-numbered lattices: neighbour lookups first search this many sorted codes next to the vertex (0 = hash only)
     int nbr_bitmap = 1;   // neighbour lookups test a slot-occupancy bitmap before they touch the hash table: 0 never, 1 when m >= 2^22, 2 always
-    int hash_v = 2;   // vertex table hash: 1 = 64-bit mix of the packed key words; 2 = linear in the key coordinates + one multiplicative mix (a neighbour's hash is the vertex's own plus a constant, slot = top bits)
-    int table_fp = 1;   // hash_v = 2, m < 2^24: the table word of a numbered vertex carries 8 fingerprint bits of its key above the id
-    int nbr_sliced = 1;   // neighbour lookups served by the XCD that owns the slot's eighth of a 4-bit-per-slot map (L2 resident): 0 never, 1 when the lattice keeps first-touch numbering and m >= 2^20, 2 always (needs hash_v = 2)
+    int nbr_sliced = 1;   // neighbour lookups served by the XCD that owns the slot's eighth of a 4-bit-per-slot map (L2 resident): 0 never, 1 when the lattice keeps first-touch numbering and m >= 2^20, 2 always
     int insert_xcd = 2;   // XCD-aware tile order (each XCD one contiguous eighth of the points): bit 0 the point-per-thread insert (measured slower), bit 1 the id lookup
     int order_sample = 8;   // point-order key layout from the coordinate ranges of every k-th point (1: of all points); from 65,536 points up
     int embed_vrange = 0;   // 1: the embedding finds the range of the vertices' blur-axis coordinates (Morton renumbering) itself -- no pass over the vertex keys, no read-back of its own; measured: saves 22 us there, costs the embedding 30 (l = 1) to 70 us (l = 0.25): off
     int reference_growth = 0;   // 1: replay the reference CPU path's hash-table-growth quirk (plx_replay.hip): literal parity with cpp/permutohedral.h where its table doubles; plain single-process builds only, O(m) host work per build (the event form); 2: the lookup-by-lookup form, O(N (d+1)) (the checker of 1)
     int blk_sort = 15;   // per-block LDS sort of the block tables: 0 = (vertex, corner) pairs, 4 bits per pass; 4 / 5 / 6 = corner index packed under the vertex id, keys only, that many bits per pass, 256 threads; 15 = 5 bits with 512 threads
-    int insert_v = 2;   // hashed insert: 1 = one thread per corner over the packed corner keys (ekeys); 2 = one thread per point over the point records, several probe chains in flight per thread
-    int flag_own = 1;   // first-touch flags without table gathers: the insert marks who claimed / lowered a slot (top bit of eslot) and who was displaced
     int assign_evid = 1;   // the numbering pass stores the vertex id of every first-touch corner itself when the numbering is final; the id lookup then serves the other corners only
     int nbr_seed = 1;   // sliced neighbour lookups: the +1 neighbour that is a corner of the vertex's own first-touch simplex comes from the embedding, no lookup
     int contract_v = 1;   // fused backward, slice + contraction: 1 = corner count compiled in (all rows in flight, all-lane contraction), 0 = the run-time form
@@ -133,12 +129,8 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_embed_vrange (plx::tl_tune->embed_vrange)
 #define g_reference_growth (plx::tl_tune->reference_growth)
 #define g_blk_sort (plx::tl_tune->blk_sort)
-#define g_insert_v (plx::tl_tune->insert_v)
-#define g_flag_own (plx::tl_tune->flag_own)
 #define g_assign_evid (plx::tl_tune->assign_evid)
 #define g_nbr_seed (plx::tl_tune->nbr_seed)
-#define g_hash_v (plx::tl_tune->hash_v)
-#define g_table_fp (plx::tl_tune->table_fp)
 #define g_nbr_sliced (plx::tl_tune->nbr_sliced)
 #define g_contract_v (plx::tl_tune->contract_v)
 #define g_splat_ablate (plx::tl_tune->splat_ablate)
@@ -162,6 +154,10 @@ struct plx_lattice {
     bool single_use = false;     // built by plx_filter for one MVM: no vertex renumbering, no axis-pair tables
     bool for_merge = false;      // the local stage of a sharded build is running (vertex renumbering waits for the merge)
     bool lattice_rows = false;   // d_src / d_out rows are in lattice order (plx_set_row_order)
+    bool reuse_order = false;    // plx_set_reuse_order: the NEXT build keeps the point order of the previous one (one shot)
+    int64_t order_n = 0;         // what L->perm was computed for: rows, dimension, shard (0 rows: no order yet)
+    int order_d = 0, order_shard = 0, order_shards = 0;
+    int order_age = 0;           // builds since the order was computed from the positions themselves
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
 
     // problem
@@ -177,7 +173,6 @@ struct plx_lattice {
     int64_t nchunks = 0;           // ceil(nnz / kSplatChunk)
     uint32_t table_mask = 0;       // capacity - 1
     int table_bits = 0;            // log2(capacity)
-    int table_hash = 1;            // hash function the table of this build was filled under (Tune::hash_v)
     uint32_t table_idmask = 0xFFFFFFFFu;   // id bits of a numbered vertex's table word (0x00FFFFFF when the word carries a fingerprint)
 
     // point order: perm[i] = original row of the i-th point in lattice order (shard-major, then
@@ -186,7 +181,6 @@ struct plx_lattice {
     plx::DevBuf sortkey_in, sortkey_out, iota;   // uint64 [n], uint64 [n], uint32 [n]
 
     // build scratch
-    plx::DevBuf ekeys;      // uint32 [d+1][n][DW]   packed int16 keys of every simplex corner
     plx::DevBuf eslot;      // uint32 [d+1][n]       hash slot of every corner
     plx::DevBuf flagmask;   // uint32 [n]            bit r set: corner r is the first touch of its vertex
     plx::DevBuf blockcnt;   // int32  [nblocks+1]    per-workgroup first-touch counts, then offsets
@@ -197,7 +191,7 @@ struct plx_lattice {
     plx::DevBuf slotmap;    // uint32 [capacity / 32] one bit per hash slot: occupied (neighbour lookups of large lattices)
     plx::DevBuf prank;      // uint32 [n][W]         the point records (plx_build.hip, Rec<D>): packed greedy coordinates + one rank byte per coordinate (h:427-457), lattice order
     plx::DevBuf vowner;     // uint32 [m]            first-touch corner e = p (d+1) + r of every vertex (first-touch numbering; neighbour seeding)
-    plx::DevBuf vs0;        // uint32 [m]            pre-mix hash of every vertex key (hash_v = 2; sliced neighbour lookups)
+    plx::DevBuf vs0;        // uint32 [m]            pre-mix hash of every vertex key (sliced neighbour lookups)
     bool vs0_valid = false;
     plx::DevBuf vaxis;      // uint8  [m]            blur axis whose +1 neighbour was taken from the vertex's first-touch simplex (255: none)
     bool prank_valid = false;      // prank / flagmask describe THIS build's points and final vertex ids (plain single-process builds)
@@ -339,8 +333,9 @@ int slice_block_impl(plx_lattice *L, const float *d_values, float *d_out, hipStr
 size_t radix_temp_bytes(int64_t n);
 int radix_sort_pairs64(void *temp, uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
                        int *in_second, hipStream_t stream);
+// first_keys (optional): the first pass reads its keys from there (left untouched) with the values 0, 1, 2, ... implied
 int radix_sort_pairs32(void *temp, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
-                       int *in_second, hipStream_t stream);
+                       int *in_second, hipStream_t stream, const uint32_t *first_keys = nullptr);
 int selftest_sort(int64_t n, int key_bytes, int end_bit, uint64_t seed, hipStream_t stream, int64_t *mismatches);
 // block tables built in LDS, one workgroup per block (256-thread blocks): sort by vertex + every per-corner record;
 // the block's vertex list lands in rows_tmp[b * cpb + row] and is compacted once the row offsets are scanned

@@ -4,6 +4,8 @@
 // [1e6][11]; this is two streaming reads (~20 us).
 #include "plx_internal.h"
 
+#include <algorithm>
+
 namespace plx {
 
 constexpr int kDotBlocks = 1024;
@@ -206,6 +208,161 @@ __global__ __launch_bounds__(kBlock) void cg_step_direction4_kernel(float4 *__re
     }
 }
 
+// ----------------------------------------------------------------------------
+// The same two steps WITHOUT the two stand-alone reductions between them (round 6: a CG iteration was MVM + coldot_final
+// + update + coldot_final + direction; each coldot_final is a 7 us kernel behind a dependent-launch boundary of about
+// 5 us).  Rows of whole 16-byte chunks (vd = 4 NCH, NCH <= 4: the padded widths solvers.khat_solve runs at).
+//   update_fused:    every workgroup first sums the slice kernel's per-tile partial sums of <P, AP> itself (ntiles rows
+//                    of NCH chunks: 0.56 MB at N = 1e6, 12 columns -- re-read by each of the kFusedBlocks workgroups from
+//                    its XCD's L2), forms alpha, then streams its share of X, R, P, AP; |R|^2 leaves as ONE partial
+//                    row per workgroup ([kFusedBlocks][vd]).
+//   direction_fused: every workgroup sums those kFusedBlocks rows (12 KB), forms beta and the next activity mask,
+//                    then streams its share of P, R; workgroup 0 also stores rs_new, beta, active_out.
+// All sums in a fixed order (thread-strided partial sums, a fixed xor butterfly over the lanes, the waves in order):
+// every workgroup computes bit-identical coefficients, runs are reproducible.
+constexpr int kFusedBlocks = 256;        // update_fused: one 1024-thread workgroup per CU
+constexpr int kFusedThreads = 1024;
+constexpr int kFusedDirBlocks = 1024;    // direction_fused: persistent 256-thread workgroups
+
+__device__ __forceinline__ float4 f4_xor_sum(float4 a)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        a.x += __shfl_xor(a.x, off); a.y += __shfl_xor(a.y, off); a.z += __shfl_xor(a.z, off); a.w += __shfl_xor(a.w, off);
+    }
+    return a;
+}
+
+// column sums of `rows` rows of NCH float4 chunks, by all T threads of the workgroup; result in out[4 NCH] (LDS), valid
+// after the trailing barrier.  wsum: [T / 64][NCH] float4 of LDS scratch.
+template <int NCH, int T>
+__device__ __forceinline__ void block_column_sums(const float4 *__restrict__ part, int rows, float4 *wsum, float *out)
+{
+    const int total = rows * NCH;                          // chunks
+    float4 acc[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = (int)threadIdx.x % NCH;                        // chunk-in-row of this thread's current chunk
+    constexpr int U = 8;
+    int f = threadIdx.x;
+    for (; f + (U - 1) * T < total; f += U * T) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = part[f + u * T];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                if (k == j) { acc[j].x += v[u].x; acc[j].y += v[u].y; acc[j].z += v[u].z; acc[j].w += v[u].w; }
+            k = (k + T % NCH) % NCH;
+        }
+    }
+    for (; f < total; f += T) {
+        const float4 v = part[f];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (k == j) { acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w; }
+        k = (k + T % NCH) % NCH;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const float4 r = f4_xor_sum(acc[j]);
+        if (lane == 0) wsum[wave * NCH + j] = r;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 4 * NCH) {
+        const int j = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float sacc = 0.f;
+        for (int w = 0; w < T / 64; ++w) sacc += reinterpret_cast<const float *>(&wsum[w * NCH + j])[e];
+        out[threadIdx.x] = sacc;
+    }
+    __syncthreads();
+}
+
+template <int NCH>
+__global__ __launch_bounds__(kFusedThreads) void cg_step_update_fused_kernel(float *__restrict__ X, float *__restrict__ R,
+                                                                             const float *__restrict__ P,
+                                                                             const float *__restrict__ AP,
+                                                                             const float *__restrict__ rs,
+                                                                             const float4 *__restrict__ pap_partial, int ntiles,
+                                                                             const float *__restrict__ active, int64_t n,
+                                                                             float *__restrict__ rs_partial,
+                                                                             float *__restrict__ alpha_out)
+{
+    constexpr int vd = 4 * NCH, T = kFusedThreads;
+    __shared__ float4 wsum[(T / 64) * NCH];
+    __shared__ float pap[4 * NCH], salpha[4 * NCH];
+    __shared__ float red[T];
+    block_column_sums<NCH, T>(pap_partial, ntiles, wsum, pap);
+    if ((int)threadIdx.x < vd) {
+        const int c = threadIdx.x;
+        const float a = active[c] > 0.f ? rs[c] / fmaxf(pap[c], 1e-30f) : 0.f;
+        salpha[c] = a;
+        if (blockIdx.x == 0) alpha_out[c] = a;
+    }
+    __syncthreads();
+    const int c = threadIdx.x % vd, rl = threadIdx.x / vd;
+    constexpr int rows_per_step = T / vd;
+    const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, n);
+    float acc = 0.f;
+    if (rl < rows_per_step) {
+        const float a = salpha[c];
+        for (int64_t r = r0 + rl; r < r1; r += rows_per_step) {
+            const int64_t i = r * vd + c;
+            X[i] += P[i] * a;
+            const float res = R[i] - AP[i] * a;
+            R[i] = res;
+            acc += res * res;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        float s = 0.f;
+        for (int k = 0; k < rows_per_step; ++k) s += red[k * vd + c];
+        rs_partial[(size_t)blockIdx.x * vd + c] = s;
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void cg_step_direction_fused_kernel(float4 *__restrict__ P, const float4 *__restrict__ R,
+                                                                         const float4 *__restrict__ rs_partial, int nparts,
+                                                                         const float *__restrict__ rs,
+                                                                         const float *__restrict__ active,
+                                                                         const float *__restrict__ b_norm, float tol,
+                                                                         int64_t quads, float *__restrict__ rs_new_out,
+                                                                         float *__restrict__ beta_out,
+                                                                         float *__restrict__ active_out)
+{
+    constexpr int vd = 4 * NCH;
+    __shared__ float4 wsum[(kBlock / 64) * NCH];
+    __shared__ float rsn[4 * NCH];
+    __shared__ float4 sbeta[NCH];
+    block_column_sums<NCH, kBlock>(rs_partial, nparts, wsum, rsn);
+    if ((int)threadIdx.x < vd) {
+        const int c = threadIdx.x;
+        const bool on = active[c] > 0.f;
+        const float b = on ? rsn[c] / fmaxf(rs[c], 1e-30f) : 0.f;
+        reinterpret_cast<float *>(sbeta)[c] = b;
+        if (blockIdx.x == 0) {
+            rs_new_out[c] = rsn[c];
+            beta_out[c] = b;
+            active_out[c] = (on && sqrtf(rsn[c]) / b_norm[c] > tol) ? 1.f : 0.f;
+        }
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < quads; q += stride) {
+        const float4 b = sbeta[(int)(q % NCH)];
+        const float4 r = R[q];
+        float4 p = P[q];
+        p.x = r.x + p.x * b.x; p.y = r.y + p.y * b.y; p.z = r.z + p.z * b.z; p.w = r.w + p.w * b.w;
+        P[q] = p;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void cg_direction_kernel(float *__restrict__ P, const float *__restrict__ R,
                                                               const float *__restrict__ beta, int64_t total, int vd)
 {
@@ -346,6 +503,65 @@ extern "C" int plx_cg_step_direction(float *d_p, const float *d_r, const float *
     const int grid = total > 0 ? ceil_div(total, kBlock) : 1;
     cg_step_direction_kernel<<<grid, kBlock, 0, (hipStream_t)stream>>>(d_p, d_r, d_rs_new, d_rs, d_active, d_b_norm, tol, total,
                                                                      vd, d_beta, d_active_out);
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int64_t plx_cg_fused_work_floats(int vd) { return (vd >= 4 && vd <= 16 && vd % 4 == 0) ? (int64_t)kFusedBlocks * vd : -1; }
+
+extern "C" int plx_cg_step_update_fused(float *d_x, float *d_r, const float *d_p, const float *d_ap, const float *d_rs,
+                                        const float *d_pap_partial, int ntiles, const float *d_active, int64_t n, int vd,
+                                        float *d_alpha, float *d_work, void *stream)
+{
+    if (!d_x || !d_r || !d_p || !d_ap || !d_rs || !d_pap_partial || !d_active || !d_alpha || !d_work) {
+        set_error("plx_cg_step_update_fused: NULL argument");
+        return PLX_ERR_INVALID;
+    }
+    if (n < 0 || ntiles < 0 || plx_cg_fused_work_floats(vd) < 0) {
+        set_error("plx_cg_step_update_fused: vd = %d is not 4, 8, 12 or 16 (use plx_cg_step_update)", vd);
+        return PLX_ERR_INVALID;
+    }
+    if ((reinterpret_cast<uintptr_t>(d_pap_partial) & 15) != 0) { set_error("plx_cg_step_update_fused: d_pap_partial must be 16-byte aligned"); return PLX_ERR_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    const float4 *pp = reinterpret_cast<const float4 *>(d_pap_partial);
+    switch (vd / 4) {
+    case 1: cg_step_update_fused_kernel<1><<<kFusedBlocks, kFusedThreads, 0, s>>>(d_x, d_r, d_p, d_ap, d_rs, pp, ntiles, d_active, n, d_work, d_alpha); break;
+    case 2: cg_step_update_fused_kernel<2><<<kFusedBlocks, kFusedThreads, 0, s>>>(d_x, d_r, d_p, d_ap, d_rs, pp, ntiles, d_active, n, d_work, d_alpha); break;
+    case 3: cg_step_update_fused_kernel<3><<<kFusedBlocks, kFusedThreads, 0, s>>>(d_x, d_r, d_p, d_ap, d_rs, pp, ntiles, d_active, n, d_work, d_alpha); break;
+    default: cg_step_update_fused_kernel<4><<<kFusedBlocks, kFusedThreads, 0, s>>>(d_x, d_r, d_p, d_ap, d_rs, pp, ntiles, d_active, n, d_work, d_alpha); break;
+    }
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_cg_step_direction_fused(float *d_p, const float *d_r, const float *d_work, const float *d_rs,
+                                           const float *d_active, const float *d_b_norm, float tol, int64_t n, int vd,
+                                           float *d_rs_new, float *d_beta, float *d_active_out, void *stream)
+{
+    if (!d_p || !d_r || !d_work || !d_rs || !d_active || !d_b_norm || !d_rs_new || !d_beta || !d_active_out) {
+        set_error("plx_cg_step_direction_fused: NULL argument");
+        return PLX_ERR_INVALID;
+    }
+    if (d_active == d_active_out || d_rs == d_rs_new) { set_error("plx_cg_step_direction_fused: active / rs and their outputs must be different buffers"); return PLX_ERR_INVALID; }
+    if (n < 0 || plx_cg_fused_work_floats(vd) < 0) {
+        set_error("plx_cg_step_direction_fused: vd = %d is not 4, 8, 12 or 16 (use plx_cg_step_direction)", vd);
+        return PLX_ERR_INVALID;
+    }
+    if (((reinterpret_cast<uintptr_t>(d_p) | reinterpret_cast<uintptr_t>(d_r) | reinterpret_cast<uintptr_t>(d_work)) & 15) != 0) {
+        set_error("plx_cg_step_direction_fused: d_p, d_r and d_work must be 16-byte aligned");
+        return PLX_ERR_INVALID;
+    }
+    const int64_t quads = n * vd / 4;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(kFusedDirBlocks, ceil_div(quads, kBlock)));
+    hipStream_t s = (hipStream_t)stream;
+    float4 *p4 = reinterpret_cast<float4 *>(d_p);
+    const float4 *r4 = reinterpret_cast<const float4 *>(d_r), *w4 = reinterpret_cast<const float4 *>(d_work);
+    switch (vd / 4) {
+    case 1: cg_step_direction_fused_kernel<1><<<grid, kBlock, 0, s>>>(p4, r4, w4, kFusedBlocks, d_rs, d_active, d_b_norm, tol, quads, d_rs_new, d_beta, d_active_out); break;
+    case 2: cg_step_direction_fused_kernel<2><<<grid, kBlock, 0, s>>>(p4, r4, w4, kFusedBlocks, d_rs, d_active, d_b_norm, tol, quads, d_rs_new, d_beta, d_active_out); break;
+    case 3: cg_step_direction_fused_kernel<3><<<grid, kBlock, 0, s>>>(p4, r4, w4, kFusedBlocks, d_rs, d_active, d_b_norm, tol, quads, d_rs_new, d_beta, d_active_out); break;
+    default: cg_step_direction_fused_kernel<4><<<grid, kBlock, 0, s>>>(p4, r4, w4, kFusedBlocks, d_rs, d_active, d_b_norm, tol, quads, d_rs_new, d_beta, d_active_out); break;
+    }
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const K *__restrict__
     for (int j = 0; j < kKeysPerThread; ++j) {
         const int i = base + j * 64 + lane;
         k[j] = i < n ? keys_in[i] : (K)0;
-        if (HAS_VALS) v[j] = i < n ? vals_in[i] : 0u;
+        if (HAS_VALS) v[j] = i < n ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;      // vals_in == nullptr: the values are 0, 1, 2, ... (first pass)
     }
     // start of every bin in the output (exclusive scan of the bin totals; thread t owns bins t * BPT ..) + this tile's
     // offset inside the bin
@@ -184,7 +184,7 @@ static int one_pass_kpt(int *counts, int *totals, const K *src, K *dst, const ui
     const size_t lds = (size_t)(kThreads / 64) * BINS * sizeof(int);
     count_kernel<K, DB, KPT><<<ntiles, kThreads, 0, stream>>>(src, n, shift, ntiles, counts);
     scan_rows_kernel<<<BINS, kThreads, 0, stream>>>(counts, ntiles, totals);
-    if (vsrc)
+    if (vdst)      // (vsrc may be null: the values of the first pass are the positions themselves)
         scatter_kernel<K, DB, KPT, true><<<ntiles, kThreads, lds, stream>>>(src, vsrc, dst, vdst, n, shift, ntiles, counts, totals);
     else
         scatter_kernel<K, DB, KPT, false><<<ntiles, kThreads, lds, stream>>>(src, nullptr, dst, nullptr, n, shift, ntiles, counts, totals);
@@ -218,26 +218,35 @@ inline int digit_bits(int64_t n, int end_bit)
 // Sorts bits [0, end_bit) of the keys in passes of digit_bits(n, end_bit) bits, ping-ponging between
 // the two buffer pairs; *in_second tells where the result is (0: keys_a / vals_a, 1: keys_b / vals_b).  vals may be null
 // (keys only).  n <= 2^31 - 4096.  temp: temp_bytes(n).
+// first_keys (optional): the first pass reads its keys from there (left untouched) and takes the values to be 0, 1, 2, ...;
+// the later passes ping-pong between the two buffer pairs as usual (n > 1 and end_bit > 0 required: there must BE a pass).
 template <class K>
 int sort_pairs(void *temp, K *keys_a, K *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit, int *in_second,
-               hipStream_t stream)
+               hipStream_t stream, const K *first_keys = nullptr)
 {
     *in_second = 0;
-    if (n <= 1 || end_bit <= 0) return PLX_OK;
+    if (n <= 1 || end_bit <= 0) {
+        if (first_keys) { set_error("radix::sort_pairs: a sort from constant keys needs at least one pass"); return PLX_ERR_INVALID; }
+        return PLX_OK;
+    }
     const int ntiles = num_tiles(n);
     const int db = digit_bits(n, end_bit);
     int *counts = reinterpret_cast<int *>(temp);
     int *totals = counts + ((size_t)1 << db) * ntiles;
-    K *src = keys_a, *dst = keys_b;
-    uint32_t *vsrc = vals_a, *vdst = vals_b;
+    const K *src = first_keys ? first_keys : keys_a;
+    K *dst = keys_b;
+    const uint32_t *vsrc = first_keys ? nullptr : vals_a;
+    uint32_t *vdst = vals_b;
     for (int shift = 0; shift < end_bit; shift += db) {
         switch (db) {
         case 8: one_pass<K, 8>(counts, totals, src, dst, vsrc, vdst, (int)n, shift, ntiles, stream); break;
         case 9: one_pass<K, 9>(counts, totals, src, dst, vsrc, vdst, (int)n, shift, ntiles, stream); break;
         default: one_pass<K, 10>(counts, totals, src, dst, vsrc, vdst, (int)n, shift, ntiles, stream); break;
         }
-        std::swap(src, dst);
-        std::swap(vsrc, vdst);
+        src = dst;
+        dst = dst == keys_b ? keys_a : keys_b;
+        vsrc = vdst;
+        vdst = vdst == vals_b ? vals_a : vals_b;
         *in_second ^= 1;
     }
     PLX_HIP_TRY(hipGetLastError());

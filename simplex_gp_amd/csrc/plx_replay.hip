@@ -231,7 +231,7 @@ struct EventTable {
             if (pos + 32 < n_old && old[pos + 32] >= 0) __builtin_prefetch(&hk[vertex_of(old[pos + 32])]);
             const int32_t l = old[pos];
             if (l < 0) continue;
-            uint64_t h = hk[vertex_of(l)] % cap;   // (old-position order visits the new homes in two rising runs: cache friendly)
+            uint64_t h = hk[vertex_of(l)] & (cap - 1);   // cap is a power of two: hash % cap (h:104) is a mask.  (Old-position order visits the new homes in two rising runs: cache friendly)
             while (tab[h] != -1) { if (++h == cap) h = 0; }
             tab[h] = l;
         }
@@ -241,7 +241,7 @@ struct EventTable {
     // h:104-106 + h:58-95, as RefTable::lookup; *created tells whether the probe ended on an empty slot and made an entry
     int32_t lookup(int32_t v, bool create, bool *created)
     {
-        uint64_t h = hk[v] % cap;
+        uint64_t h = hk[v] & (cap - 1);             // = hash % cap with the capacity in force BEFORE the growth check
         if (due()) grow();
         for (;;) {
             const int32_t l = tab[h];
@@ -351,14 +351,14 @@ static int replay_events(plx_lattice *L, hipStream_t stream, std::vector<int> &d
         if (T.due() && e + 1 < E) make_affected(vat_at(e + 1), e + 1);
     };
     int64_t i = 0;
-    constexpr int64_t kAhead = 24;
+    constexpr int64_t kAhead = 32;
     for (;;) {
         while (i < m && affected[cv[i]]) ++i;               // an affected vertex's creation comes off the queue
         const int64_t tc = i < m ? (int64_t)ce[i] : INT64_MAX, th = pq.empty() ? INT64_MAX : (int64_t)pq.top().first;
         if (tc == INT64_MAX && th == INT64_MAX) break;
         bool created = false;
         if (tc < th) {
-            if (i + kAhead < m) __builtin_prefetch(&T.tab[hk[cv[i + kAhead]] % T.cap]);
+            if (i + kAhead < m) __builtin_prefetch(&T.tab[hk[cv[i + kAhead]] & (T.cap - 1)]);
             if (i + 2 * kAhead < m) __builtin_prefetch(&hk[cv[i + 2 * kAhead]]);
             const int32_t v = (int32_t)cv[i++];
             T.lookup(v, true, &created);

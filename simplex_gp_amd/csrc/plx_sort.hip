@@ -39,9 +39,9 @@ int radix_sort_pairs64(void *temp, uint64_t *keys_a, uint64_t *keys_b, uint32_t 
 }
 
 int radix_sort_pairs32(void *temp, uint32_t *keys_a, uint32_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, int64_t n, int end_bit,
-                       int *in_second, hipStream_t stream)
+                       int *in_second, hipStream_t stream, const uint32_t *first_keys)
 {
-    return radix::sort_pairs<uint32_t>(temp, keys_a, keys_b, vals_a, vals_b, n, end_bit, in_second, stream);
+    return radix::sort_pairs<uint32_t>(temp, keys_a, keys_b, vals_a, vals_b, n, end_bit, in_second, stream, first_keys);
 }
 
 // ---- self test of the radix sort (plx_selftest_sort): keys with many duplicates, values = positions; sorted + stable?

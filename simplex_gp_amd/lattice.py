@@ -74,14 +74,19 @@ class Lattice:
             pass
 
     # -- structure --------------------------------------------------------
-    def build(self, ref, coeffs, shard=None):
+    def build(self, ref, coeffs, shard=None, reuse_order=False):
         """shard = (index, count): this process splats / slices block `index` of the
-        `count` contiguous near-equal row blocks (distributed.shard_bounds); None = all rows."""
+        `count` contiguous near-equal row blocks (distributed.shard_bounds); None = all rows.
+        reuse_order=True: `ref` is the previous build's positions re-scaled a little (a lengthscale that moved): keep the
+        lattice order of the points (plx_set_reuse_order: the order passes of the build are skipped; the result is the
+        cold build's up to the order of the fp32 sums inside a vertex row).  Ignored when no order of that shape exists."""
         _check_f32_cuda(ref, "ref")
         ref = ref.contiguous()
         taps = _taps_array(coeffs)
         n, d = ref.shape
         index, count = (0, 1) if shard is None else shard
+        if reuse_order:
+            nv.check(nv.lib().plx_set_reuse_order(self._h, 1), "plx_set_reuse_order")
         with torch.cuda.device(self.device):
             rc = nv.lib().plx_build(self._h, ctypes.c_void_p(ref.data_ptr()), n, d,
                                     taps.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), taps.size,
@@ -150,6 +155,11 @@ class Lattice:
                                           int(total_points), _stream_ptr(self.device))
         nv.check(rc, "plx_build_merge")
         return self
+
+    @property
+    def order_age(self):
+        """Builds since the point order was computed from the positions themselves (0: by the last build; -1: none)."""
+        return int(nv.lib().plx_order_age(self._h))
 
     @property
     def n(self):
@@ -356,7 +366,9 @@ class Lattice:
     def apply_affine(self, src, scale_shift, out=None, want_dot=False):
         """out = a * K src + b * src with (a, b) = scale_shift (a 2-element float32 tensor on the device, read
         there: no host synchronisation on hyper-parameters).  want_dot: also return the column-wise <src, out>
-        (the p^T A p of a CG iteration), formed inside the slice kernel; needs 2..256 columns."""
+        (the p^T A p of a CG iteration), formed inside the slice kernel; needs 2..256 columns.  want_dot="partial":
+        return (out, work, tiles) with the per-tile partial sums of those dots left un-reduced in `work` (the fused CG
+        step adds them up itself); `work` is the lattice's own buffer, valid until the next such call."""
         src = self._src(src, self.n_owned)
         _check_f32_cuda(scale_shift, "scale_shift", ndim=1)
         assert scale_shift.numel() == 2 and scale_shift.is_contiguous()
@@ -370,6 +382,15 @@ class Lattice:
                 raise ValueError(f"apply_affine(want_dot=True) needs 2..256 columns on a built lattice, got {vd}")
             if self._dot_work is None or self._dot_work.numel() < need:
                 self._dot_work = torch.empty(need, dtype=torch.float32, device=self.device)
+            if want_dot == "partial":
+                # the slice kernel's per-tile partial sums stay in the work buffer: (out, partials, tiles) for
+                # plx_cg_step_update_fused, which adds them up itself (no stand-alone reduction launch)
+                with torch.cuda.device(self.device):
+                    rc = L.plx_apply_affine_dot(self._h, ctypes.c_void_p(src.data_ptr()), vd, ctypes.c_void_p(out.data_ptr()),
+                                                ctypes.c_void_p(scale_shift.data_ptr()), None,
+                                                ctypes.c_void_p(self._dot_work.data_ptr()), _stream_ptr(self.device))
+                nv.check(rc, "plx_apply_affine_dot")
+                return out, self._dot_work, int(L.plx_affine_dot_tiles(self._h, vd))
             dot = torch.empty(self.values_stride(vd), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 rc = L.plx_apply_affine_dot(self._h, ctypes.c_void_p(src.data_ptr()), vd, ctypes.c_void_p(out.data_ptr()),

@@ -605,6 +605,9 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     return X, info
 
 
+FUSED_CG_STEPS = True      # False: every CG iteration runs its reductions as stand-alone launches (A/B, tests)
+
+
 def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matmul_dot=None, floor=0):
     """batched_cg on one GPU with the iteration's scalars kept on the device: per iteration one
     MVM, one column dot, plx_cg_step_update and plx_cg_step_direction (alpha, beta and the
@@ -631,9 +634,32 @@ def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matm
     betas = torch.zeros(kmax if want_tridiag else 1, t, dtype=torch.float32, device=dev)
     p = lambda a: ctypes.c_void_p(a.data_ptr())          # noqa: E731
     it = 0
+    # the iteration without its two stand-alone reductions (plx_cg_step_*_fused): rows of whole 16-byte chunks, and an
+    # MVM that can leave its <P, AP> partial sums un-reduced (matmul_dot.partial)
+    partial_mm = getattr(matmul_dot, "partial", None) if FUSED_CG_STEPS else None
+    fused = partial_mm is not None and int(lib.plx_cg_fused_work_floats(t)) > 0
+    if fused:
+        fkey = (dev.index, t, "fused")
+        fwork = _dot_work.get(fkey)
+        if fwork is None:
+            fwork = _dot_work[fkey] = torch.empty(int(lib.plx_cg_fused_work_floats(t)), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         for it in range(1, max_iter + 1):
+            if fused:
+                AP, pap_part, tiles = partial_mm(P)
+                row = it - 1 if want_tridiag else 0
+                nv.check(lib.plx_cg_step_update_fused(p(X), p(R), p(P), p(AP), p(rs), p(pap_part), tiles, p(active), n, t,
+                                                      p(alphas[row]), p(fwork), stream), "plx_cg_step_update_fused")
+                step_tol = float(tol) if it >= floor else min(float(tol), _FROZEN_BELOW)
+                nv.check(lib.plx_cg_step_direction_fused(p(P), p(R), p(fwork), p(rs), p(active), p(b_norm), step_tol, n, t,
+                                                         p(rs_new), p(betas[row]), p(active_next), stream),
+                         "plx_cg_step_direction_fused")
+                rs, rs_new = rs_new, rs
+                active, active_next = active_next, active
+                if tol > 0 and (it % check_every == 0 or it == max_iter) and not bool(active.any()):
+                    break
+                continue
             if matmul_dot is not None:
                 AP, pAp = matmul_dot(P)
                 pAp = pAp.contiguous()
@@ -826,8 +852,9 @@ class LatticeGP(nn.Module):
                 return batched_cg(self.khat_matmul(x, K), rhs, **cg_args)
             # the positions of an existing operator share storage with its tensor: same lattice-cache key, so the
             # differentiable MVM that follows a solve reuses the lattice built here
-            ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
-            ref = ref if ref.is_contiguous() else ref.contiguous()
+            ref = lk.carry_hint(K.x.detach(), K.x) if isinstance(K, lk.SquareLazyLattice) \
+                else lk.position_hint(x.div(self.kernel.lengthscale), x)
+            ref = ref if ref.is_contiguous() else lk.carry_hint(ref.contiguous(), ref)
             pre = cg_args.get("precond")
             if isinstance(pre, LatticePreconditioner) and pre.ref is not None and pre.ref is not ref \
                     and self._same_positions(pre, x):
@@ -854,7 +881,11 @@ class LatticeGP(nn.Module):
                 rhs_l = lat.to_lattice_order(rhs)
                 if pad:
                     rhs_l = torch.cat([rhs_l, rhs_l.new_zeros(rhs_l.shape[0], pad)], 1).contiguous()
-                fused_dot = (lambda V: lat.apply_affine(V, ss, want_dot=True)) if 2 <= rhs_l.shape[1] <= 256 else None
+                fused_dot = None
+                if 2 <= rhs_l.shape[1] <= 256:
+                    def fused_dot(V):
+                        return lat.apply_affine(V, ss, want_dot=True)
+                    fused_dot.partial = lambda V: lat.apply_affine(V, ss, want_dot="partial")
                 sol, info = batched_cg(lambda V: lat.apply_affine(V, ss), rhs_l, matmul_dot=fused_dot, lattice_rows=native_pre,
                                        **cg_args)
                 if pad:
@@ -878,8 +909,9 @@ class LatticeGP(nn.Module):
             # (the native passes hold at most LatticePreconditioner.MAX_RANK factor columns: larger ranks take the torch form)
             if lk.LatticeFilterGeneral.method is None and x.is_cuda and x.dtype == torch.float32 \
                     and min(int(rank), x.shape[0]) <= LatticePreconditioner.MAX_RANK:
-                ref = K.x.detach() if isinstance(K, lk.SquareLazyLattice) else x.div(self.kernel.lengthscale)
-                ref = ref if ref.is_contiguous() else ref.contiguous()
+                ref = lk.carry_hint(K.x.detach(), K.x) if isinstance(K, lk.SquareLazyLattice) \
+                    else lk.position_hint(x.div(self.kernel.lengthscale), x)
+                ref = ref if ref.is_contiguous() else lk.carry_hint(ref.contiguous(), ref)
                 lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
                 pre = LatticePreconditioner(lat, self.outputscale, self.noise, rank, factor_dtype=factor_dtype)
                 pre.ref = ref          # the positions its lattice was built on (kept alive: the lattice-cache key)

@@ -147,14 +147,22 @@ def make_optimizer(model, lr=0.1):
 
 
 def fit(model, train, val=None, test=None, epochs=100, lr=0.1, patience=200, log_every=1, num_probes=10,
-        cg_iter=1000, cg_tol=1.0, cg_eval_tol=1e-2, lanc_iter=100, pre_size=100, checkpoint=None, log=None):
+        cg_iter=1000, cg_tol=1.0, cg_eval_tol=1e-2, lanc_iter=100, pre_size=100, checkpoint=None, log=None,
+        cap_host_threads=False):
     """Adam on -MLL; every `log_every` epochs evaluate on val/test, keep the state
     with the best validation RMSE, stop after `patience` evaluations without
     improvement; optionally torch.save the best state_dict to `checkpoint`.
     Defaults are the reference's (train_simplexgp.py:87-90): `pre_size` = 100 is the rank of the pivoted-Cholesky
     preconditioner (train_simplexgp.py:36; on the HIP path it is built and applied natively, solvers.LatticePreconditioner;
-    0 = plain CG)."""
+    0 = plain CG).
+    cap_host_threads=True: the process's host BLAS pool is capped at half the container's CPU quota for good
+    (solvers.cap_host_threads: a 128-thread pool under a 16-CPU quota stalls the loop's small host steps for 30-100 ms
+    every few epochs).  Opt-in, because it changes the host application's thread count; the library itself only caps
+    the pool for the duration of its own small host factorisations and restores it."""
     x, y = train
+    if cap_host_threads:
+        from . import solvers
+        solvers.cap_host_threads()
     opt = make_optimizer(model, lr=lr)
     stopper = EarlyStopper(patience=patience)
     history = []

@@ -474,6 +474,9 @@ def test_bench_train_step_phases_add_up(plx):
     they were taken from within 25 %, and the un-synchronised step_ms is not above it (round 4 reported an `optimizer` phase
     of 73 ms inside a 12.8 ms step: one outlier step)."""
     import bench
+    from simplex_gp_amd import solvers
+    solvers.cap_host_threads()          # as bench.main does: the process-wide BLAS-pool cap is the caller's opt-in (the
+                                        # library only caps the pool inside its own small host factorisations)
 
     class Ctx:
         dev = torch.device("cuda:0")

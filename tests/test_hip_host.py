@@ -640,6 +640,141 @@ def test_affine_apply_and_device_side_cg(plx):
     lat.close()
 
 
+@pytest.mark.parametrize("t", [4, 8, 12, 16])
+def test_cg_iteration_without_standalone_reductions(plx, t):
+    """plx_cg_step_update_fused / plx_cg_step_direction_fused (round 6: the <P, AP> partial sums of the slice kernel and the
+    |R|^2 partial sums of the update are added up inside their consumers, two launches fewer per iteration) against the
+    pair with stand-alone reductions: one step on random vectors, coefficient by coefficient; then whole solves -- the
+    same iteration counts, iterates equal to rounding, the same Lanczos tridiagonals; reproducible bit for bit."""
+    import ctypes
+    from simplex_gp_amd import solvers, _native as nv
+    lib = nv.lib()
+    g = torch.Generator().manual_seed(40 + t)
+    n, d = 60001, 4
+    x = torch.randn(n, d, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    lat = plx.Lattice().build(x, taps)
+    lat.set_lattice_row_order(True)
+    ss = torch.tensor([0.7, 0.3], device="cuda")
+    p = lambda a: ctypes.c_void_p(a.data_ptr())          # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # ---- one step
+    X, R, P = (torch.randn(n, t, generator=g).cuda() for _ in range(3))
+    rs = (R * R).sum(0).contiguous()
+    active = torch.ones(t, device="cuda")
+    active[1] = 0.0                                                       # a frozen column: alpha = beta = 0 there
+    b_norm = rs.sqrt().contiguous()
+    AP, dot = lat.apply_affine(P, ss, want_dot=True)
+    X0, R0, P0 = X.clone(), R.clone(), P.clone()
+    work = torch.empty(int(lib.plx_coldot_work_floats(t)), device="cuda")
+    rs_new, alpha, beta, act2 = (torch.empty(t, device="cuda") for _ in range(4))
+    nv.check(lib.plx_cg_step_update(p(X0), p(R0), p(P0), p(AP), p(rs), p(dot.contiguous()), p(active), n, t, p(rs_new), p(alpha), p(work), stream), "update")
+    nv.check(lib.plx_cg_step_direction(p(P0), p(R0), p(rs_new), p(rs), p(active), p(b_norm), 1e-3, n, t, p(beta), p(act2), stream), "direction")
+    AP2, part, tiles = lat.apply_affine(P, ss, want_dot="partial")
+    assert torch.equal(AP2, AP) and tiles == int(lib.plx_affine_dot_tiles(lat._h, t)) > 0
+    X1, R1, P1 = X.clone(), R.clone(), P.clone()
+    fwork = torch.empty(int(lib.plx_cg_fused_work_floats(t)), device="cuda")
+    rs_new1, alpha1, beta1, act21 = (torch.empty(t, device="cuda") for _ in range(4))
+    nv.check(lib.plx_cg_step_update_fused(p(X1), p(R1), p(P1), p(AP2), p(rs), p(part), tiles, p(active), n, t, p(alpha1), p(fwork), stream), "update_fused")
+    nv.check(lib.plx_cg_step_direction_fused(p(P1), p(R1), p(fwork), p(rs), p(active), p(b_norm), 1e-3, n, t, p(rs_new1), p(beta1), p(act21), stream), "direction_fused")
+    assert float(alpha1[1]) == 0.0 and float(beta1[1]) == 0.0 and torch.equal(act2, act21)
+    assert torch.allclose(alpha1, alpha, rtol=2e-5) and torch.allclose(rs_new1, rs_new, rtol=2e-5) and torch.allclose(beta1, beta, rtol=4e-5)
+    assert torch.allclose(rs_new1.double(), (R1.double() ** 2).sum(0), rtol=1e-5)
+    for a, b in ((X1, X0), (R1, R0), (P1, P0)):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+    assert int(lib.plx_cg_fused_work_floats(11)) == -1
+    # ---- whole solves through solvers.batched_cg (the path khat_solve takes)
+    V = torch.randn(n, t, generator=g).cuda()
+
+    def mm_dot(W):
+        return lat.apply_affine(W, ss, want_dot=True)
+    mm_dot.partial = lambda W: lat.apply_affine(W, ss, want_dot="partial")
+    mm = lambda W: lat.apply_affine(W, ss)       # noqa: E731
+    assert solvers.FUSED_CG_STEPS
+    Xf, inf_f = solvers.batched_cg(mm, V, max_iter=20, tol=1e-6, want_tridiag=True, check_every=1, matmul_dot=mm_dot)
+    Xf2, _ = solvers.batched_cg(mm, V, max_iter=20, tol=1e-6, want_tridiag=True, check_every=1, matmul_dot=mm_dot)
+    assert torch.equal(Xf, Xf2)                                            # fixed summation orders: reproducible
+    solvers.FUSED_CG_STEPS = False
+    try:
+        Xu, inf_u = solvers.batched_cg(mm, V, max_iter=20, tol=1e-6, want_tridiag=True, check_every=1, matmul_dot=mm_dot)
+    finally:
+        solvers.FUSED_CG_STEPS = True
+    # (two fp32 CG runs whose dot products are associated differently drift apart like cond(A) x eps x iterations: 6.5e-4
+    # measured here at 20 iterations of an unconverged solve; what must hold is that neither is the worse solution -- the
+    # true residuals below -- and that the quadrature agrees)
+    assert inf_f["iterations"] == inf_u["iterations"] and rel_l2(Xf.cpu().numpy(), Xu.cpu().numpy()) <= 3e-3
+    # the Lanczos coefficients: the leading block to rounding (another association of the dot products: the fp32 recurrences
+    # drift apart by a few 1e-5 per iteration, and the late coefficients of a converged column are noise in both), and
+    # what they are FOR -- the quadrature e1^T log(T) e1 of the log-determinant -- to 1e-3
+    Tf, Tu = inf_f["tridiag"].cpu(), inf_u["tridiag"].cpu()
+    assert torch.allclose(Tf[:, :6, :6], Tu[:, :6, :6], rtol=5e-3, atol=5e-4)
+    qf, qu = solvers.slq_terms(Tf), solvers.slq_terms(Tu)
+    assert torch.allclose(qf, qu, rtol=2e-3, atol=2e-4), (qf, qu)
+    rf, ru = (mm(Xf) - V).norm() / V.norm(), (mm(Xu) - V).norm() / V.norm()
+    assert float(rf) <= 1.5 * float(ru) + 1e-6
+    lat.close()
+
+
+def test_point_order_warm_start_across_rescaled_rebuilds(plx):
+    """Lattice.build(reuse_order=True) / plx_set_reuse_order: a rebuild on re-scaled positions keeps the point order of the
+    previous build (the order passes are skipped) and gives the cold build's structure and output (up to the order of the
+    fp32 sums inside a vertex row); it is ignored for another row count.  The kernel-level cache does it by itself when the
+    SAME data tensor comes back under another lengthscale (LatticeAccelerated.forward tags its scaled positions), not for
+    other data, and refreshes the order after MAX_ORDER_AGE rebuilds."""
+    from simplex_gp_amd import lattice_kernel as lk, _native as nv
+    g = torch.Generator().manual_seed(77)
+    n, d = 40000, 5
+    x = torch.randn(n, d, generator=g).cuda()
+    v = torch.randn(n, 3, generator=g).cuda()
+    taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
+    cold, warm = plx.Lattice(), plx.Lattice()
+    assert warm.order_age == -1
+    warm.build((x / 0.7).contiguous(), taps)
+    assert warm.order_age == 0
+    perm0 = warm.export(nv.ARRAY_POINT_PERM).copy()
+    ref1 = (x / 0.9).contiguous()
+    warm.build(ref1, taps, reuse_order=True)
+    cold.build(ref1, taps)
+    assert warm.order_age == 1 and cold.order_age == 0
+    assert np.array_equal(warm.export(nv.ARRAY_POINT_PERM), perm0)                 # the order was kept ...
+    assert not np.array_equal(cold.export(nv.ARRAY_POINT_PERM), perm0)             # ... where a cold build finds another
+    assert warm.m == cold.m
+    kw, kc = warm.export(nv.ARRAY_KEYS), cold.export(nv.ARRAY_KEYS)
+    assert {k.tobytes() for k in kw} == {k.tobytes() for k in kc}                  # the same vertex set
+    assert rel_l2(warm.apply(v).cpu().numpy(), cold.apply(v).cpu().numpy()) <= 1e-6
+    warm.build(ref1[: n // 2].contiguous(), taps, reuse_order=True)                # other rows: the flag is ignored
+    assert warm.order_age == 0
+    warm.build(ref1, taps)                                                         # one shot: a plain build is a cold one
+    assert warm.order_age == 0
+    cold.close(); warm.close()
+    # ---- the cache: same data tensor, lengthscale moved
+    cache = lk.lattice_cache()
+    cache.clear()
+    k = plx.RBFLattice(order=1, ard_num_dims=d).cuda()
+    w0 = cache.warm_rebuilds
+    outs = []
+    with torch.no_grad():
+        for step, ell in enumerate([0.7, 0.75, 0.8]):
+            k.lengthscale = ell
+            outs.append(k(x, x).matmul(v))
+            assert cache.warm_rebuilds == w0 + step, (step, cache.warm_rebuilds)
+            assert len(cache._entries) == 1                                        # rebuilt in place, not piled up
+        lat = list(cache._entries.values())[0][0]
+        assert lat.order_age == 2
+        want = plx.Lattice().build((x / 0.8).contiguous(), taps).apply(v)
+        assert rel_l2(outs[-1].cpu().numpy(), want.cpu().numpy()) <= 1e-6
+        x2 = x.clone()                                                             # other data (another tensor): no warm start
+        k(x2, x2).matmul(v)
+        assert cache.warm_rebuilds == w0 + 2 and len(cache._entries) == 2
+        seen = []
+        for i in range(lk.MAX_ORDER_AGE + 2):                                      # the order is refreshed now and then
+            k.lengthscale = 0.8 + 0.01 * (i + 1)
+            k(x, x).matmul(v)
+            seen.append(max(l.order_age for l, _ in cache._entries.values()))
+        assert max(seen) == lk.MAX_ORDER_AGE and seen[-1] < lk.MAX_ORDER_AGE and len(cache._entries) == 2
+    cache.clear()
+
+
 def test_fused_entry_points_reject_bad_use(plx):
     """plx_apply_backward / plx_apply_affine fail loudly (error code -> PlxError / ValueError), never silently."""
     from simplex_gp_amd._native import PlxError

@@ -3,7 +3,7 @@
 (minimum over rounds), table-build time (plx_prepare), one MVM's time, and the built structure compared with the first
 variant's bit for bit (vertex keys, per-corner vertex ids, neighbour table, output of one MVM).
 
-    python tools/ab_build_r5.py --ells 1.0 0.25 --variants "hash_v=1,nbr_sliced=0" "hash_v=2,nbr_sliced=0" "hash_v=2,nbr_sliced=1"
+    python tools/ab_build_r5.py --ells 1.0 0.25 --variants "nbr_sliced=0" "nbr_sliced=1" "nbr_sliced=2"
 """
 import argparse, json, os, sys, time
 import numpy as np, torch
@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--d", type=int, default=8)
 ap.add_argument("--ells", type=float, nargs="+", default=[1.0, 0.6931, 0.25])
-ap.add_argument("--variants", nargs="+", default=["hash_v=1,nbr_sliced=0", "hash_v=2,nbr_sliced=0", "hash_v=2,nbr_sliced=1"])
+ap.add_argument("--variants", nargs="+", default=["nbr_sliced=0", "nbr_sliced=1", "nbr_sliced=2"])
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--no-compare", action="store_true")
 args = ap.parse_args()

@@ -27,7 +27,7 @@ def alg_bytes(name, m_fwd, m_bwd):
         return m_bwd * (8 * vd + 8 * r), f"m (8 vd + 8 r), vd = {vd}, m = {m_bwd}"
     if "splat_wide_kernel" in name and "StackSource" in name:
         return 4 * N * vd + 8 * N * (d + 1) + 4 * m_bwd * vd, "B_splat at vd = 198 (the stack is formed from packed records, never stored)"
-    if "slice_contract_kernel" in name:
+    if "slice_contract" in name:
         return 8 * N * (d + 1) + 4 * m_bwd * vd + 4 * N * (d + L), "B_slice at vd = 198 without the N x vd output, + grad_x, grad_src"
     if "backward_pack_kernel" in name:
         return 4 * N * (2 * L + d) + 4 * N * 32, "g, src, x in; one 128-byte record per point out"
@@ -35,9 +35,9 @@ def alg_bytes(name, m_fwd, m_bwd):
         return 2 * kp * N + 4 * N * 12, "fp16 factor [112][N] + R [N][12]"
     if "pcg_apply_kernel<12, false, true>" in name:
         return 2 * 100 * N + 2 * 4 * N * 12, "fp16 factor [100][N] + R in + Z out"
-    if "cg_step_update_kernel" in name:
+    if "cg_step_update" in name:
         return 6 * 4 * N * 12, "X, R, P, AP in; X, R out"
-    if "step_direction4_kernel" in name:
+    if "step_direction4_kernel" in name or "cg_step_direction_fused" in name:
         return 3 * 4 * N * 12, "P, R (or Z) in; P out"
     if "pchol_multi_step_kernel" in name:
         return 4 * N * (2 * 16 + 3), "16 panel rows in, 16 factor columns out, diagonal in / out, tie-break ranks in"
@@ -60,7 +60,9 @@ def table(rows, m_fwd, m_bwd, steps, top=34):
             gbps = ab[0] / (mean * 1e-6) / 1e9
             frac = f"  {ab[0] / 1e6:8.1f} MB  {gbps:7.0f} GB/s  {gbps / 8000:5.2f} of 8 TB/s   [{ab[1]}]"
         out.append(f"{name:72s} calls/step {int(x['Calls']) / steps:7.1f}  mean {mean:9.2f} us  per step {float(x['TotalDurationNs']) / steps / 1e6:7.3f} ms{frac}")
-    out.append(f"(kernel time per step: {total / steps / 1e6:.2f} ms)")
+    launches = sum(int(x["Calls"]) for x in rows) / steps
+    out.append(f"(kernel time per step: {total / steps / 1e6:.2f} ms; launches per step: {launches:.0f} -- all {len(rows)} kernel names of the "
+               "trace, the build of the step's lattice included)")
     return "\n".join(out)
 
 

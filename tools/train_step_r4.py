@@ -9,6 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import solvers
+solvers.cap_host_threads()      # the process-wide BLAS-pool cap is the caller's opt-in (bench.py does the same)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1_000_000)
