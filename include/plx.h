@@ -292,6 +292,14 @@ int plx_cg_step_update_fused(float *d_x, float *d_r, const float *d_p, const flo
 int plx_cg_step_direction_fused(float *d_p, const float *d_r, const float *d_work, const float *d_rs, const float *d_active,
                                 const float *d_b_norm, float tol, int64_t n, int vd, float *d_rs_new, float *d_beta,
                                 float *d_active_out, void *stream);
+/* ... and of the preconditioned iteration: <R, Z> as the partial sums plx_pcg_apply(d_rz = NULL) left in its d_work
+ * (plx_pcg_rz_partial_rows(n, factor_type) rows of vd floats at float offset plx_pcg_rz_partial_offset(kp)), |R|^2 as
+ * plx_cg_step_update_fused's partial sums; stores rz_new (!= d_rz), rr = |R|^2, beta, active_out; P = Z + beta P. */
+int64_t plx_pcg_rz_partial_offset(int kp);
+int plx_pcg_rz_partial_rows(int64_t n, int factor_type);
+int plx_pcg_step_direction_fused(float *d_p, const float *d_z, const float *d_rz_partial, int nrz, const float *d_rr_partial,
+                                 const float *d_rz, const float *d_active, const float *d_b_norm, float tol, int64_t n, int vd,
+                                 float *d_rz_new, float *d_rr, float *d_beta, float *d_active_out, void *stream);
 int plx_cg_step_direction(float *d_p, const float *d_r, const float *d_rs_new, const float *d_rs, const float *d_active,
                           const float *d_b_norm, float tol, int64_t n, int vd, float *d_beta, float *d_active_out,
                           void *stream);

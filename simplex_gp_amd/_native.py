@@ -71,6 +71,10 @@ _SIGNATURES = {
     "plx_cg_fused_work_floats": (_i64, [_i32]),
     "plx_cg_step_update_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_step_direction_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "plx_pcg_rz_partial_offset": (_i64, [_i32]),
+    "plx_pcg_rz_partial_rows": (_i32, [_i64, _i32]),
+    "plx_pcg_step_direction_fused": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp, _vp,
+                                            _vp]),
     "plx_cg_step_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "plx_cg_step_direction": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),

@@ -235,20 +235,21 @@ __device__ __forceinline__ float4 f4_xor_sum(float4 a)
 
 // column sums of `rows` rows of NCH float4 chunks, by all T threads of the workgroup; result in out[4 NCH] (LDS), valid
 // after the trailing barrier.  wsum: [T / 64][NCH] float4 of LDS scratch.
-template <int NCH, int T>
+template <int NCH, int T, int U>
 __device__ __forceinline__ void block_column_sums(const float4 *__restrict__ part, int rows, float4 *wsum, float *out)
 {
+    // U loads of every thread are in flight together (predicated: no tail loop whose trips wait for each other -- with 8
+    // in flight and a scalar tail the prologue cost the update 8 us and the direction 3.7 us); chunk f belongs to column
+    // group f % NCH, tracked without a division
     const int total = rows * NCH;                          // chunks
     float4 acc[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     int k = (int)threadIdx.x % NCH;                        // chunk-in-row of this thread's current chunk
-    constexpr int U = 8;
-    int f = threadIdx.x;
-    for (; f + (U - 1) * T < total; f += U * T) {
+    for (int f = threadIdx.x; f < total; f += U * T) {
         float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = part[f + u * T];
+        for (int u = 0; u < U; ++u) v[u] = (f + u * T < total) ? part[f + u * T] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -256,13 +257,6 @@ __device__ __forceinline__ void block_column_sums(const float4 *__restrict__ par
                 if (k == j) { acc[j].x += v[u].x; acc[j].y += v[u].y; acc[j].z += v[u].z; acc[j].w += v[u].w; }
             k = (k + T % NCH) % NCH;
         }
-    }
-    for (; f < total; f += T) {
-        const float4 v = part[f];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j)
-            if (k == j) { acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w; }
-        k = (k + T % NCH) % NCH;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -294,7 +288,7 @@ __global__ __launch_bounds__(kFusedThreads) void cg_step_update_fused_kernel(flo
     __shared__ float4 wsum[(T / 64) * NCH];
     __shared__ float pap[4 * NCH], salpha[4 * NCH];
     __shared__ float red[T];
-    block_column_sums<NCH, T>(pap_partial, ntiles, wsum, pap);
+    block_column_sums<NCH, T, 12>(pap_partial, ntiles, wsum, pap);
     if ((int)threadIdx.x < vd) {
         const int c = threadIdx.x;
         const float a = active[c] > 0.f ? rs[c] / fmaxf(pap[c], 1e-30f) : 0.f;
@@ -340,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void cg_step_direction_fused_kernel(float4 
     __shared__ float4 wsum[(kBlock / 64) * NCH];
     __shared__ float rsn[4 * NCH];
     __shared__ float4 sbeta[NCH];
-    block_column_sums<NCH, kBlock>(rs_partial, nparts, wsum, rsn);
+    block_column_sums<NCH, kBlock, NCH>(rs_partial, nparts, wsum, rsn);
     if ((int)threadIdx.x < vd) {
         const int c = threadIdx.x;
         const bool on = active[c] > 0.f;
@@ -359,6 +353,48 @@ __global__ __launch_bounds__(kBlock) void cg_step_direction_fused_kernel(float4 
         const float4 r = R[q];
         float4 p = P[q];
         p.x = r.x + p.x * b.x; p.y = r.y + p.y * b.y; p.z = r.z + p.z * b.z; p.w = r.w + p.w * b.w;
+        P[q] = p;
+    }
+}
+
+// the preconditioned iteration's direction step fed the same way: <R, Z> as the partial sums plx_pcg_apply left behind
+// (nrz rows), |R|^2 as the partial sums of update_fused (kFusedBlocks rows); P = Z + beta P, activity from the TRUE residual
+template <int NCH>
+__global__ __launch_bounds__(kBlock) void pcg_step_direction_fused_kernel(float4 *__restrict__ P, const float4 *__restrict__ Z,
+                                                                          const float4 *__restrict__ rz_partial, int nrz,
+                                                                          const float4 *__restrict__ rr_partial, int nrr,
+                                                                          const float *__restrict__ rz,
+                                                                          const float *__restrict__ active,
+                                                                          const float *__restrict__ b_norm, float tol,
+                                                                          int64_t quads, float *__restrict__ rz_new_out,
+                                                                          float *__restrict__ rr_out, float *__restrict__ beta_out,
+                                                                          float *__restrict__ active_out)
+{
+    constexpr int vd = 4 * NCH;
+    __shared__ float4 wsum[(kBlock / 64) * NCH];
+    __shared__ float rzn[4 * NCH], rr[4 * NCH];
+    __shared__ float4 sbeta[NCH];
+    block_column_sums<NCH, kBlock, 8>(rz_partial, nrz, wsum, rzn);
+    block_column_sums<NCH, kBlock, NCH>(rr_partial, nrr, wsum, rr);
+    if ((int)threadIdx.x < vd) {
+        const int c = threadIdx.x;
+        const bool on = active[c] > 0.f;
+        const float b = on ? rzn[c] / fmaxf(rz[c], 1e-30f) : 0.f;
+        reinterpret_cast<float *>(sbeta)[c] = b;
+        if (blockIdx.x == 0) {
+            rz_new_out[c] = rzn[c];
+            rr_out[c] = rr[c];
+            beta_out[c] = b;
+            active_out[c] = (on && sqrtf(rr[c]) / b_norm[c] > tol) ? 1.f : 0.f;
+        }
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < quads; q += stride) {
+        const float4 b = sbeta[(int)(q % NCH)];
+        const float4 z = Z[q];
+        float4 p = P[q];
+        p.x = z.x + p.x * b.x; p.y = z.y + p.y * b.y; p.z = z.z + p.z * b.z; p.w = z.w + p.w * b.w;
         P[q] = p;
     }
 }
@@ -562,6 +598,43 @@ extern "C" int plx_cg_step_direction_fused(float *d_p, const float *d_r, const f
     case 3: cg_step_direction_fused_kernel<3><<<grid, kBlock, 0, s>>>(p4, r4, w4, kFusedBlocks, d_rs, d_active, d_b_norm, tol, quads, d_rs_new, d_beta, d_active_out); break;
     default: cg_step_direction_fused_kernel<4><<<grid, kBlock, 0, s>>>(p4, r4, w4, kFusedBlocks, d_rs, d_active, d_b_norm, tol, quads, d_rs_new, d_beta, d_active_out); break;
     }
+    PLX_HIP_TRY(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_pcg_step_direction_fused(float *d_p, const float *d_z, const float *d_rz_partial, int nrz,
+                                            const float *d_rr_partial, const float *d_rz, const float *d_active,
+                                            const float *d_b_norm, float tol, int64_t n, int vd, float *d_rz_new, float *d_rr,
+                                            float *d_beta, float *d_active_out, void *stream)
+{
+    if (!d_p || !d_z || !d_rz_partial || !d_rr_partial || !d_rz || !d_active || !d_b_norm || !d_rz_new || !d_rr || !d_beta || !d_active_out) {
+        set_error("plx_pcg_step_direction_fused: NULL argument");
+        return PLX_ERR_INVALID;
+    }
+    if (d_active == d_active_out || d_rz == d_rz_new) { set_error("plx_pcg_step_direction_fused: active / rz and their outputs must be different buffers"); return PLX_ERR_INVALID; }
+    if (n < 0 || nrz < 0 || plx_cg_fused_work_floats(vd) < 0) {
+        set_error("plx_pcg_step_direction_fused: vd = %d is not 4, 8, 12 or 16 (use plx_pcg_step_direction)", vd);
+        return PLX_ERR_INVALID;
+    }
+    if (((reinterpret_cast<uintptr_t>(d_p) | reinterpret_cast<uintptr_t>(d_z) | reinterpret_cast<uintptr_t>(d_rz_partial) |
+          reinterpret_cast<uintptr_t>(d_rr_partial)) & 15) != 0) {
+        set_error("plx_pcg_step_direction_fused: d_p, d_z and the partial sums must be 16-byte aligned");
+        return PLX_ERR_INVALID;
+    }
+    const int64_t quads = n * vd / 4;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(kFusedDirBlocks, ceil_div(quads, kBlock)));
+    hipStream_t s = (hipStream_t)stream;
+    float4 *p4 = reinterpret_cast<float4 *>(d_p);
+    const float4 *z4 = reinterpret_cast<const float4 *>(d_z), *a4 = reinterpret_cast<const float4 *>(d_rz_partial),
+                 *b4 = reinterpret_cast<const float4 *>(d_rr_partial);
+#define PLX_CASE(NCH) pcg_step_direction_fused_kernel<NCH><<<grid, kBlock, 0, s>>>(p4, z4, a4, nrz, b4, kFusedBlocks, d_rz, d_active, d_b_norm, tol, quads, d_rz_new, d_rr, d_beta, d_active_out)
+    switch (vd / 4) {
+    case 1: PLX_CASE(1); break;
+    case 2: PLX_CASE(2); break;
+    case 3: PLX_CASE(3); break;
+    default: PLX_CASE(4); break;
+    }
+#undef PLX_CASE
     PLX_HIP_TRY(hipGetLastError());
     return PLX_OK;
 }

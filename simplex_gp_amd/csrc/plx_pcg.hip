@@ -845,6 +845,14 @@ extern "C" int plx_pcg_apply(const void *d_lt, int factor_type, int64_t ld, int 
     return PLX_OK;
 }
 
+// where plx_pcg_apply(d_rz = NULL) leaves the per-workgroup partial sums of <R, Z>: d_work + offset, `rows` rows of t floats
+extern "C" int64_t plx_pcg_rz_partial_offset(int kp) { return (kp >= 16 && (kp & 15) == 0) ? (int64_t)pcg_gram_floats(kp) : -1; }
+extern "C" int plx_pcg_rz_partial_rows(int64_t n, int factor_type)
+{
+    if (n < 0 || (factor_type != PLX_FACTOR_F16 && factor_type != PLX_FACTOR_F32)) return -1;
+    return ceil_div(n, kBlock * (factor_type == PLX_FACTOR_F16 ? 2 : 1));
+}
+
 extern "C" int plx_pcg_step_direction(float *d_p, const float *d_z, const float *d_rz_new, const float *d_rz,
                                       const float *d_rr, const float *d_active, const float *d_b_norm, float tol, int64_t n,
                                       int vd, float *d_beta, float *d_active_out, void *stream)

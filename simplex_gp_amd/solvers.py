@@ -496,9 +496,36 @@ def _batched_pcg_native(matmul, B, precond, max_iter, tol, want_tridiag, check_e
     alphas = torch.zeros(max_iter if want_tridiag else 1, t, dtype=torch.float32, device=dev)
     betas = torch.zeros(max_iter if want_tridiag else 1, t, dtype=torch.float32, device=dev)
     it = 0
+    # the iteration without its three stand-alone reductions (pAp, |R|^2, <R, Z>): the partial sums are added up inside the
+    # update and the direction kernels (plx_cg_step_update_fused, plx_pcg_step_direction_fused)
+    partial_mm = getattr(matmul_dot, "partial", None) if FUSED_CG_STEPS else None
+    fused = partial_mm is not None and int(lib.plx_cg_fused_work_floats(t)) > 0
+    if fused:
+        fkey = (dev.index, t, "fused")
+        fwork = _dot_work.get(fkey)
+        if fwork is None:
+            fwork = _dot_work[fkey] = torch.empty(int(lib.plx_cg_fused_work_floats(t)), dtype=torch.float32, device=dev)
+        pwork = precond._workspace(t)
+        rz_part = pwork[int(lib.plx_pcg_rz_partial_offset(precond.kp)):]
+        nrz = int(lib.plx_pcg_rz_partial_rows(n, precond.factor_type))
     with torch.cuda.device(dev):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         for it in range(1, max_iter + 1):
+            if fused:
+                AP, pap_part, tiles = partial_mm(P)
+                row = it - 1 if want_tridiag else 0
+                nv.check(lib.plx_cg_step_update_fused(_vp(X), _vp(R), _vp(P), _vp(AP), _vp(rz), _vp(pap_part), tiles, _vp(active), n, t,
+                                                      _vp(alphas[row]), _vp(fwork), stream), "plx_cg_step_update_fused")
+                precond.solve_lattice(R, out=Z, rz=None)              # <R, Z> stays as partial sums in the preconditioner's work buffer
+                step_tol = float(tol) if it >= floor else min(float(tol), _FROZEN_BELOW)
+                nv.check(lib.plx_pcg_step_direction_fused(_vp(P), _vp(Z), _vp(rz_part), nrz, _vp(fwork), _vp(rz), _vp(active), _vp(b_norm),
+                                                          step_tol, n, t, _vp(rz_new), _vp(rr), _vp(betas[row]), _vp(active_next),
+                                                          stream), "plx_pcg_step_direction_fused")
+                rz, rz_new = rz_new, rz
+                active, active_next = active_next, active
+                if tol > 0 and (it % check_every == 0 or it == max_iter) and not bool(active.any()):
+                    break
+                continue
             if matmul_dot is not None:
                 AP, pAp = matmul_dot(P)
                 pAp = pAp.contiguous()

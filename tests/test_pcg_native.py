@@ -181,6 +181,23 @@ def test_native_pcg_matches_torch_pcg(plx):
     assert float((true_h - info_h["residual"]).abs().max()) < 2e-3      # fp32 recurrence drift over 60 ill-conditioned iterations
     ratio = float((info_h["residual"].log() - info_n["residual"].log()).mean().exp())
     assert 0.6 < ratio < 1.6, ratio
+    # round 6: the iteration without its three stand-alone reductions (pAp, |R|^2, <R, Z> added up inside the update and the
+    # direction kernels) against the one with them: the same iteration to rounding, reproducible bit for bit
+    assert solvers.FUSED_CG_STEPS
+    with torch.no_grad():
+        sol_f2, _ = model.khat_solve(x, rhs, K=K, max_iter=60, tol=0.0, precond=pre_n, want_tridiag=True)
+        solvers.FUSED_CG_STEPS = False
+        try:
+            sol_u, info_u = model.khat_solve(x, rhs, K=K, max_iter=60, tol=0.0, precond=pre_n, want_tridiag=True)
+        finally:
+            solvers.FUSED_CG_STEPS = True
+    assert torch.equal(sol_f2, sol_n)
+    assert float((sol_u - sol_n).norm() / sol_n.norm()) < 1e-3
+    assert torch.allclose(info_u["rz0"], info_n["rz0"], rtol=1e-5)
+    Tu = info_u["tridiag"][:, :8, :8]
+    assert float((Tu - Tn).abs().max() / Tn.abs().max()) < 1e-2
+    true_n = (model.khat_matmul(x, K)(sol_n) - rhs).norm(dim=0) / rhs.norm(dim=0)
+    assert float((true_n - info_n["residual"]).abs().max()) < 2e-3        # rr as the fused direction kernel stores it
     plx.lattice_cache().clear()
 
 

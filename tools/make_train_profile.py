@@ -68,6 +68,13 @@ def table(rows, m_fwd, m_bwd, steps, top=34):
 
 r0, rows0 = last_row(log0)
 r100, rows100 = last_row(log100)
+
+
+def two(ms):
+    """(lattice of the forward / solve, lattice of the backward filter): the RBF step runs both on ONE lattice, and since round 6
+    the cache rebuilds that lattice in place when the lengthscale moves, so the log names one."""
+    ms = list(ms or [0])
+    return (ms + ms)[:2] if len(ms) == 1 else ms[-2:]
 prof0 = [x for x in rows0 if "phases_ms" not in x]          # the steps that ran under the profiler (the phase runs are appended to the log)
 prof100 = [x for x in rows100 if "phases_ms" not in x]
 md = f"""# rocprofv3 of the training step ({tag})
@@ -80,16 +87,16 @@ taps, py:113-123; for the RBF profile these are the forward taps, so it runs on 
 different lattices; the table is the mean over the run's steps.  Fractions: SURVEY 8(d) algorithmic bytes / mean launch
 time / 8 TB/s.
 
-## pre_size 0 ({len(prof0)} steps under the profiler; lattices of the last step m = {r0.get('lattices_m')}: the previous step's and this step's)
+## pre_size 0 ({len(prof0)} steps under the profiler; lattice(s) in the cache after the last step m = {r0.get('lattices_m')})
 
 ```
-{table(stats(dir0), *(r0.get('lattices_m') or [0, 0])[:2], len(prof0))}
+{table(stats(dir0), *two(r0.get('lattices_m')), len(prof0))}
 ```
 
 ## pre_size 100 ({len(prof100)} steps under the profiler; m = {r100.get('lattices_m')})
 
 ```
-{table(stats(dir100), *(r100.get('lattices_m') or [0, 0])[:2], len(prof100))}
+{table(stats(dir100), *two(r100.get('lattices_m')), len(prof100))}
 ```
 
 Wall time per step (no profiler; phases from `--steps 3` with the phase synchronisation on):
