@@ -494,6 +494,22 @@ def test_bench_train_step_phases_add_up(plx):
         assert all(v >= 0 for v in leg["phases_ms"].values())
 
 
+def test_cg_iteration_is_ten_launches(plx):
+    """A plain CG iteration of khat_solve at 12 columns is 10 kernel launches (round 5: 12): splat + fix-up, four two-axis blur
+    passes + one single pass at d = 8, slice, update, direction -- the reductions between them run inside the update and the
+    direction kernels.  Counted from HIP-graph captures of a 6- and a 2-iteration solve (bench.cg_launch_leg, the bench
+    line's `config3.launches_per_cg_iteration`); the device is usable afterwards."""
+    import bench
+
+    class Ctx:
+        dev = torch.device("cuda:0")
+
+    out = bench.cg_launch_leg(Ctx, n=150_000, d=8)
+    assert out is not None, "the CG iteration could not be captured into a HIP graph"
+    assert out["kernels"] == out["graph_nodes"] == 10.0, out
+    assert float(torch.ones(8, device="cuda").sum()) == 8.0
+
+
 @pytest.mark.parametrize("name,n,d", [("houseelectric (10 % of its rows)", 204_928, 11), ("precipitation", 628_474, 3),
                                       ("keggdirected", 48_827, 20), ("elevators", 16_599, 17), ("protein", 45_730, 9)])
 def test_published_shapes_against_the_oracle(plx, name, n, d):
