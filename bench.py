@@ -493,13 +493,17 @@ def config3_leg(ctx, n=1_000_000, d=8, iters=50):
     best, best_warm, best_rebuild, res, m = float("inf"), float("inf"), float("inf"), None, None
     with torch.no_grad():
         for trial in range(4):
-            # a COLD build: nothing of an earlier lattice on these points is reused (the cache is emptied, so the lattice is
-            # a fresh object and its point order is computed from the positions) -- the figure of rounds 1-5
-            plx.lattice_cache().clear()
+            # a COLD build: the point order is computed from the positions (the cache's warm start is switched off for this
+            # solve; the lattice OBJECT is the recycled one, as in rounds 1-5: its buffers exist) -- the figure of rounds 1-5
+            from simplex_gp_amd import lattice_kernel as lk
+            saved_age, lk.MAX_ORDER_AGE = lk.MAX_ORDER_AGE, 0
             model.kernel.lengthscale = 0.6931 * (1 + 1e-5 * trial)
             ctx.sync()
             t0 = time.perf_counter()
-            _, info = model.khat_solve(x, rhs, max_iter=iters, tol=0.0)
+            try:
+                _, info = model.khat_solve(x, rhs, max_iter=iters, tol=0.0)
+            finally:
+                lk.MAX_ORDER_AGE = saved_age
             ctx.sync()
             dt = time.perf_counter() - t0
             t1 = time.perf_counter()

@@ -498,7 +498,7 @@ def _batched_pcg_native(matmul, B, precond, max_iter, tol, want_tridiag, check_e
     it = 0
     # the iteration without its three stand-alone reductions (pAp, |R|^2, <R, Z>): the partial sums are added up inside the
     # update and the direction kernels (plx_cg_step_update_fused, plx_pcg_step_direction_fused)
-    partial_mm = getattr(matmul_dot, "partial", None) if FUSED_CG_STEPS else None
+    partial_mm = getattr(matmul_dot, "partial", None) if _fuse_cg_steps(n) else None
     fused = partial_mm is not None and int(lib.plx_cg_fused_work_floats(t)) > 0
     if fused:
         fkey = (dev.index, t, "fused")
@@ -632,7 +632,19 @@ def batched_cg(matmul, B, max_iter=1000, tol=1e-4, reduce=None, want_tridiag=Fal
     return X, info
 
 
-FUSED_CG_STEPS = True      # False: every CG iteration runs its reductions as stand-alone launches (A/B, tests)
+# The column reductions of a CG iteration (<P, AP>, |R|^2, and <R, Z> of a preconditioned one) inside the update / direction
+# kernels (plx_cg_step_*_fused: 10 launches per plain iteration instead of 12, 12 per preconditioned one instead of 15): True
+# always, False never, "auto" = while the vectors have at most FUSED_CG_MAX_ROWS rows.  Measured interleaved
+# (tools/ab_cg_steps_r6.py, 50 iterations at 12 columns, ms fused / stand-alone): N = 2e4, d = 4: 2.03 / 2.28; N = 10,623, d = 18:
+# 4.88 / 4.98 (rank-100 preconditioner: 6.72 / 6.88); N = 1e5: 2.82 / 2.81; N = 3e5: 12.33 / 12.35; N = 1e6: 28.57 / 28.48
+# (preconditioned 35.97 / 35.81): the fold pays where an iteration is launch-bound and costs 0.3-0.5 % where each workgroup's
+# redundant sum over the partials (0.56 MB at N = 1e6) outweighs two 7 us launches.
+FUSED_CG_STEPS = "auto"
+FUSED_CG_MAX_ROWS = 65536
+
+
+def _fuse_cg_steps(n):
+    return FUSED_CG_STEPS is True or (FUSED_CG_STEPS == "auto" and n <= FUSED_CG_MAX_ROWS)
 
 
 def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matmul_dot=None, floor=0):
@@ -663,7 +675,7 @@ def _batched_cg_native(matmul, B, max_iter, tol, want_tridiag, check_every, matm
     it = 0
     # the iteration without its two stand-alone reductions (plx_cg_step_*_fused): rows of whole 16-byte chunks, and an
     # MVM that can leave its <P, AP> partial sums un-reduced (matmul_dot.partial)
-    partial_mm = getattr(matmul_dot, "partial", None) if FUSED_CG_STEPS else None
+    partial_mm = getattr(matmul_dot, "partial", None) if _fuse_cg_steps(n) else None
     fused = partial_mm is not None and int(lib.plx_cg_fused_work_floats(t)) > 0
     if fused:
         fkey = (dev.index, t, "fused")

@@ -494,19 +494,25 @@ def test_bench_train_step_phases_add_up(plx):
         assert all(v >= 0 for v in leg["phases_ms"].values())
 
 
-def test_cg_iteration_is_ten_launches(plx):
-    """A plain CG iteration of khat_solve at 12 columns is 10 kernel launches (round 5: 12): splat + fix-up, four two-axis blur
-    passes + one single pass at d = 8, slice, update, direction -- the reductions between them run inside the update and the
-    direction kernels.  Counted from HIP-graph captures of a 6- and a 2-iteration solve (bench.cg_launch_leg, the bench
-    line's `config3.launches_per_cg_iteration`); the device is usable afterwards."""
+def test_cg_iteration_launch_counts(plx):
+    """A plain CG iteration of khat_solve at 12 columns, d = 8: splat + fix-up, four two-axis blur passes + one single pass,
+    slice, update, direction = 10 kernel launches when the column reductions run inside the update and the direction kernels
+    (round 6; what solvers does by itself up to FUSED_CG_MAX_ROWS rows, where an iteration is launch-bound), 12 with the two
+    stand-alone reductions (above that: measured neutral to 0.5 % slower at N >= 1e5, tools/ab_cg_steps_r6.py).  Counted from
+    HIP-graph captures of a 6- and a 2-iteration solve (bench.cg_launch_leg, the bench line's
+    `config3.launches_per_cg_iteration`); the device is usable afterwards."""
     import bench
+    from simplex_gp_amd import solvers
 
     class Ctx:
         dev = torch.device("cuda:0")
 
-    out = bench.cg_launch_leg(Ctx, n=150_000, d=8)
-    assert out is not None, "the CG iteration could not be captured into a HIP graph"
-    assert out["kernels"] == out["graph_nodes"] == 10.0, out
+    assert solvers.FUSED_CG_STEPS == "auto"
+    small = bench.cg_launch_leg(Ctx, n=50_000, d=8)
+    large = bench.cg_launch_leg(Ctx, n=150_000, d=8)
+    assert small is not None and large is not None, "the CG iteration could not be captured into a HIP graph"
+    assert small["kernels"] == small["graph_nodes"] == 10.0, small
+    assert large["kernels"] == large["graph_nodes"] == 12.0, large
     assert float(torch.ones(8, device="cuda").sum()) == 8.0
 
 

@@ -690,15 +690,17 @@ def test_cg_iteration_without_standalone_reductions(plx, t):
         return lat.apply_affine(W, ss, want_dot=True)
     mm_dot.partial = lambda W: lat.apply_affine(W, ss, want_dot="partial")
     mm = lambda W: lat.apply_affine(W, ss)       # noqa: E731
-    assert solvers.FUSED_CG_STEPS
-    Xf, inf_f = solvers.batched_cg(mm, V, max_iter=20, tol=1e-6, want_tridiag=True, check_every=1, matmul_dot=mm_dot)
-    Xf2, _ = solvers.batched_cg(mm, V, max_iter=20, tol=1e-6, want_tridiag=True, check_every=1, matmul_dot=mm_dot)
-    assert torch.equal(Xf, Xf2)                                            # fixed summation orders: reproducible
-    solvers.FUSED_CG_STEPS = False
+    default = solvers.FUSED_CG_STEPS
+    assert default == "auto" and solvers._fuse_cg_steps(n) and not solvers._fuse_cg_steps(1_000_000)
     try:
+        solvers.FUSED_CG_STEPS = True
+        Xf, inf_f = solvers.batched_cg(mm, V, max_iter=20, tol=1e-6, want_tridiag=True, check_every=1, matmul_dot=mm_dot)
+        Xf2, _ = solvers.batched_cg(mm, V, max_iter=20, tol=1e-6, want_tridiag=True, check_every=1, matmul_dot=mm_dot)
+        assert torch.equal(Xf, Xf2)                                        # fixed summation orders: reproducible
+        solvers.FUSED_CG_STEPS = False
         Xu, inf_u = solvers.batched_cg(mm, V, max_iter=20, tol=1e-6, want_tridiag=True, check_every=1, matmul_dot=mm_dot)
     finally:
-        solvers.FUSED_CG_STEPS = True
+        solvers.FUSED_CG_STEPS = default
     # (two fp32 CG runs whose dot products are associated differently drift apart like cond(A) x eps x iterations: 6.5e-4
     # measured here at 20 iterations of an unconverged solve; what must hold is that neither is the worse solution -- the
     # true residuals below -- and that the quadrature agrees)

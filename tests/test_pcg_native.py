@@ -183,14 +183,16 @@ def test_native_pcg_matches_torch_pcg(plx):
     assert 0.6 < ratio < 1.6, ratio
     # round 6: the iteration without its three stand-alone reductions (pAp, |R|^2, <R, Z> added up inside the update and the
     # direction kernels) against the one with them: the same iteration to rounding, reproducible bit for bit
-    assert solvers.FUSED_CG_STEPS
+    default = solvers.FUSED_CG_STEPS
+    assert default == "auto" and solvers._fuse_cg_steps(n)                 # (30,000 rows: the fold is on by itself)
     with torch.no_grad():
-        sol_f2, _ = model.khat_solve(x, rhs, K=K, max_iter=60, tol=0.0, precond=pre_n, want_tridiag=True)
-        solvers.FUSED_CG_STEPS = False
         try:
+            solvers.FUSED_CG_STEPS = True
+            sol_f2, _ = model.khat_solve(x, rhs, K=K, max_iter=60, tol=0.0, precond=pre_n, want_tridiag=True)
+            solvers.FUSED_CG_STEPS = False
             sol_u, info_u = model.khat_solve(x, rhs, K=K, max_iter=60, tol=0.0, precond=pre_n, want_tridiag=True)
         finally:
-            solvers.FUSED_CG_STEPS = True
+            solvers.FUSED_CG_STEPS = default
     assert torch.equal(sol_f2, sol_n)
     assert float((sol_u - sol_n).norm() / sol_n.norm()) < 1e-3
     assert torch.allclose(info_u["rz0"], info_n["rz0"], rtol=1e-5)

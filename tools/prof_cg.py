@@ -19,13 +19,16 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--ell", type=float, default=0.6931)
     ap.add_argument("--tune", nargs="*", default=[])
-    ap.add_argument("--no-fused-steps", action="store_true", help="the CG iteration with its two stand-alone reductions (round 5)")
+    ap.add_argument("--no-fused-steps", action="store_true", help="the CG iteration with its two stand-alone reductions (what solvers does by itself above FUSED_CG_MAX_ROWS rows)")
+    ap.add_argument("--fused-steps", action="store_true", help="the reductions inside the update / direction kernels at any size")
     args = ap.parse_args()
     import torch
     import simplex_gp_amd as plx
     from simplex_gp_amd import solvers, _native as nv
     if args.no_fused_steps:
         solvers.FUSED_CG_STEPS = False
+    if args.fused_steps:
+        solvers.FUSED_CG_STEPS = True
     for kv in args.tune:
         k, v = kv.split("=")
         nv.check(nv.lib().plx_tune(k.encode(), int(v)), "plx_tune")
