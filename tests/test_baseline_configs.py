@@ -256,13 +256,19 @@ def test_config5_matern_order3_d18(plx):
     assert abs(np.linalg.norm(got2.astype(np.float64)) / float(z[f"{key}/out_l2"]) - 1) <= max(1e-4, quirk + 1e-5)
     lat.close()
     model = solvers.LatticeGP(k, min_noise=0.1).cuda()
-    history, _ = training.fit(model, (x.cuda(), y.cuda()), epochs=12, lr=0.1, num_probes=10, cg_iter=500, cg_tol=1.0,
-                              pre_size=100)          # the recipe of configs/simplexgp.yml
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    history, _ = training.fit(model, (x.cuda(), y.cuda()), epochs=100, lr=0.1, num_probes=10, cg_iter=500, cg_tol=1.0,
+                              pre_size=100)          # the recipe of configs/simplexgp.yml, all of its 100 epochs (round 6; 12 before)
+    torch.cuda.synchronize()
     mll = np.array([h["train/mll"] for h in history])
-    print("config 5 stand-in: train/mll per epoch", np.round(mll, 4))
-    assert len(mll) == 12 and np.isfinite(mll).all()
-    assert mll[-3:].mean() > mll[:3].mean() + 0.01          # -MLL falls
-    assert (np.diff(mll) > -0.05).all()                      # no epoch undoes the progress (probe noise only)
+    print("config 5 stand-in: 100 epochs in %.2f s; train/mll every 10th epoch" % (time.perf_counter() - t0), np.round(mll[::10], 4),
+          "last", round(float(mll[-1]), 4), "lengthscale range", float(model.kernel.lengthscale.detach().min()), float(model.kernel.lengthscale.detach().max()))
+    assert len(mll) == 100 and np.isfinite(mll).all()
+    assert mll[:12][-3:].mean() > mll[:3].mean() + 0.01    # -MLL falls from the start (the round-5 assertion on the first 12 epochs)
+    assert mll[-10:].mean() > mll[:3].mean() + 0.05         # ... and keeps the ground it gained over the whole run
+    assert (np.diff(mll) > -0.1).all()                       # no epoch undoes the progress (probe noise and Adam's overshoot only)
 
 
 def test_predict_matches_dense_formulas_on_gpu(plx):
