@@ -204,7 +204,11 @@ def roofline_for(lat, kt, n, d, m, vd, r, ell=1.0):
     roof = {
         "bound": "hbm", "stage": dom, "kernel": " + ".join(names[dom]), "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-        "traffic": pmc["bytes"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,
+        "traffic": pmc["bytes"] if pmc else None,
+        # (a PMC table is only quoted for the kernel sources it was collected on: an edited source says so here instead of
+        # turning the figure into a silent null)
+        "traffic_source": pmc["source"] if pmc else ("none: no profiles/*_pmc.json was collected on these kernel sources (sha16 %s); "
+                                                     "run tools/run_profiles.sh" % kernel_sources_sha16()),
         "stage_event_scale": kt.get("event_overhead_scale"),
         "bytes_per_launch": int(ab[dom]), "launch_us": round(launch_ms * 1e3, 2),
         "launches_per_mvm": (d + 1) if dom == "blur_axis" else 1,
