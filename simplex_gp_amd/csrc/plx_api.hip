@@ -78,7 +78,7 @@ void release(DevBuf &b)
 static std::vector<DevBuf *> all_bufs(plx_lattice *L)
 {
     return {&L->eslot, &L->flagmask, &L->blockcnt, &L->table, &L->counters,
-            &L->sort_keys_in, &L->slotmap, &L->nibmap, &L->prank, &L->vaxis, &L->vs0, &L->vowner, &L->ew_splat, &L->replay_vat, &L->replay_list, &L->replay_invisible, &L->replay_keys, &L->oh_pos, &L->oh_list, &L->oh_cnt, &L->ex_vid, &L->ex_pt, &L->ex_w, &L->ex_keys, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
+            &L->sort_keys_in, &L->slotmap, &L->nibmap, &L->prank, &L->vaxis, &L->vs0, &L->vowner, &L->ew_splat, &L->replay_vat, &L->replay_list, &L->replay_invisible, &L->replay_keys, &L->active_list, &L->active_cnt, &L->oh_pos, &L->oh_list, &L->oh_cnt, &L->ex_vid, &L->ex_pt, &L->ex_w, &L->ex_keys, &L->sort_vals_in, &L->sort_vals_out, &L->sort_temp,
             &L->vkeys, &L->ew, &L->evid, &L->nbr, &L->csr_pt, &L->csr_row, &L->csr_w, &L->csr_vid, &L->row_ptr,
             &L->head_partial, &L->tail_partial, &L->val_a, &L->val_b, &L->ssrc, &L->rec, &L->perm, &L->iota, &L->cmask, &L->cbase, &L->cids, &L->merge_slot, &L->merge_flags,
             &L->sortkey_in, &L->sortkey_out,

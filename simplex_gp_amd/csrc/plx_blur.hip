@@ -348,6 +348,7 @@ int build_blur_pairs(plx_lattice *L, hipStream_t stream)
 {
     L->use_pairs = false;
     L->pairs_ready = false;
+    L->active_ready = false;      // (every build passes here: the active-row lists belong to the previous neighbour table)
     const int d1 = L->d + 1, m = (int)L->m;
     if (g_blur_fuse == 0 || L->order != 1 || d1 < 2 || m == 0) return PLX_OK;
     if (g_blur_fuse == 1 && (m > kPairMaxVertices || L->single_use)) return PLX_OK;
@@ -534,6 +535,176 @@ __global__ __launch_bounds__(kBlock) void blur_axis_multi_kernel(const float4 *_
     }
 }
 
+// ----------------------------------------------------------------------------
+// Wide rows on SPARSE lattices (round 6).  The taps of every kernel profile are normalised to a centre tap of exactly 1
+// (py:19-28: vals / vals[r]), so a vertex without a neighbour on the pass' axis keeps its row: new = 0 + 1 * old.  On the
+// lattices of the high-dimensional data sets every point sits in a simplex of its own (m = n (d + 1)); along one axis
+// exactly two of a simplex's d + 1 vertices are neighbours of each other, i.e. 2 / (d + 1) of the rows change (10.5 % at
+// d = 18; 24 % at N = 1e6, d = 8, l = 0.25) while blur_axis_multi_kernel streams all of them in and out: the 418-column
+// backward filter of the config-5 stand-in spent 19 x 243 us = 4.6 of its 6.0 ms there.  Here a pass works IN PLACE on the
+// rows that change: (1) one wave per listed vertex forms its new row -- the dense kernel's operations in the dense kernel's
+// order: lower taps, centre, upper taps, from zero -- into the scratch buffer at the vertex' place in the list (every row
+// is read before any is written: Jacobi), (2) the rows go back to their vertices.  Rows of vertices that are not listed
+// are bit for bit what the dense pass writes (up to the sign of a zero: 0 + 1 * (-0) = +0).  The lists are built by the
+// first wide blur that qualifies (ensure_active_lists: ordered compaction, one read-back of the d + 1 counts).
+constexpr double kActiveShare = 0.35;      // use the lists while at most this share of the vertices changes per axis (mean over the axes)
+
+__device__ __forceinline__ bool has_neighbour(const int *__restrict__ nb, int64_t mstride, int taps2, int v)
+{
+    bool any = false;
+    for (int s = 0; s < taps2; ++s) any = any || nb[(size_t)s * mstride + v] >= 0;
+    return any;
+}
+
+// counts[axis][block] = vertices of the block with a neighbour on the axis
+__global__ __launch_bounds__(kBlock) void active_count_kernel(const int *__restrict__ nbr, int m, int64_t mstride, int taps2,
+                                                              int nblocks, int *__restrict__ counts)
+{
+    __shared__ int wsum[kBlock / 64];
+    const int v = blockIdx.x * kBlock + threadIdx.x, axis = blockIdx.y;
+    const int *nb = nbr + (size_t)axis * taps2 * mstride;
+    const bool on = v < m && has_neighbour(nb, mstride, taps2, v);
+    const int c = __popcll(__ballot(on));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += wsum[w];
+        counts[(size_t)axis * nblocks + blockIdx.x] = t;
+    }
+}
+
+// one workgroup per axis: counts -> exclusive offsets within the axis; totals[axis] = its sum
+__global__ __launch_bounds__(1024) void active_scan_kernel(int *__restrict__ counts, int nblocks, int *__restrict__ totals)
+{
+    __shared__ int wsum[16];
+    int *row = counts + (size_t)blockIdx.x * nblocks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {           // same trip count in every thread
+        const int b = b0 + threadIdx.x;
+        const int val = b < nblocks ? row[b] : 0;
+        const int incl = wave_inclusive_sum(val);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int sw = wsum[w]; if (w < wave) before += sw; tot += sw; }
+        __syncthreads();
+        if (b < nblocks) row[b] = carry + before + incl - val;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+// list[off[axis] + counts[axis][block] + rank in the block] = v   (ascending within an axis)
+struct ActiveOffsets { long long off[PLX_MAX_DIM + 2]; };
+__global__ __launch_bounds__(kBlock) void active_fill_kernel(const int *__restrict__ nbr, int m, int64_t mstride, int taps2,
+                                                             int nblocks, const int *__restrict__ counts, ActiveOffsets ao,
+                                                             int *__restrict__ list)
+{
+    __shared__ int wsum[kBlock / 64];
+    const int v = blockIdx.x * kBlock + threadIdx.x, axis = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int *nb = nbr + (size_t)axis * taps2 * mstride;
+    const bool on = v < m && has_neighbour(nb, mstride, taps2, v);
+    const unsigned long long mask = __ballot(on);
+    if (lane == 0) wsum[wave] = __popcll(mask);
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (on) {
+        const int rank = before + __popcll(mask & ((1ull << lane) - 1ull));
+        list[ao.off[axis] + counts[(size_t)axis * nblocks + blockIdx.x] + rank] = v;
+    }
+}
+
+int ensure_active_lists(plx_lattice *L, hipStream_t stream)
+{
+    if (L->active_ready) return PLX_OK;
+    PLX_TRY(refuse_under_capture(stream, "the active-row lists of this lattice's wide blur"));
+    const int d1 = L->d + 1, m = (int)L->m, taps2 = 2 * L->order;
+    const int nblocks = ceil_div(m, kBlock);
+    PLX_TRY(ensure(L->active_cnt, (size_t)d1 * nblocks * 4 + 64));
+    int *totals = L->counters.as<int>() + 2;        // (the build's counters are free between builds: d + 1 <= 33 ints)
+    active_count_kernel<<<dim3(nblocks, d1), kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, taps2, nblocks, L->active_cnt.as<int>());
+    active_scan_kernel<<<d1, 1024, 0, stream>>>(L->active_cnt.as<int>(), nblocks, totals);
+    int h_tot[PLX_MAX_DIM + 1];
+    PLX_TRY(read_back(L, totals, d1, h_tot, stream));
+    ActiveOffsets ao;
+    int64_t total = 0, longest = 0;
+    for (int a = 0; a < d1; ++a) {
+        ao.off[a] = total; L->active_off[a] = total;
+        total += h_tot[a];
+        longest = std::max<int64_t>(longest, h_tot[a]);
+    }
+    ao.off[d1] = total; L->active_off[d1] = total;
+    L->active_max = longest;
+    PLX_TRY(ensure(L->active_list, (size_t)total * 4 + 64));
+    if (total > 0)
+        active_fill_kernel<<<dim3(nblocks, d1), kBlock, 0, stream>>>(L->nbr.as<int>(), m, L->mstride, taps2, nblocks,
+                                                                     L->active_cnt.as<int>(), ao, L->active_list.as<int>());
+    PLX_HIP_TRY(hipGetLastError());
+    L->active_ready = true;
+    return PLX_OK;
+}
+
+// (1) tmp[k] = the new row of vertex list[k]: one wave per listed vertex, lanes over the 16-byte chunks of the row
+template <int ORDER, int MAXCH>
+__global__ __launch_bounds__(kBlock) void blur_active_rows_kernel(const float4 *__restrict__ old, float4 *__restrict__ tmp,
+                                                                  const int *__restrict__ nbr, const int *__restrict__ list,
+                                                                  int count, int64_t mstride, int nch, TapArgs taps)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (k >= count) return;                         // whole waves leave together
+    const int v = __builtin_amdgcn_readfirstlane(list[k]);
+    int nb[2 * ORDER];
+#pragma unroll
+    for (int s = 0; s < 2 * ORDER; ++s) nb[s] = __builtin_amdgcn_readfirstlane(nbr[(size_t)s * mstride + v]);
+    float4 c[MAXCH], g[2 * ORDER][MAXCH];
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) c[q] = (lane + 64 * q < nch) ? old[(size_t)v * nch + lane + 64 * q] : f4_zero();
+#pragma unroll
+    for (int s = 0; s < 2 * ORDER; ++s)
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q)
+            g[s][q] = (nb[s] >= 0 && lane + 64 * q < nch) ? old[(size_t)nb[s] * nch + lane + 64 * q] : f4_zero();   // (wave-uniform: an absent neighbour issues nothing)
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        float4 acc = f4_zero();
+#pragma unroll
+        for (int s = 0; s < ORDER; ++s)
+            if (nb[s] >= 0) acc = f4_add(acc, f4_scale(taps.c[s], g[s][q]));
+        acc = f4_add(acc, f4_scale(taps.c[ORDER], c[q]));
+#pragma unroll
+        for (int s = 0; s < ORDER; ++s)
+            if (nb[ORDER + s] >= 0) acc = f4_add(acc, f4_scale(taps.c[ORDER + 1 + s], g[ORDER + s][q]));
+        if (lane + 64 * q < nch) tmp[(size_t)k * nch + lane + 64 * q] = acc;
+    }
+}
+
+// (2) values[list[k]] = tmp[k]
+__global__ __launch_bounds__(kBlock) void blur_active_store_kernel(const float4 *__restrict__ tmp, float4 *__restrict__ values,
+                                                                   const int *__restrict__ list, int count, int nch)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (k >= count) return;
+    const int v = __builtin_amdgcn_readfirstlane(list[k]);
+    for (int ch = lane; ch < nch; ch += 64) values[(size_t)v * nch + ch] = tmp[(size_t)k * nch + ch];
+}
+
+template <int ORDER>
+static void launch_blur_active(const float4 *cur, float4 *tmp, const int *nb, const int *list, int count, int64_t mstride, int nch,
+                               const TapArgs &taps, hipStream_t stream)
+{
+    if (count <= 0) return;
+    const int grid = ceil_div(count, kBlock / 64);
+    if (nch <= 64) blur_active_rows_kernel<ORDER, 1><<<grid, kBlock, 0, stream>>>(cur, tmp, nb, list, count, mstride, nch, taps);
+    else blur_active_rows_kernel<ORDER, 2><<<grid, kBlock, 0, stream>>>(cur, tmp, nb, list, count, mstride, nch, taps);
+    blur_active_store_kernel<<<grid, kBlock, 0, stream>>>(tmp, const_cast<float4 *>(cur), list, count, nch);
+}
+
 template <int ORDER>
 static void launch_blur_v1(const float *cur, float *nxt, const int *nb, int m, int64_t mstride, const TapArgs &taps,
                            hipStream_t stream)
@@ -591,8 +762,31 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
     const bool pair_vec = !nocentre && vd > 1 && order == 1 && g_blur_fuse_vec != 0 && !(L->single_use && !L->pairs_ready) && g_blur_narrow && vdp / 4 >= 2 && vdp / 4 <= 4 &&
                           d1 >= 2 && m > 0 && (int64_t)8 * L->mstride < (1ll << 32);
     if (pair_vec) PLX_TRY(ensure_blur_pairs(L, stream));
+    // wide rows on a sparse lattice whose centre tap is 1: only the rows that change, in place (see blur_active_rows_kernel)
+    bool active = false;
+    if (!nocentre && g_blur_active != 0 && g_blur_multi && order >= 1 && order <= 3 && vd > 1 && vdp / 4 >= 32 && vdp / 4 <= 128 &&
+        L->taps.c[order] == 1.0f && m > 0) {
+        // (cheap gate before the lists exist: the lattices in question have nearly as many vertices as corners)
+        if (g_blur_active == 2 || (double)m >= 0.75 * (double)L->n * d1) {
+            PLX_TRY(ensure_active_lists(L, stream));
+            active = g_blur_active == 2 || (double)L->active_off[d1] <= kActiveShare * (double)m * d1;
+        }
+    }
     for (int axis = 0; axis < d1; ++axis) {
         const int *nb = L->nbr.as<int>() + (size_t)axis * 2 * order * L->mstride;
+        if (active) {
+            const int *list = L->active_list.as<int>() + L->active_off[axis];
+            const int count = (int)(L->active_off[axis + 1] - L->active_off[axis]);
+            const float4 *c4 = reinterpret_cast<const float4 *>(cur);
+            float4 *t4 = reinterpret_cast<float4 *>(nxt);
+            switch (order) {
+            case 1: launch_blur_active<1>(c4, t4, nb, list, count, L->mstride, vdp / 4, L->taps, stream); break;
+            case 2: launch_blur_active<2>(c4, t4, nb, list, count, L->mstride, vdp / 4, L->taps, stream); break;
+            default: launch_blur_active<3>(c4, t4, nb, list, count, L->mstride, vdp / 4, L->taps, stream); break;
+            }
+            L->kn_blur = "blur_active_rows_kernel+blur_active_store_kernel";
+            continue;                               // in place: no ping-pong swap
+        }
         const int pair = pair_at_axis(d1, axis);
         if (pair_vec && pair >= 0) {
             const int *pn = L->pair_nbr.as<int>() + (size_t)pair * 8 * L->mstride;

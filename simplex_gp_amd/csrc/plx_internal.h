@@ -82,6 +82,7 @@ struct Tune {
     int blk_sort = 15;   // per-block LDS sort of the block tables: 0 = (vertex, corner) pairs, 4 bits per pass; 4 / 5 / 6 = corner index packed under the vertex id, keys only, that many bits per pass, 256 threads; 15 = 5 bits with 512 threads
     int assign_evid = 1;   // the numbering pass stores the vertex id of every first-touch corner itself when the numbering is final; the id lookup then serves the other corners only
     int nbr_seed = 1;   // sliced neighbour lookups: the +1 neighbour that is a corner of the vertex's own first-touch simplex comes from the embedding, no lookup
+    int blur_active = 1;   // wide rows on sparse lattices (centre tap 1): a blur pass touches only the vertices that have a neighbour on its axis, in place (0 never, 1 when under kActiveShare of the vertices are, 2 whenever representable)
     int contract_v = 1;   // fused backward, slice + contraction: 1 = corner count compiled in (all rows in flight, all-lane contraction), 0 = the run-time form
     int splat_first = 1;   // vd = 1 splat on lattices where almost every corner owns its vertex: first-touch corners store, the rest add (0 never, 1 when m >= 0.9 nnz, 2 whenever representable, 3 = 2 without the contiguous-range store)
     // diagnostic ablations: the members always exist (one layout for both libraries), but only libplx_diag.so knows
@@ -133,6 +134,7 @@ extern thread_local const Tune *tl_tune;   // the snapshot of the lattice this t
 #define g_nbr_seed (plx::tl_tune->nbr_seed)
 #define g_nbr_sliced (plx::tl_tune->nbr_sliced)
 #define g_contract_v (plx::tl_tune->contract_v)
+#define g_blur_active (plx::tl_tune->blur_active)
 #define g_splat_ablate (plx::tl_tune->splat_ablate)
 #define g_blur_ablate (plx::tl_tune->blur_ablate)
 #define g_block_ablate (plx::tl_tune->block_ablate)
@@ -213,6 +215,13 @@ struct plx_lattice {
     plx::DevBuf cmask;      // uint32 [d+1][nquads]
     plx::DevBuf cbase;      // uint32 [d+1][nqwaves + 1]
     plx::DevBuf cids;       // int32  [total existing neighbours]
+    // sparse lattices, wide rows (plx_blur.hip, round 6): per axis the vertices that have at least one neighbour on it -- the
+    // only rows a pass changes when the centre tap is 1
+    bool active_ready = false;
+    int64_t active_off[PLX_MAX_DIM + 2] = {};    // first entry of each axis in active_list; [d+1] = total
+    int64_t active_max = 0;                      // longest per-axis list
+    plx::DevBuf active_list;                     // int32 [active_off[d+1]] vertex ids, ascending within an axis
+    plx::DevBuf active_cnt;                      // int32 [d+1][blocks] per-block counts -> exclusive offsets
     bool pairs_ready = false, use_pairs = false;      // pair_nbr holds the composite neighbours of the axis pairs (0,1), (2,3), ... (plx_blur.hip)
     plx::DevBuf pair_nbr;   // int32  [(d+1)/2][8][mstride]  nbr_i(nbr_j(v, b), a) without the centre; -1 absent
     plx::DevBuf csr_pt;     // int32  [nnz]          local (owned) point index, sorted by vertex

@@ -17,7 +17,7 @@ const Tunable *tunables()
                                 {"blur_narrow", &Tune::blur_narrow}, {"splat_group", &Tune::splat_group}, {"splat_direct", &Tune::splat_direct},
                                 {"splat_wide", &Tune::splat_wide}, {"block_path", &Tune::block_path}, {"block_e", &Tune::block_e},
                                 {"block_dense_combine", &Tune::block_dense_combine}, {"blur_fuse", &Tune::blur_fuse}, {"blur_fuse_vec", &Tune::blur_fuse_vec},
-                                {"nbr_bitmap", &Tune::nbr_bitmap}, {"nbr_window", &Tune::nbr_window}, {"perm_rows", &Tune::perm_rows}, {"splat_first", &Tune::splat_first}, {"blk_sort", &Tune::blk_sort}, {"reference_growth", &Tune::reference_growth}, {"embed_vrange", &Tune::embed_vrange}, {"order_sample", &Tune::order_sample}, {"insert_xcd", &Tune::insert_xcd}, {"assign_evid", &Tune::assign_evid}, {"nbr_seed", &Tune::nbr_seed}, {"nbr_sliced", &Tune::nbr_sliced}, {"scatter_store", &Tune::scatter_store}, {"unpermute_gather", &Tune::unpermute_gather}, {"contract_v", &Tune::contract_v},
+                                {"nbr_bitmap", &Tune::nbr_bitmap}, {"nbr_window", &Tune::nbr_window}, {"perm_rows", &Tune::perm_rows}, {"splat_first", &Tune::splat_first}, {"blk_sort", &Tune::blk_sort}, {"reference_growth", &Tune::reference_growth}, {"embed_vrange", &Tune::embed_vrange}, {"order_sample", &Tune::order_sample}, {"insert_xcd", &Tune::insert_xcd}, {"assign_evid", &Tune::assign_evid}, {"nbr_seed", &Tune::nbr_seed}, {"nbr_sliced", &Tune::nbr_sliced}, {"scatter_store", &Tune::scatter_store}, {"unpermute_gather", &Tune::unpermute_gather}, {"contract_v", &Tune::contract_v}, {"blur_active", &Tune::blur_active},
 #ifdef PLX_DIAG
                                 {"splat_ablate", &Tune::splat_ablate}, {"blur_ablate", &Tune::blur_ablate}, {"block_ablate", &Tune::block_ablate},
 #endif

@@ -329,8 +329,12 @@ class Lattice:
         _check_f32_cuda(values, "values")
         vd = values.shape[1] if vd is None else vd
         assert values.shape[1] == self.values_stride(vd) and values.is_contiguous()
+        if values.shape[0] < self.m:
+            raise ValueError(f"values has {values.shape[0]} rows, the lattice {self.m} vertices")
         if scratch is None:
             scratch = torch.empty_like(values)
+        elif scratch.numel() < values.numel() or not scratch.is_contiguous():
+            raise ValueError("scratch must be a contiguous buffer at least as large as values")
         flag = ctypes.c_int(0)
         with torch.cuda.device(self.device):
             rc = nv.lib().plx_blur(self._h, ctypes.c_void_p(values.data_ptr()),

@@ -717,6 +717,70 @@ def test_cg_iteration_without_standalone_reductions(plx, t):
     lat.close()
 
 
+@pytest.mark.parametrize("n,d,ell,order,vd", [(3000, 18, 1.0, 3, 418), (3000, 18, 1.0, 1, 130), (20000, 8, 0.2, 1, 198),
+                                              (20000, 8, 0.2, 2, 256), (5000, 12, 0.5, 3, 500), (40000, 4, 0.05, 1, 126)])
+def test_wide_blur_on_active_rows_equals_the_dense_passes(plx, n, d, ell, order, vd):
+    """Wide rows on sparse lattices (round 6): a blur pass that touches only the vertices with a neighbour on its axis, in place
+    (blur_active_rows_kernel + blur_active_store_kernel; the centre tap of every kernel profile is exactly 1, so the other rows
+    do not change), gives what the dense passes give -- the same operations in the same order for the rows that change, the
+    untouched rows as they were -- on lattices where every point has a simplex of its own and on partly shared ones, orders
+    1-3, one and two chunks per lane.  Also: the lists are rebuilt with the lattice, a centre tap other than 1 keeps the
+    dense passes, and the whole filter (splat, blur, slice) agrees with the oracle."""
+    from simplex_gp_amd import _native as nv
+    lib = nv.lib()
+    g = torch.Generator().manual_seed(n + d + vd)
+    x = (torch.randn(n, d, generator=g) / ell).contiguous()
+    taps = {1: [0.34608543, 1.0, 0.34608543], 2: [0.0826, 0.5362, 1.0, 0.5362, 0.0826],
+            3: [0.0844, 0.2424, 0.6031, 1.0, 0.6031, 0.2424, 0.0844]}[order]
+    taps = np.array(taps, np.float32)
+    lat = plx.Lattice().build(x.cuda(), taps)
+    m = lat.m
+    vals = torch.randn(m, lat.values_stride(vd), generator=g).cuda()
+    outs, kinds = {}, {}
+    try:
+        for mode in (0, 2, 1):
+            nv.check(lib.plx_tune(b"blur_active", mode), "plx_tune")
+            lat.build(x.cuda(), taps)
+            a, b = vals.clone(), torch.empty_like(vals)
+            outs[mode] = lat.blur(a, b, vd=vd).clone()
+            kinds[mode] = lat.stage_kernels()["blur_axis"]
+    finally:
+        nv.check(lib.plx_tune(b"blur_active", 1), "plx_tune")
+    assert kinds[0] == ["blur_axis_multi_kernel"] and kinds[2] == ["blur_active_rows_kernel", "blur_active_store_kernel"], kinds
+    assert torch.equal(outs[2], outs[0])                       # (numeric equality: a zero may change its sign, nothing else may differ)
+    assert torch.equal(outs[1], outs[0])
+    nbr = lat.export(nv.ARRAY_NEIGHBORS)
+    share = float((nbr >= 0).any(axis=1).mean())
+    sparse = m >= 0.75 * n * (d + 1) and share <= 0.35
+    assert (kinds[1] == kinds[2]) == sparse, (kinds[1], share, m / (n * (d + 1)))
+    # a centre tap that is not 1: the rows without neighbours DO change (scaled): the dense passes run whatever the switch says
+    odd = taps.copy()
+    odd[order] = 0.9
+    try:
+        nv.check(lib.plx_tune(b"blur_active", 2), "plx_tune")
+        lat.build(x.cuda(), odd)                      # (other taps, other scale factors: another lattice, another m)
+        vals2 = torch.randn(lat.m, lat.values_stride(vd), generator=g).cuda()
+        forced = lat.blur(vals2.clone(), torch.empty_like(vals2), vd=vd).clone()
+        assert lat.stage_kernels()["blur_axis"] == ["blur_axis_multi_kernel"]
+        nv.check(lib.plx_tune(b"blur_active", 0), "plx_tune")
+        lat.build(x.cuda(), odd)
+        assert lat.m == vals2.shape[0]
+        assert torch.equal(forced, lat.blur(vals2.clone(), torch.empty_like(vals2), vd=vd))
+    finally:
+        nv.check(lib.plx_tune(b"blur_active", 1), "plx_tune")
+    # the whole filter against the oracle on this lattice (whatever path the gate picks)
+    lat.build(x.cuda(), taps)
+    src = torch.randn(n, vd, generator=g)
+    oracle.set_exact_mode(False)
+    try:
+        want = oracle.filter(src.numpy(), x.numpy(), taps)
+    finally:
+        oracle.set_exact_mode(True)
+    got = lat.apply(src.cuda()).cpu().numpy()
+    assert rel_l2(got, want) <= 1e-5
+    lat.close()
+
+
 def test_point_order_warm_start_across_rescaled_rebuilds(plx):
     """Lattice.build(reuse_order=True) / plx_set_reuse_order: a rebuild on re-scaled positions keeps the point order of the
     previous build (the order passes are skipped) and gives the cold build's structure and output (up to the order of the

@@ -3,7 +3,7 @@
 training step phases and the evaluation (training.predict) split into its parts."""
 import json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import solvers, training
 
