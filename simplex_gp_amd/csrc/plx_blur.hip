@@ -547,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void blur_axis_multi_kernel(const float4 *_
 // is read before any is written: Jacobi), (2) the rows go back to their vertices.  Rows of vertices that are not listed
 // are bit for bit what the dense pass writes (up to the sign of a zero: 0 + 1 * (-0) = +0).  The lists are built by the
 // first wide blur that qualifies (ensure_active_lists: ordered compaction, one read-back of the d + 1 counts).
-constexpr double kActiveShare = 0.35;      // use the lists while at most this share of the vertices changes per axis (mean over the axes)
+constexpr double kActiveShare = 0.40;      // use the lists while at most this share of the vertices changes per axis (mean over the axes; measured break-even: 0.43-0.45, tools/ab_blur_active_r6.py)
 
 __device__ __forceinline__ bool has_neighbour(const int *__restrict__ nb, int64_t mstride, int taps2, int v)
 {

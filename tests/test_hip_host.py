@@ -751,7 +751,7 @@ def test_wide_blur_on_active_rows_equals_the_dense_passes(plx, n, d, ell, order,
     assert torch.equal(outs[1], outs[0])
     nbr = lat.export(nv.ARRAY_NEIGHBORS)
     share = float((nbr >= 0).any(axis=1).mean())
-    sparse = m >= 0.75 * n * (d + 1) and share <= 0.35
+    sparse = m >= 0.75 * n * (d + 1) and share <= 0.40
     assert (kinds[1] == kinds[2]) == sparse, (kinds[1], share, m / (n * (d + 1)))
     # a centre tap that is not 1: the rows without neighbours DO change (scaled): the dense passes run whatever the switch says
     odd = taps.copy()
