@@ -419,7 +419,8 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  *   first-touch stores + a short extras list when m >= 0.9 nnz; 0 never, 2 whenever representable, 3 = 2 with scattered
  *   stores), "perm_rows" (1 = multi-column row permutations by 16-byte chunks / LDS-transposed whole-line stores; 0 = the
  *   per-float forms), "reference_growth" (0; 1 = replay the reference CPU path's table-growth quirk: plx_reference_growth_info; 2 = the same by
- *   running every lookup, the checker of 1), "contract_v" (1 = the fused backward's slice + contraction with the corner count
+ *   running every lookup, the checker of 1), "blur_active" (1: wide rows on sparse lattices -- centre tap 1 -- blur only the vertices with a neighbour on the axis, in place; 0 never, 2 whenever representable),
+ *   "contract_v" (1 = the fused backward's slice + contraction with the corner count
  *   compiled in; 0 = the run-time form),
  *   and the round-5 build switches "nbr_sliced" (1), "nbr_seed" (1), "assign_evid" (1), "insert_xcd" (2), "order_sample" (8),
  *   "embed_vrange" (0), "blk_sort" (15): DESIGN.md 2.  (Round 6 removed "hash_v", "table_fp", "flag_own" and "insert_v" with the
