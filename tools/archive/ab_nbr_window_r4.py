@@ -4,7 +4,7 @@ Morton-numbered lattices (N=1e6, d=8); build stage times and exported neighbour 
     python tools/ab_nbr_window_r4.py [ell ...]"""
 import json, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import _native as nv
 import bench

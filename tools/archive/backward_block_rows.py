@@ -6,7 +6,7 @@ corners, and the line traffic a column-tiled gather would move against the row-a
     python tools/backward_block_rows.py"""
 import json, os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import _native as nv
 

@@ -6,7 +6,7 @@
      splat / blur / slice (the vertex all-reduce of values[m, vdp] sits between splat and blur and is not timed here)"""
 import json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import solvers
 import bench

@@ -6,7 +6,7 @@ kernel timeline of the LAST factor build (one line per launch: start offset, gap
 import collections, json, os, re, sqlite3, sys
 
 tag, dbp, log = sys.argv[1:4]
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 db = sqlite3.connect(dbp)
 rows = db.execute("select name, start, end, grid_x from kernels order by start").fetchall()
 short = lambda n: re.sub(r"\(.*", "", n.replace("void ", ""))[:70]

@@ -4,7 +4,7 @@ switches of its build (kernel rows on the frontier / by the dense stages; exact 
 config-3 size.  python tools/pchol_batch_sweep.py [n] [rank] [ell]"""
 import json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import solvers
 

@@ -7,7 +7,7 @@ The constructor's batch loop, piece by piece: (a) with a synchronisation after e
 """
 import ctypes, json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from simplex_gp_amd import solvers, _native as nv
 

@@ -4,7 +4,7 @@ all W local builds are run here one after the other to obtain the key sets, then
 and its splat / blur / slice over the merged lattice are timed.  Collectives are not included."""
 import json, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import simplex_gp_amd as plx
 from tools.archive.ab_apply import timeit, RBF1
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
