@@ -217,3 +217,61 @@ def test_torch_extension_boundary_on_cpu():
     taps = torch.tensor([0.5, 1.0, 0.5])
     with pytest.raises(RuntimeError, match="must be a CUDA"):
         ext.filter(torch.randn(4, 1), torch.randn(4, 2), taps)
+
+
+def test_lattice_cache_rebuilds_the_same_data_in_place_with_the_order_kept(monkeypatch):
+    """Host logic of the point-order warm start (lattice_kernel._LatticeCache, no GPU): positions tagged as derived from the same
+    data tensor (LatticeAccelerated.forward's position_hint) find the entry of that data and rebuild ITS lattice with
+    reuse_order=True; other data, other taps or a data tensor changed in place take the ordinary path; the order is computed
+    afresh after MAX_ORDER_AGE kept rebuilds; detach() / contiguous() copies carry the hint."""
+    from simplex_gp_amd import lattice_kernel as lk
+
+    class FakeLattice:
+        made = 0
+
+        def __init__(self, device=None):
+            FakeLattice.made += 1
+            self.builds, self.order_age, self.closed = [], -1, False
+
+        def build(self, ref, taps, reuse_order=False):
+            keep = reuse_order and self.order_age >= 0
+            self.order_age = self.order_age + 1 if keep else 0
+            self.builds.append(bool(keep))
+            return self
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(lk, "Lattice", FakeLattice)
+    cache = lk._LatticeCache(capacity=4)
+    x = torch.randn(16, 3)
+    taps = np.array([0.3, 1.0, 0.3], np.float32)
+    r0 = lk.position_hint(x / 0.7, x)
+    lat0 = cache.get(r0, taps)
+    assert cache.get(r0, taps) is lat0 and cache.hits == 1 and lat0.builds == [False]
+    r1 = lk.position_hint(x / 0.8, x)
+    assert cache.get(r1, taps) is lat0 and lat0.builds == [False, True] and cache.warm_rebuilds == 1 and len(cache._entries) == 1
+    assert cache.get(lk.carry_hint(r1.detach(), r1), taps) is lat0 and cache.hits == 2          # same storage, same key: a hit
+    other_taps = np.array([0.1, 0.5, 1.0, 0.5, 0.1], np.float32)
+    lat1 = cache.get(lk.position_hint(x / 0.8, x), other_taps)                                   # other taps: a lattice of its own
+    assert lat1 is not lat0 and lat1.builds == [False] and len(cache._entries) == 2
+    x2 = x.clone()
+    lat2 = cache.get(lk.position_hint(x2 / 0.8, x2), taps)                                       # other data: no warm start
+    assert lat2 is not lat0 and lat2.builds == [False] and cache.warm_rebuilds == 1
+    assert cache.get(x / 0.9, taps) not in (lat0, lat1, lat2)                                    # untagged positions: the ordinary path
+    x.mul_(1.5)                                                                                  # the data changed in place: its old
+    lat5 = cache.get(lk.position_hint(x / 0.8, x), taps)                                         # order says nothing about it
+    assert lat5.builds[-1] is False and cache.warm_rebuilds == 1
+    cache.clear()
+    assert lat0.closed and lat1.closed
+    # the order is refreshed after MAX_ORDER_AGE kept rebuilds, in place
+    y = torch.randn(8, 2)
+    lat = cache.get(lk.position_hint(y / 1.0, y), taps)
+    for i in range(lk.MAX_ORDER_AGE + 3):
+        assert cache.get(lk.position_hint(y / (1.0 + 0.01 * (i + 1)), y), taps) is lat
+    assert lat.builds == [False] + [True] * lk.MAX_ORDER_AGE + [False, True, True] and len(cache._entries) == 1
+    # the kernel's forward tags its scaled positions with the data they came from
+    k = plx.RBFLattice(order=1)
+    op = k(y, y)
+    src, ver, shape = op.x._plx_positions_of
+    assert src() is y and ver == y._version and shape == tuple(y.shape)
