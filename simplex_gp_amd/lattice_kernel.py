@@ -34,11 +34,18 @@ from .stencil import DiscretizedKernelFN, Matern, rbf
 MAX_ORDER_AGE = 8          # rebuilds before the order is computed afresh (Adam at lr 0.1 moves a lengthscale < 2.2x in 8 steps)
 
 
-def position_hint(scaled, source):
-    """Mark `scaled` as positions derived from the data tensor `source` by a re-scaling (returns `scaled`)."""
+def position_hint(scaled, source, scale_of=None):
+    """Mark `scaled` as positions derived from the data tensor `source` by a re-scaling (returns `scaled`).
+    scale_of: the tensor the scale is a deterministic function of (the kernel's raw lengthscale PARAMETER; the lengthscale
+    itself is a fresh softplus output on every access).  Two hints with the same source whose scale_of is the same tensor
+    holding the same VALUES mark bit-identical positions: the cache then serves the lattice it has instead of rebuilding it
+    (an evaluation followed by the next training step: the same hyper-parameters twice).  The values are compared on the
+    device (d floats and one read-back, only when identity and version counter already agree): the version counter alone
+    cannot vouch for them -- torch.optim.Adam(fused=True) writes parameters without moving it (measured on this image)."""
     import weakref
     try:
-        scaled._plx_positions_of = (weakref.ref(source), source._version, tuple(source.shape))
+        scale_key = None if scale_of is None else (weakref.ref(scale_of), scale_of._version)
+        scaled._plx_positions_of = (weakref.ref(source), source._version, tuple(source.shape), scale_key)
     except (AttributeError, TypeError):
         pass
     return scaled
@@ -62,6 +69,29 @@ def _same_hint(a, b):
     return src is not None and src is b[0]() and a[1] == b[1] and a[2] == b[2] and src._version == a[1]
 
 
+def _scale_tensor(hint):
+    """The live parameter a hint's scale comes from, or None."""
+    k = hint[3] if hint is not None and len(hint) > 3 else None
+    return None if k is None else k[0]()
+
+
+def _same_scale(a, b, snapshot):
+    """Both hints name the same live scale parameter, its version counter has not moved since either was made, and it
+    still holds the values `snapshot` (taken when the lattice was built) -- the last by comparison on the device."""
+    ka, kb = a[3] if len(a) > 3 else None, b[3] if len(b) > 3 else None
+    if ka is None or kb is None or snapshot is None:
+        return False
+    p = ka[0]()
+    if p is None or p is not kb[0]() or not (ka[1] == kb[1] == p._version) or snapshot.shape != p.shape:
+        return False
+    return bool(torch.equal(snapshot, p.detach()))
+
+
+def _snapshot_scale(hint):
+    p = _scale_tensor(hint)
+    return None if p is None else p.detach().clone()
+
+
 class _LatticeCache:
     """Small LRU of built lattices keyed on the position tensor and the taps.
 
@@ -79,6 +109,7 @@ class _LatticeCache:
         self.hits = 0
         self.misses = 0
         self.warm_rebuilds = 0             # misses served by rebuilding an entry of the same data in place (point order kept)
+        self.same_positions = 0            # new position tensors recognised as the positions of an entry (same data, same scale state)
 
     @staticmethod
     def _key(ref, taps):
@@ -96,25 +127,34 @@ class _LatticeCache:
         # the same data under a lengthscale that moved: rebuild that entry's lattice in place, point order kept
         hint = getattr(ref, "_plx_positions_of", None)
         if hint is not None:
-            for k2, (lat2, ref2) in self._entries.items():
-                if (k2[0], k2[3], k2[4]) == (key[0], key[3], key[4]) and _same_hint(hint, getattr(ref2, "_plx_positions_of", None)):
+            for k2, (lat2, ref2, snap2) in self._entries.items():
+                hint2 = getattr(ref2, "_plx_positions_of", None)
+                if (k2[0], k2[3], k2[4]) == (key[0], key[3], key[4]) and _same_hint(hint, hint2):
                     del self._entries[k2]
+                    if _same_scale(hint, hint2, snap2):
+                        # the same data divided by the same lengthscale, as a new tensor: the positions this lattice was
+                        # built on.  The entry moves under the new tensor (the one the caller will come back with).
+                        self._entries[key] = (lat2, ref, snap2)
+                        self.misses -= 1
+                        self.hits += 1
+                        self.same_positions += 1
+                        return lat2
                     keep = 0 <= lat2.order_age < MAX_ORDER_AGE      # (an order that old is computed afresh, in place all the same)
                     lat2.build(ref, taps, reuse_order=keep)
-                    self._entries[key] = (lat2, ref)
+                    self._entries[key] = (lat2, ref, _snapshot_scale(hint))
                     self.warm_rebuilds += 1 if keep else 0
                     return lat2
         if len(self._entries) >= self.capacity:
-            _, (old, _) = self._entries.popitem(last=False)
+            _, (old, _, _) = self._entries.popitem(last=False)
             lat = old                      # recycle the device buffers of the evicted lattice
         else:
             lat = Lattice(ref.device)
         lat.build(ref, taps)
-        self._entries[key] = (lat, ref)
+        self._entries[key] = (lat, ref, _snapshot_scale(hint))
         return lat
 
     def clear(self):
-        for lat, _ in self._entries.values():
+        for lat, _, _ in self._entries.values():
             lat.close()
         self._entries.clear()
 
@@ -297,7 +337,7 @@ class LatticeAccelerated(Kernel):
     def forward(self, x1, x2, diag=False, **params):
         if diag:
             return x1.new_ones(x1.shape[:-1])
-        scaled1 = position_hint(x1.div(self.lengthscale), x1)
+        scaled1 = position_hint(x1.div(self.lengthscale), x1, scale_of=getattr(self, "raw_lengthscale", None))
         if self._same_points(x1, x2):
             return SquareLazyLattice(scaled1, self.dkernel_fn)
         return RectangularLazyLattice(scaled1, x2.div(self.lengthscale), self.dkernel_fn)

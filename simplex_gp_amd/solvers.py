@@ -14,6 +14,7 @@ batched_cg also runs over a row-sharded operator: pass the sharded `matmul` and
 ranks (distributed.sharded_solve).  The marginal likelihood below is
 single-process.
 """
+import contextlib
 import math
 
 import torch
@@ -859,6 +860,29 @@ class LatticeGP(nn.Module):
             return self.outputscale * K.matmul(V) + self.noise * V
         return mm
 
+    @contextlib.contextmanager
+    def khat_in_lattice_rows(self, x, K=None):
+        """with ... as (mm, to_rows, from_rows): V -> (s K + sigma^2 I) V on vectors whose rows are in the lattice's own
+        point order (no gradients), and the two permutations between that order and the caller's.  What khat_solve runs
+        its iteration on, offered to other Krylov loops (training.lanczos): every MVM is splat -> blur -> slice + the affine
+        tail in ONE pass over the rows, without the two row permutations of the caller-order MVM.  Away from the HIP
+        path: the ordinary closure and identity permutations."""
+        from . import lattice_kernel as lk
+        with torch.no_grad():
+            if lk.LatticeFilterGeneral.method is not None or not x.is_cuda:
+                yield self.khat_matmul(x, K), (lambda v: v), (lambda v: v)
+                return
+            ref = lk.carry_hint(K.x.detach(), K.x) if isinstance(K, lk.SquareLazyLattice) \
+                else lk.position_hint(x.div(self.kernel.lengthscale), x, scale_of=getattr(self.kernel, "raw_lengthscale", None))
+            ref = ref if ref.is_contiguous() else lk.carry_hint(ref.contiguous(), ref)
+            lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
+            ss = torch.stack([self.outputscale.detach().reshape(()), self.noise.detach().reshape(())]).to(torch.float32).contiguous()
+            lat.set_lattice_row_order(True)
+            try:
+                yield (lambda V: lat.apply_affine(V.contiguous(), ss)), lat.to_lattice_order, lat.from_lattice_order
+            finally:
+                lat.set_lattice_row_order(False)
+
     def _positions_key(self, x):
         """What x / lengthscale was derived from: x by identity (a weak reference: a freed tensor whose address the
         caching allocator hands to another one cannot match) and version, the raw lengthscale PARAMETER by identity and
@@ -868,7 +892,27 @@ class LatticeGP(nn.Module):
         return (weakref.ref(x), x._version, tuple(x.shape), None if raw is None else weakref.ref(raw),
                 None if raw is None else raw._version)
 
+    def _hyper_snapshot(self):
+        """The values every operator of this model is a function of (raw lengthscale, raw outputscale, raw noise), cloned:
+        what a remembered lattice / preconditioner is checked against.  Version counters cannot vouch for parameters --
+        torch.optim.Adam(fused=True) writes them without moving the counter (measured on this image) -- so 'nothing
+        moved' is confirmed by comparing these few floats on the device (one read-back, only after the cheap identity and
+        version checks have passed)."""
+        raw = getattr(self.kernel, "raw_lengthscale", None)
+        parts = ([] if raw is None else [raw.detach().reshape(-1)]) + [self.raw_outputscale.detach().reshape(1),
+                                                                     self.raw_noise.detach().reshape(1)]
+        return torch.cat([p.to(torch.float32) for p in parts])
+
+    def _same_hyper(self, pre):
+        snap = getattr(pre, "hyper_snapshot", None)
+        if snap is None or getattr(pre, "min_noise", None) != float(self.min_noise):
+            return False
+        now = self._hyper_snapshot()
+        return snap.shape == now.shape and snap.device == now.device and bool(torch.equal(snap, now))
+
     def _same_positions(self, pre, x):
+        """pre was built from this x (identity, version, shape) under the lengthscale the kernel has NOW (the parameter's
+        identity and version first, then its values against the copy taken at the build)."""
         key = pre.ref_key
         if key is None or len(key) != 5:
             return False
@@ -878,7 +922,19 @@ class LatticeGP(nn.Module):
             return False
         if raw is None:
             return rr is None
-        return rr is not None and rr() is raw and rv == raw._version
+        if not (rr is not None and rr() is raw and rv == raw._version):
+            return False
+        snap = getattr(pre, "hyper_snapshot", None)
+        if snap is None:
+            return True
+        k = raw.numel()
+        return snap.numel() == k + 2 and bool(torch.equal(snap[:k], raw.detach().reshape(-1).to(torch.float32)))
+
+    def __getstate__(self):
+        # (copy.deepcopy / pickling of the module: the remembered preconditioner holds device handles of this process)
+        state = self.__dict__.copy()
+        state.pop("_last_preconditioner", None)
+        return state
 
     def khat_solve(self, x, rhs, K=None, **cg_args):
         """(s K + sigma^2 I)^-1 rhs by batched CG, no gradients.  On the HIP path the
@@ -892,15 +948,18 @@ class LatticeGP(nn.Module):
             # the positions of an existing operator share storage with its tensor: same lattice-cache key, so the
             # differentiable MVM that follows a solve reuses the lattice built here
             ref = lk.carry_hint(K.x.detach(), K.x) if isinstance(K, lk.SquareLazyLattice) \
-                else lk.position_hint(x.div(self.kernel.lengthscale), x)
+                else lk.position_hint(x.div(self.kernel.lengthscale), x, scale_of=getattr(self.kernel, "raw_lengthscale", None))
             ref = ref if ref.is_contiguous() else lk.carry_hint(ref.contiguous(), ref)
             pre = cg_args.get("precond")
             if isinstance(pre, LatticePreconditioner) and pre.ref is not None and pre.ref is not ref \
+                    and (pre.ref.data_ptr(), pre.ref._version, pre.ref.shape) != (ref.data_ptr(), ref._version, ref.shape) \
                     and self._same_positions(pre, x):
                 # the same x and lengthscale the preconditioner was built from, as a fresh tensor (no K handed over): solve
                 # on the preconditioner's lattice.  (Decided from the identities and version counters of x ITSELF -- held
-                # through a weak reference, a recycled address cannot pass for it -- and of the raw lengthscale PARAMETER;
-                # comparing the n x d positions on the device cost a pass and a host synchronisation per solve.)
+                # through a weak reference, a recycled address cannot pass for it -- and of the raw lengthscale PARAMETER,
+                # then from the parameter's d values against the copy taken when the factor was built: one small
+                # read-back, and only on this path -- positions that share the factor's storage are not asked.
+                # Comparing the n x d positions on the device cost a pass and a host synchronisation per solve.)
                 ref = pre.ref
             lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
             s, noise = self.outputscale, self.noise
@@ -949,12 +1008,22 @@ class LatticeGP(nn.Module):
             if lk.LatticeFilterGeneral.method is None and x.is_cuda and x.dtype == torch.float32 \
                     and min(int(rank), x.shape[0]) <= LatticePreconditioner.MAX_RANK:
                 ref = lk.carry_hint(K.x.detach(), K.x) if isinstance(K, lk.SquareLazyLattice) \
-                    else lk.position_hint(x.div(self.kernel.lengthscale), x)
+                    else lk.position_hint(x.div(self.kernel.lengthscale), x, scale_of=getattr(self.kernel, "raw_lengthscale", None))
                 ref = ref if ref.is_contiguous() else lk.carry_hint(ref.contiguous(), ref)
                 lat = lk.lattice_cache().get(ref, self.kernel.dkernel_fn.get_coeffs())
+                # the factor of the same operator again (an evaluation, then the next training step: the optimiser has not
+                # moved between them): the one built last, if nothing it depends on has been written since
+                last = self.__dict__.get("_last_preconditioner")
+                if last is not None and last.lat is lat and last.build_id == lat.build_id and last.asked == (int(rank), factor_dtype) \
+                        and self._same_positions(last, x) and self._same_hyper(last):
+                    self.preconditioner_reuses = self.__dict__.get("preconditioner_reuses", 0) + 1
+                    return last
                 pre = LatticePreconditioner(lat, self.outputscale, self.noise, rank, factor_dtype=factor_dtype)
                 pre.ref = ref          # the positions its lattice was built on (kept alive: the lattice-cache key)
                 pre.ref_key = self._positions_key(x)
+                pre.asked = (int(rank), factor_dtype)
+                pre.hyper_snapshot, pre.min_noise = self._hyper_snapshot(), float(self.min_noise)
+                self.__dict__["_last_preconditioner"] = pre
                 return pre
             K = self.kernel(x, x) if K is None else K
             return PivotedCholeskyPreconditioner(K.matmul, x.shape[0], self.outputscale, self.noise, rank,

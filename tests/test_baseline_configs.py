@@ -271,6 +271,102 @@ def test_config5_matern_order3_d18(plx):
     assert (np.diff(mll) > -0.1).all()                       # no epoch undoes the progress (probe noise and Adam's overshoot only)
 
 
+def test_evaluation_and_the_next_step_share_lattice_and_preconditioner(plx):
+    """The reference's loop (train_simplexgp.py:123-165): step, evaluate on two splits, step ...  Between an evaluation
+    and the next step the optimiser does not move, so (1) both splits predict from ONE mean / variance cache
+    (training.PredictionCache: GPyTorch's eval-mode prediction strategy), (2) the next step's operator -- the same data under
+    the same lengthscale, as a new tensor -- is served the evaluation's lattice without a build, (3) and its
+    preconditioner.  'Same' is decided on the parameters' VALUES (fused Adam writes them without moving their version
+    counters): after an optimiser step nothing is taken for the same.  Values equal those computed with nothing remembered."""
+    from simplex_gp_amd import solvers, training
+    torch.manual_seed(0)
+    n, d = 6000, 5
+    x = torch.randn(n, d).cuda()
+    y = (torch.sin(x[:, 0]) + 0.1 * torch.randn(n, device="cuda"))
+    xv, xt = torch.randn(500, d).cuda(), torch.randn(700, d).cuda()
+    model = solvers.LatticeGP(plx.MaternLattice(nu=1.5, order=2, ard_num_dims=d), min_noise=0.1).cuda()
+    opt = training.make_optimizer(model, lr=0.1)
+    cache = plx.lattice_cache()
+    cache.clear()
+
+    def step(seed):
+        opt.zero_grad()
+        mll = solvers.marginal_log_likelihood(model, x, y, num_probes=10, max_cg_iter=500, cg_tol=1.0, seed=seed, pre_size=50)
+        (-mll).backward()
+        return float(mll), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    step(0)
+    versions = {k: p._version for k, p in model.named_parameters()}
+    opt.step()
+    print("version counters moved by the optimiser:", {k: p._version > versions[k] for k, p in model.named_parameters()})
+    same0, reuse0 = cache.same_positions, model.__dict__.get("preconditioner_reuses", 0)
+    pc = training.PredictionCache(model, x, y, cg_tol=1e-2, lanc_iter=50, pre_size=50)
+    mv, vv = pc.predict(xv)
+    mt, vt = pc.predict(xt)
+    for xs, m_c, v_c in ((xv, mv, vv), (xt, mt, vt)):                          # the shared cache predicts what predict() alone does
+        m_1, v_1 = training.predict(model, x, y, xs, cg_tol=1e-2, lanc_iter=50, pre_size=50)
+        assert torch.allclose(m_c, m_1, atol=2e-4, rtol=1e-3) and torch.allclose(v_c, v_1, atol=2e-4, rtol=1e-3)
+    misses = cache.misses
+    reuse1 = model.preconditioner_reuses                                        # (the predict() calls above reused it too)
+    got, got_grads = step(1)
+    assert cache.same_positions > same0 and model.preconditioner_reuses == reuse1 + 1 > reuse0
+    assert cache.misses - misses <= 1                                           # at most the lattice of the derivative taps
+    # nothing remembered: the same value and gradients
+    cache.clear()
+    model.__dict__.pop("_last_preconditioner")
+    want, want_grads = step(1)
+    assert abs(got - want) <= 1e-4 * max(1.0, abs(want))
+    for k in got_grads:
+        assert torch.allclose(got_grads[k], want_grads[k], rtol=2e-3, atol=1e-5), k
+    # ... and after the optimiser moved, nothing is taken for the same
+    opt.step()
+    reuse2, same2 = model.preconditioner_reuses, cache.same_positions
+    step(2)
+    assert model.preconditioner_reuses == reuse2 and cache.same_positions == same2
+
+
+def test_lanczos_replayed_graph_equals_the_eager_loop(plx):
+    """training.lanczos on the GPU replays ONE captured step (HIP graph, step index on the device) on the operator in
+    lattice row order: the same tridiagonal and basis as the eager three-term loop on the caller-order operator, to fp32
+    Lanczos accuracy; an operator that cannot be captured (it reads the device back) falls back to the eager loop, leaves
+    the reason in _graph_refusals, and the next capture works."""
+    from simplex_gp_amd import solvers, training
+    torch.manual_seed(0)
+    n, d, steps = 3000, 6, 40
+    x = torch.randn(n, d).cuda()
+    r = torch.randn(n).cuda()
+    model = solvers.LatticeGP(plx.MaternLattice(nu=1.5, order=2, ard_num_dims=d), min_noise=0.1).cuda()
+    with torch.no_grad():
+        mm = model.khat_matmul(x)
+        Q0, T0 = training.lanczos(mm, r, steps, graph=False)
+        with model.khat_in_lattice_rows(x) as (mm_rows, to_rows, from_rows):
+            Q1, T1 = training.lanczos(mm_rows, to_rows(r.reshape(-1, 1)).squeeze(-1), steps, graph=True)   # True: a refusal raises
+            Q1 = from_rows(Q1.contiguous())
+        assert Q1.shape == Q0.shape == (n, steps) and T1.shape == T0.shape
+        scale = float(T0.diagonal().abs().max())
+        assert float((T1 - T0).abs().max()) <= 2e-3 * scale
+        assert float((Q1[:, :8] - Q0[:, :8]).abs().max()) <= 1e-3                  # the leading vectors agree; later ones
+        A_Q = torch.cat([mm(Q1[:, j:j + 1].contiguous()) for j in range(steps)], 1)  # drift apart as any two fp32 Lanczos runs do,
+        H = Q1.T @ A_Q                                                               # but diagonal and sub-diagonal of Q^T A Q
+        assert float((H.diagonal() - T1.diagonal()).abs().max()) <= 2e-3 * scale     # are T's for each (the lattice operator is
+        assert float((H.diagonal(-1) - T1.diagonal(-1)).abs().max()) <= 2e-3 * scale  # only approximately symmetric: the upper
+        assert float(H.tril(-2).abs().max()) <= 2e-3 * scale                         # triangle is not T's)
+        assert float((Q1.T @ Q1 - torch.eye(steps, device="cuda")).abs().max()) <= 1e-4
+        # a refused capture: the eager loop's answer, and the library is usable afterwards
+        training._graph_refusals.clear()
+        calls = []
+
+        def reads_back(V):
+            out = mm(V)
+            calls.append(float(out[0, 0]))                                         # a host read-back: not capturable
+            return out
+        Q2, T2 = training.lanczos(reads_back, r, steps)
+        assert len(training._graph_refusals) == 1 and T2.shape == T0.shape
+        assert float((T2 - T0).abs().max()) <= 2e-3 * scale
+        Q3, T3 = training.lanczos(mm, r, steps, graph=True)
+        assert float((T3 - T0).abs().max()) <= 2e-3 * scale
+
+
 def test_predict_matches_dense_formulas_on_gpu(plx):
     """training.predict on the HIP path (CG mean + Lanczos variance through the rectangular operator, py:142-160)
     against the dense expressions built from the same operators, n = 2000."""

@@ -836,7 +836,7 @@ def test_point_order_warm_start_across_rescaled_rebuilds(plx):
         for i in range(lk.MAX_ORDER_AGE + 2):                                      # the order is refreshed now and then
             k.lengthscale = 0.8 + 0.01 * (i + 1)
             k(x, x).matmul(v)
-            seen.append(max(l.order_age for l, _ in cache._entries.values()))
+            seen.append(max(e[0].order_age for e in cache._entries.values()))
         assert max(seen) == lk.MAX_ORDER_AGE and seen[-1] < lk.MAX_ORDER_AGE and len(cache._entries) == 2
     cache.clear()
 

@@ -273,5 +273,17 @@ def test_lattice_cache_rebuilds_the_same_data_in_place_with_the_order_kept(monke
     # the kernel's forward tags its scaled positions with the data they came from
     k = plx.RBFLattice(order=1)
     op = k(y, y)
-    src, ver, shape = op.x._plx_positions_of
+    src, ver, shape, scale = op.x._plx_positions_of
     assert src() is y and ver == y._version and shape == tuple(y.shape)
+    assert scale[0]() is k.raw_lengthscale and scale[1] == k.raw_lengthscale._version
+    # ... and with the state of the parameter their scale comes from: the same data under the SAME lengthscale, as a new
+    # tensor (an evaluation, then the next training step), is served the lattice it has -- no build at all; a write to the
+    # parameter (an optimiser step) makes it a re-scaled rebuild again
+    cache.clear()
+    lat = cache.get(k(y, y).x, taps)
+    assert cache.get(k(y, y).x, taps) is lat and lat.builds == [False] and cache.same_positions == 1 and len(cache._entries) == 1
+    with torch.no_grad():
+        k.raw_lengthscale.add_(0.1)
+    assert cache.get(k(y, y).x, taps) is lat and lat.builds == [False, True] and cache.same_positions == 1
+    k2 = plx.RBFLattice(order=1)                                                                 # another kernel's lengthscale, equal
+    assert cache.get(k2(y, y).x, taps) is lat and lat.builds == [False, True, True]               # or not: not the same state

@@ -29,6 +29,34 @@ def test_lanczos_reproduces_the_operator():
     assert torch.allclose(Q.T @ A @ Q, T, atol=1e-8)
 
 
+def test_lanczos_device_indexed_step_equals_the_eager_recurrence():
+    """The step the HIP-graph form replays (training._lanczos_replayed: step index on the device, projection over the
+    whole basis buffer, two Gram-Schmidt passes) run eagerly on the CPU: the same Q and T as the three-term loop, a
+    breakdown found at the same place, and khat_in_lattice_rows away from the HIP path is the ordinary closure."""
+    g = torch.Generator().manual_seed(1)
+    n = 60
+    B = torch.randn(n, n, generator=g, dtype=torch.float64)
+    A = B @ B.T / n + torch.eye(n, dtype=torch.float64)
+    v0 = torch.randn(n, generator=g, dtype=torch.float64)
+    for steps in (1, 2, 25, n):
+        Q0, T0 = training.lanczos(lambda V: A @ V, v0, steps, graph=False)
+        Q1, T1 = training._lanczos_replayed(lambda V: A @ V, v0, steps, check_every=8, capture=False)
+        assert Q1.shape == Q0.shape and T1.shape == T0.shape
+        assert torch.allclose(T1, T0, atol=1e-9) and torch.allclose(Q1, Q0, atol=1e-7)
+        assert torch.allclose(Q1.T @ A @ Q1, T1, atol=1e-8)
+    # an operator of rank 5 (+ identity): the Krylov space of v0 is exhausted after 6 steps; both forms cut there
+    U = torch.randn(n, 5, generator=g, dtype=torch.float64)
+    A5 = U @ U.T + torch.eye(n, dtype=torch.float64)
+    Q0, T0 = training.lanczos(lambda V: A5 @ V, v0, 40, graph=False)
+    Q1, T1 = training._lanczos_replayed(lambda V: A5 @ V, v0, 40, check_every=8, capture=False)
+    assert Q0.shape[1] == Q1.shape[1] == 6 and torch.allclose(T1, T0, atol=1e-8)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1))
+    x = torch.randn(10, 2)
+    with model.khat_in_lattice_rows(x) as (mm, to_rows, from_rows):
+        v = torch.randn(10, 1)
+        assert to_rows(v) is v and from_rows(v) is v and callable(mm)
+
+
 def test_predict_matches_dense_formulas(cpu_method):
     """Mean and (full-rank Lanczos) variance against the dense expressions built from the same lattice operators."""
     torch.manual_seed(0)

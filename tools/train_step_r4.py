@@ -60,6 +60,6 @@ for pre in args.pre:
         if th0 and th1:
             row["cpu_throttled"] = {"periods": th1[0] - th0[0], "ms": round((th1[1] - th0[1]) / 1e3, 1)}     # the container's CPU quota ran out during the step
         row["reserved_grew_MB"] = round((torch.cuda.memory_reserved() - rs0) / 1e6, 1)                     # torch's allocator asked the driver for memory
-        row["lattices_m"] = [lat.m for lat, _ in plx.lattice_cache()._entries.values()][-2:]      # the last two lattices in the cache (RBF: the previous step's and this step's; a profile whose derivative taps differ builds two per step)
+        row["lattices_m"] = [e[0].m for e in plx.lattice_cache()._entries.values()][-2:]      # the last two lattices in the cache (RBF: the previous step's and this step's; a profile whose derivative taps differ builds two per step)
         print(json.dumps(row), flush=True)
     plx.lattice_cache().clear()
