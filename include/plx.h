@@ -305,6 +305,21 @@ int plx_pcg_step_direction_fused(float *d_p, const float *d_z, const float *d_rz
 int plx_cg_step_direction(float *d_p, const float *d_r, const float *d_rs_new, const float *d_rs, const float *d_active,
                           const float *d_b_norm, float tol, int64_t n, int vd, float *d_beta, float *d_active_out,
                           void *stream);
+/*
+ * One Lanczos step with full re-orthogonalisation next to its MVM -- the variance cache of the reference's evaluation
+ * (gpytorch.settings.fast_pred_var + max_root_decomposition_size(lanc_iter), experiments/train_simplexgp.py:63-72; GPyTorch
+ * runs the recurrence with torch ops).  d_q: the basis, float [rows >= i + 2][ld] row-major, rows 0..i orthonormal; d_w:
+ * A q_i on entry ([n], overwritten: on return the re-orthogonalised, un-normalised vector).  Writes d_alphas[i] =
+ * q_i . A q_i, d_betas[i] = the norm of w after its components along rows i-1 and i (the alpha q_i and beta q_{i-1} terms
+ * of the three-term recurrence) and then, in one classical Gram-Schmidt pass, along all rows 0..i have been removed, and
+ * row i + 1 of d_q = w / max(beta_i, 1e-30).  Four launches, two streams of the basis, deterministic (fixed-order sums, no atomics).
+ * i + 1 <= plx_lanczos_max_rows() (256); d_work: float [plx_lanczos_work_floats(n)] (< 0: n is larger than the 2,097,152
+ * rows the step serves); ld >= n, a multiple of 4, d_q 16-byte aligned (columns n..ld-1 of the basis are never written).
+ */
+int plx_lanczos_max_rows(void);
+int64_t plx_lanczos_work_floats(int64_t n);
+int plx_lanczos_step(float *d_q, int64_t ld, float *d_w, int64_t n, int i, float *d_alphas, float *d_betas, float *d_work,
+                     void *stream);
 /* The two vector updates of a batched CG iteration, one pass each (row-major [n][vd], per-column scalars on the
  * device):  plx_cg_update: X += P*alpha, R -= AP*alpha, d_rs_new[c] = sum_r R[r][c]^2 (d_work as for plx_coldot);
  *           plx_cg_direction: P = R + P*beta. */

@@ -18,7 +18,7 @@ ARRAY_KEYS, ARRAY_ENTRY_VERTEX, ARRAY_ENTRY_WEIGHT, ARRAY_NEIGHBORS = 0, 1, 2, 3
 ARRAY_ROW_PTR, ARRAY_CSR_POINT, ARRAY_CSR_WEIGHT, ARRAY_POINT_PERM = 4, 5, 6, 7
 MAX_DIM, MAX_ORDER = 32, 8
 FACTOR_F32, FACTOR_F16 = 0, 1
-ABI_VERSION = (0, 7)      # (major, minor) of plx_version() the signatures below belong to
+ABI_VERSION = (0, 8)      # (major, minor) of plx_version() the signatures below belong to
 
 
 class PlxError(RuntimeError):
@@ -75,6 +75,9 @@ _SIGNATURES = {
     "plx_pcg_rz_partial_rows": (_i32, [_i64, _i32]),
     "plx_pcg_step_direction_fused": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp, _vp,
                                             _vp]),
+    "plx_lanczos_max_rows": (_i32, []),
+    "plx_lanczos_work_floats": (_i64, [_i64]),
+    "plx_lanczos_step": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "plx_cg_step_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "plx_cg_step_direction": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i32, _vp, _vp, _vp]),
     "plx_cg_update": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp]),

@@ -119,7 +119,7 @@ const char *plx_strerror(int code)
 const char *plx_last_error(void) { return g_err; }
 
 /* minor = the round that last extended the C ABI */
-const char *plx_version(void) { return "libplx 0.7.0 gfx950"; }
+const char *plx_version(void) { return "libplx 0.8.0 gfx950"; }
 
 int plx_create(int device, plx_lattice **out)
 {

@@ -95,18 +95,68 @@ def _lanczos_replayed(matmul, v0, steps, check_every, capture=True):
     return Qb[:t].t(), _tridiagonal(alphas, betas, t)
 
 
-def lanczos(matmul, v0, steps, check_every=8, graph=None):
+LANCZOS_NATIVE = True         # on a GPU in fp32: re-orthogonalisation, coefficients and the next basis vector as four launches
+#                               of libplx (plx_lanczos_step) instead of ~19 torch launches per step
+
+
+def _lanczos_native(matmul, v0, steps, check_every):
+    """The recurrence with everything but the MVM in plx_lanczos_step (csrc/plx_lanczos.hip): per step the operator's own
+    launches + 4.  The components along q_{i-1}, q_i first (the three-term recurrence), then one classical Gram-Schmidt
+    pass against the whole basis built so far -- the torch form's order, which is what keeps the pass stable;
+    deterministic.  None when the library does not serve this shape
+    (more than 256 steps or 2,097,152 rows)."""
+    import ctypes
+    from . import _native as nv
+    lib = nv.lib()
+    n, dev = v0.shape[0], v0.device
+    work_floats = int(lib.plx_lanczos_work_floats(n))
+    if steps > int(lib.plx_lanczos_max_rows()) or work_floats < 0:
+        return None
+    ld = (n + 63) // 64 * 64                                                 # rows of the basis start on 256-byte boundaries
+    Qb = torch.zeros(steps + 1, ld, dtype=torch.float32, device=dev)         # one spare row: the last step writes q_steps
+    alphas = torch.zeros(steps, dtype=torch.float32, device=dev)
+    betas = torch.zeros(steps, dtype=torch.float32, device=dev)
+    work = torch.empty(work_floats, dtype=torch.float32, device=dev)
+    Qb[0, :n] = v0 / v0.norm()
+    t = None
+    with torch.cuda.device(dev):
+        for i in range(steps):
+            w = matmul(Qb[i, :n].unsqueeze(-1)).reshape(n)
+            if not w.is_contiguous() or w.dtype != torch.float32 or w.data_ptr() == Qb[i].data_ptr():
+                w = w.to(torch.float32).contiguous().clone()                 # (the step overwrites w: never the basis row itself)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            nv.check(lib.plx_lanczos_step(ctypes.c_void_p(Qb.data_ptr()), ld, ctypes.c_void_p(w.data_ptr()), n, i,
+                                          ctypes.c_void_p(alphas.data_ptr()), ctypes.c_void_p(betas.data_ptr()),
+                                          ctypes.c_void_p(work.data_ptr()), stream), "plx_lanczos_step")
+            if (i + 1) % check_every == 0 and i + 1 < steps:
+                t = _first_breakdown(alphas, betas, i + 1)
+                if t is not None:
+                    break
+    if t is None and steps > 1:
+        t = _first_breakdown(alphas, betas, steps - 1)
+    t = steps if t is None else t
+    return Qb[:t, :n].t(), _tridiagonal(alphas, betas, t)
+
+
+def lanczos(matmul, v0, steps, check_every=8, graph=None, native=None):
     """`steps` Lanczos iterations with full re-orthogonalisation.
     Returns Q [n, t] (orthonormal) and the tridiagonal T [t, t] with Q^T A Q = T.
 
-    The basis lives in one preallocated [steps, n] buffer (stacking the vectors anew in every step copied O(steps^2 n) bytes)
-    and the breakdown test -- beta below 1e-6 |alpha_0|: the Krylov space is exhausted -- reads the device every
-    `check_every` steps instead of twice per step (a step is one MVM of ~80 us at the elevators size: the two host
-    synchronisations cost more than the step); vectors produced after a breakdown are discarded when it is found.
-    graph (default: LANCZOS_GRAPH): on a GPU the step is captured once into a HIP graph and replayed
-    (_lanczos_replayed); `matmul` must then be capturable -- no host read-backs, no allocations outside torch's pool:
-    the operators of this package are, once their lattice is built.  A refused capture falls back to the eager loop
-    (the reason is kept in _graph_refusals)."""
+    On a GPU in fp32 (native, default LANCZOS_NATIVE): everything around the MVM is plx_lanczos_step -- four launches per
+    step (_lanczos_native).  Otherwise torch ops: the basis lives in one preallocated [steps, n] buffer (stacking the
+    vectors anew in every step copied O(steps^2 n) bytes) and the breakdown test -- beta below 1e-6 |alpha_0|: the
+    Krylov space is exhausted -- reads the device every `check_every` steps instead of twice per step; vectors produced
+    after a breakdown are discarded when it is found.
+    graph (default LANCZOS_GRAPH; looked at when the native step is off or does not serve the shape): the torch step
+    captured once into a HIP graph and replayed (_lanczos_replayed); `matmul` must then be capturable -- no host
+    read-backs, no allocations outside torch's pool: the operators of this package are, once their lattice is built.  A
+    refused capture falls back to the eager loop (the reason is kept in _graph_refusals)."""
+    if native is None:
+        native = LANCZOS_NATIVE and graph is None                   # (an explicit graph=True / False asks for a torch form)
+    if native and v0.is_cuda and v0.dtype == torch.float32 and not torch.cuda.is_current_stream_capturing():
+        out = _lanczos_native(matmul, v0, steps, max(int(check_every), 32))
+        if out is not None:
+            return out
     graph = LANCZOS_GRAPH if graph is None else graph
     if graph and v0.is_cuda and (graph is True or (steps >= LANCZOS_GRAPH_MIN_STEPS and v0.shape[0] <= LANCZOS_GRAPH_MAX_ROWS)) \
             and not torch.cuda.is_current_stream_capturing():

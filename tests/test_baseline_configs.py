@@ -325,6 +325,43 @@ def test_evaluation_and_the_next_step_share_lattice_and_preconditioner(plx):
     assert model.preconditioner_reuses == reuse2 and cache.same_positions == same2
 
 
+@pytest.mark.parametrize("n,steps", [(3000, 40), (777, 256), (70_001, 48), (300_000, 33), (1_200_003, 24)])
+def test_lanczos_native_step_equals_the_torch_recurrence(plx, n, steps):
+    """plx_lanczos_step (four launches per step: two Gram-Schmidt passes, coefficients, next basis vector) against the
+    three-term torch loop, on a symmetric operator cheap enough for every row-span shape of the kernels (256 / 1024 /
+    4096 / 8192 rows per workgroup) and for the full 256 basis rows: the same T and leading basis vectors to fp32 Lanczos
+    accuracy, Q orthonormal, Q^T A Q = T, bit-identical when repeated; shapes the library does not serve take the torch form."""
+    from simplex_gp_amd import training
+    g = torch.Generator().manual_seed(n)
+    dvec = (1.0 + 3.0 * torch.rand(n, generator=g)).cuda()
+    U = (torch.randn(n, 3, generator=g) / n ** 0.5).cuda()
+    v0 = torch.randn(n, generator=g).cuda()
+
+    def mm(V):
+        return dvec[:, None] * V + U @ (U.T @ V)
+    Q0, T0 = training.lanczos(mm, v0, steps, graph=False)
+    Q1, T1 = training.lanczos(mm, v0, steps)
+    assert training.LANCZOS_NATIVE and Q1.shape == Q0.shape == (n, steps) and T1.shape == T0.shape
+    scale = float(T0.diagonal().abs().max())
+    k = min(steps, 12)
+    assert float((T1[:k, :k] - T0[:k, :k]).abs().max()) <= 1e-4 * scale
+    assert float((Q1[:, :6] - Q0[:, :6]).abs().max()) <= 1e-4
+    eye = torch.eye(steps, device="cuda")
+    assert float((Q1.T @ Q1 - eye).abs().max()) <= 1e-4
+    assert float((Q1.T @ mm(Q1.contiguous()) - T1).abs().max()) <= 2e-4 * scale
+    Q2, T2 = training.lanczos(mm, v0, steps)
+    assert torch.equal(T1, T2) and torch.equal(Q1, Q2)
+    if n == 3000:
+        # a Krylov space exhausted after 4 vectors: the same cut as the torch loop; more steps than the library's 256 rows:
+        # the torch form serves
+        low = lambda V: V + U @ (U.T @ V)                                      # noqa: E731
+        Qa, Ta = training.lanczos(low, v0, 40, graph=False)
+        Qb, Tb = training.lanczos(low, v0, 40)
+        assert Qa.shape == Qb.shape and Qb.shape[1] <= 5 and float((Ta - Tb).abs().max()) <= 1e-4
+        Qc, Tc = training.lanczos(mm, v0, 300)
+        assert Qc.shape[1] <= 300 and float((Tc[:8, :8] - T0[:8, :8]).abs().max()) <= 1e-4 * scale
+
+
 def test_lanczos_replayed_graph_equals_the_eager_loop(plx):
     """training.lanczos on the GPU replays ONE captured step (HIP graph, step index on the device) on the operator in
     lattice row order: the same tridiagonal and basis as the eager three-term loop on the caller-order operator, to fp32
@@ -360,7 +397,7 @@ def test_lanczos_replayed_graph_equals_the_eager_loop(plx):
             out = mm(V)
             calls.append(float(out[0, 0]))                                         # a host read-back: not capturable
             return out
-        Q2, T2 = training.lanczos(reads_back, r, steps)
+        Q2, T2 = training.lanczos(reads_back, r, steps, native=False)
         assert len(training._graph_refusals) == 1 and T2.shape == T0.shape
         assert float((T2 - T0).abs().max()) <= 2e-3 * scale
         Q3, T3 = training.lanczos(mm, r, steps, graph=True)
