@@ -15,7 +15,6 @@ every filter call (permutohedral.h:272).
 """
 from collections import OrderedDict
 
-import numpy as np
 import torch
 from torch.autograd import Function
 

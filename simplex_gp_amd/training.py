@@ -10,8 +10,6 @@ against simplex_gp_amd.solvers so that it runs where GPyTorch is absent.
     fit         Adam on the CG/SLQ marginal likelihood with validation-RMSE early
                 stopping and a best-state checkpoint (train_simplexgp.py:117-165)
 """
-import math
-
 import torch
 
 from .solvers import LatticeGP, marginal_log_likelihood
@@ -45,9 +43,11 @@ def _first_breakdown(alphas, betas, upto):
 
 def _lanczos_replayed(matmul, v0, steps, check_every, capture=True):
     """The Lanczos recurrence as ONE captured HIP graph replayed once per step.  At the sizes where the variance cache
-    matters (N ~ 1e4: the reference's UCI sets) a step is ~25 launches of a few microseconds of work each, and the
-    loop is bound by launch gaps and interpreter time (100 steps at N = 10,623, d = 18: 16-27 ms, of which the MVMs'
-    kernels are ~3); the guide's prescription for a launch-bound inner loop is a graph.  For the graph to be the
+    matters (N ~ 1e4: the reference's UCI sets) a step of the torch-op recurrence is ~40 launches of a few microseconds of
+    work each (100 steps at N = 10,623, d = 18: 16-27 ms through the caller-order operator); the guide's prescription for a
+    launch-bound inner loop is a graph.  Measured (profiles/r06_measured.md section 8): the replay is as fast as the eager
+    loop when the DEVICE is the bound (3.6 us per dependent launch either way) and 4x faster when the host is; the
+    default on a GPU is the native step (_lanczos_native: fewer launches), this form serves operators in other dtypes.  For the graph to be the
     same in every step, the step index lives on the device: row `idx` of the basis is read with index_select, row
     idx + 1 written with index_copy_, and the projection runs over ALL rows of the basis buffer (rows not yet written are
     zero and contribute nothing) -- two classical Gram-Schmidt passes (which include the alpha q_i and beta q_{i-1}

@@ -114,3 +114,36 @@ def test_fit_improves_validation_rmse(cpu_method, tmp_path):
     assert history[-1]["train/mll"] > history[0]["train/mll"]
     state = torch.load(str(ckpt))
     assert set(state) == set(model.state_dict())
+
+
+def test_fit_evaluates_both_splits_from_one_cache(cpu_method, monkeypatch):
+    """The loop's evaluation (train_simplexgp.py:123-165: validation, then test, after every step) solves and runs Lanczos
+    ONCE per evaluated epoch -- GPyTorch's eval mode keeps its mean / variance caches between the reference's two test()
+    calls -- and both splits' metrics are those of predict() called split by split."""
+    torch.manual_seed(1)
+    n = 80
+    x = torch.randn(n, 2)
+    y = torch.sin(2 * x[:, 0]) + 0.1 * torch.randn(n)
+    tr, va, te = slice(0, 50), slice(50, 65), slice(65, 80)
+    model = solvers.LatticeGP(plx.RBFLattice(order=1), min_noise=1e-2)
+    made = []
+    real = training.PredictionCache
+
+    class Counting(real):
+        def __init__(self, *a, **k):
+            made.append(1)
+            super().__init__(*a, **k)
+    monkeypatch.setattr(training, "PredictionCache", Counting)
+    hist, best = training.fit(model, (x[tr], y[tr]), val=(x[va], y[va]), test=(x[te], y[te]), epochs=3, lr=0.05, num_probes=4,
+                              cg_tol=1e-4, cg_eval_tol=1e-6, lanc_iter=50, pre_size=0)
+    assert len(made) == 3 and len(hist) == 3 and {"val/rmse", "val/nll", "test/rmse", "test/mae"} <= set(hist[-1])
+    monkeypatch.setattr(training, "PredictionCache", real)
+    want_v = training.evaluate(model, x[tr], y[tr], x[va], y[va], label="val", cg_tol=1e-6, lanc_iter=50, pre_size=0)
+    want_t = training.evaluate(model, x[tr], y[tr], x[te], y[te], label="test", cg_tol=1e-6, lanc_iter=50, pre_size=0)
+    for k, v in {**want_v, **want_t}.items():
+        assert abs(hist[-1][k] - v) <= 1e-5 * max(1.0, abs(v)), k
+    # a cache handed to predict() is used as it is
+    cache = real(model, x[tr], y[tr], cg_tol=1e-6, lanc_iter=50, pre_size=0)
+    m1, v1 = training.predict(model, x[tr], y[tr], x[va], cache=cache)
+    m2, v2 = training.predict(model, x[tr], y[tr], x[va], cg_tol=1e-6, lanc_iter=50, pre_size=0)
+    assert torch.allclose(m1, m2, atol=1e-6) and torch.allclose(v1, v2, atol=1e-6)
