@@ -540,6 +540,28 @@ def config3_leg(ctx, n=1_000_000, d=8, iters=50):
                   "what": "solvers.LatticePreconditioner on the built lattice: kernel rows (plx_filter_onehot), batches "
                           "(plx_pchol_*), fp16 rounding, Gram matrix and its host Cholesky"}
         del pre, p2
+    # the evaluation the loop runs beside the step (train_simplexgp.py:123-165) at this size: one training.predict with the
+    # recipe's settings (cg_eval_tol 1e-2, 100 Lanczos steps, rank-100 preconditioner) on n / 4 held-out rows (the
+    # reference's 64 / 16 / 20 split: validation = train / 4), and its cache (solve + Lanczos run) by itself
+    from simplex_gp_amd import training
+    gs = torch.Generator().manual_seed(4321)
+    xs = torch.randn(n // 4, d, generator=gs).to(ctx.dev)
+    model.kernel.lengthscale = 0.6931
+    ys = torch.sin(x[:, 0]) + 0.1 * y
+    training.predict(model, x, ys, xs, cg_tol=1e-2, lanc_iter=100, pre_size=100)
+    ctx.sync()
+    t0 = time.perf_counter()
+    cache = training.PredictionCache(model, x, ys, cg_tol=1e-2, lanc_iter=100, pre_size=100)
+    ctx.sync()
+    t1 = time.perf_counter()
+    cache.predict(xs)
+    ctx.sync()
+    evaluation = {"cache_ms": round((t1 - t0) * 1e3, 2), "split_ms": round((time.perf_counter() - t1) * 1e3, 2),
+                  "cg_iterations": int(cache.solve_info.get("iterations", -1)), "held_out_rows": n // 4,
+                  "what": "training.PredictionCache (rank-100 factor on the lattice already built + preconditioned CG to 1e-2 + 100 "
+                          "Lanczos steps through plx_lanczos_step) and one split's mean + variance through the rectangular "
+                          "operator (101 columns); the loop pays the cache once and the split twice per epoch"}
+    del cache, xs, ys
     plx.lattice_cache().clear()
     del x, y, Z, rhs
     train = train_step_leg(ctx, n, d, lambda: plx.RBFLattice(order=1, ard_num_dims=d))
@@ -549,6 +571,7 @@ def config3_leg(ctx, n=1_000_000, d=8, iters=50):
         "ms_incl_warm_rebuild": round(best_rebuild * 1e3, 2),       # the lattice of a moved lengthscale, point order kept
         "m_vertices": m,
         "cg_iterations_per_s": round(iters / best_warm, 1), "final_rel_residual_max": res, "factor": factor,
+        "evaluation": evaluation,
         "launches_per_cg_iteration": None,         # filled in by main() as the very last measurement (cg_launch_leg)
         "train_step_ms": {k: v["step_ms"] for k, v in train.items() if k.startswith("pre_size")}, "train_step": train}}
 
