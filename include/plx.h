@@ -423,8 +423,10 @@ int64_t plx_export_bytes(const plx_lattice *lat, int which);
  *   d+1 corner planes of a run of points are adjacent workgroups of the hashed insert / neighbour lookups; 0 =
  *   plane-major launch order), "nbr_symmetric" (1), "compact_nbr" (1 = when under a quarter of the neighbour slots exist;
  *   0 never, 2 always), "blur_vpt" (4; vertices per thread at vd = 1: 2 or 4, anything else selects the general kernel),
- *   "blur_small" (1), "blur_narrow" (1), "blur_multi" (1), "blur_fuse" (1), "blur_fuse_vec" (1 = two blur axes per launch
- *   for rows of 2..4 chunks; 0 = one), "splat_direct" (1), "splat_group" (1), "splat_wide" (1), "xcd_remap" (1),
+ *   "blur_small" (1), "blur_narrow" (1), "blur_multi" (1 = the wide-row blur kernels from 17 chunks per row; 2 = from 32, the
+ *   gate of rounds 1-5), "blur_fuse" (1), "blur_fuse_vec" (1 = two blur axes per launch
+ *   for rows of 2..4 chunks; 0 = one), "splat_direct" (1), "splat_group" (1), "splat_wide" (1 = the row-parallel splat from 17 chunks per
+ *   row; 2 = from 32), "xcd_remap" (1),
  *   "block_path" (1 = block tables for vd = 1 when corners share vertices; 0 never, 2 whenever representable),
  *   "block_e" (0 = corners per thread of the block kernels chosen per lattice; 16 or 24: a block holds 256 * e corners),
  *   "block_dense_combine" (1), "scatter_store" (0), "unpermute_gather" (1), "nbr_window" (512: on Morton-numbered lattices a neighbour lookup first binary-searches this

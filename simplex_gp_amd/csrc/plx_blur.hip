@@ -764,7 +764,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
     if (pair_vec) PLX_TRY(ensure_blur_pairs(L, stream));
     // wide rows on a sparse lattice whose centre tap is 1: only the rows that change, in place (see blur_active_rows_kernel)
     bool active = false;
-    if (!nocentre && g_blur_active != 0 && g_blur_multi && order >= 1 && order <= 3 && vd > 1 && vdp / 4 >= 32 && vdp / 4 <= 128 &&
+    if (!nocentre && g_blur_active != 0 && g_blur_multi && order >= 1 && order <= 3 && vd > 1 && vdp / 4 >= (g_blur_multi >= 2 ? 32 : 17) && vdp / 4 <= 128 &&
         L->taps.c[order] == 1.0f && m > 0) {
         // (cheap gate before the lists exist: the lattices in question have nearly as many vertices as corners)
         if (g_blur_active == 2 || (double)m >= 0.75 * (double)L->n * d1) {
@@ -843,7 +843,7 @@ int blur_impl(plx_lattice *L, float *d_values, float *d_scratch, int vd, int *re
             default: launch_blur_narrow<3>(c4, n4, nb, m, L->mstride, vdp / 4, L->taps, stream, g_xcd_remap); break;
             }
             L->kn_blur = "blur_axis_narrow_kernel";
-        } else if (order >= 1 && order <= 3 && g_blur_multi && vdp / 4 >= 32) {   // narrower rows: no gain (vd 2..16 measured 0-30 % slower)
+        } else if (order >= 1 && order <= 3 && g_blur_multi && vdp / 4 >= (g_blur_multi >= 2 ? 32 : 17)) {   // narrower rows: no gain (vd 2..16 measured 0-30 % slower); 17..31 chunks: 5-8 % faster than the general kernel (round 6; blur_multi = 2: the 32-chunk gate of rounds 1-5)
             constexpr int IPT = 4;
             const int rowlen = vdp / 4;
             const int nt = ceil_div((int64_t)m * rowlen, kBlock * IPT);

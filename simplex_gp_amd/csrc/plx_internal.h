@@ -61,9 +61,9 @@ struct Tune {
     int xcd_remap = 1;   // workgroup b works on tile (b % 8) * ceil(nb/8) + b / 8: every XCD owns one contiguous slice of the lattice
     int splat_direct = 1;   // vd = 1 CSR splat gathers from d_src through caller-row indices: 0 never, 1 for <= 2e6 corners, 2 always
     int blur_narrow = 1;   // vd 2..16 blur: row length compiled in, branch-free
-    int blur_multi = 1;   // vd > 1 blur: 4 items per thread on rows of >= 32 chunks
+    int blur_multi = 1;   // vd > 1 blur: 4 items per thread (and, on sparse lattices, only the rows that change) on rows of >= 17 chunks; 2: >= 32 (rounds 1-5)
     int splat_group = 1;   // vd 2..64: lane-group streaming splat
-    int splat_wide = 1;   // row-parallel splat for rows of 32..128 chunks
+    int splat_wide = 1;   // row-parallel splat for rows of 17..128 chunks; 2: 32..128 (rounds 1-5)
     int blur_fuse = 1;   // two blur axes per launch (vd = 1): 0 never, 1 on cache-resident lattices, 2 always
     int blur_fuse_vec = 1;   // two blur axes per launch for rows of 2..4 chunks
     int block_path = 1;   // 0 never, 1 when the lattice qualifies (see build_blocks), 2 whenever representable

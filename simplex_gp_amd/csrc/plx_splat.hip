@@ -1,4 +1,4 @@
-// plx_splat.hip -- gather-in and the splat kernels of the per-MVM path: segmented scan (1 chunk), lane groups (2..16 chunks), corner-streaming wide rows (>= 32 chunks, also the stacked source of the fused position gradient).  Reference: h:478-479.
+// plx_splat.hip -- gather-in and the splat kernels of the per-MVM path: segmented scan (1 chunk), lane groups (2..16 chunks), corner-streaming wide rows (>= 17 chunks, also the stacked source of the fused position gradient).  Reference: h:478-479.
 // Overview of the per-MVM path, value-row layout and shared helpers: plx_kernels.h.
 
 #include "plx_kernels.h"
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kSplatBlock) void splat_scan_kernel(const int *__re
 }
 
 // ----------------------------------------------------------------------------
-// splat for WIDE rows (nch >= 32 chunks, i.e. vd >= 125: the backward pass, py:113-119).  The scan kernel tiles the
+// splat for WIDE rows (nch >= 17 chunks, i.e. vd >= 65: the backward pass, py:113-119, and the evaluation's 101 columns).  The scan kernel tiles the
 // columns, so with 50 chunks it would touch every gathered source row 17-25 times, 32-48 bytes at a time.  Here the
 // lanes of a wave own the 16-byte chunks of the value row and the wave walks a range of corners: every gathered
 // source row is read once, contiguously (splat_wide_kernel below).
@@ -646,7 +646,10 @@ int splat_impl(plx_lattice *L, const float *d_src, int vd, float *d_values, hipS
     } else {
         const float4 *s4 = reinterpret_cast<const float4 *>(ss);
         float4 *v4 = reinterpret_cast<float4 *>(d_values), *h4 = reinterpret_cast<float4 *>(hp), *t4 = reinterpret_cast<float4 *>(tp);
-        if (nch_total >= 32 && nch_total <= 128 && g_splat_wide) {   // measured: 16 chunks 8 % slower, 50 chunks 1.8x faster
+        // measured: 16 chunks 8 % slower than the group kernel, 50 chunks 1.8x faster than column tiles; 17..31 chunks (round 6,
+        // tools/ab_splat_mid_r6.py: the evaluation's 101 columns; 6-26 of the wave's lanes idle): the MVM 6.91 -> 5.28 ms at
+        // m = 1.9e6 against 9-13 column tiles through splat_scan_kernel.  splat_wide = 2: the gate of rounds 1-5 (32 chunks)
+        if (nch_total >= (g_splat_wide >= 2 ? 32 : 17) && nch_total <= 128 && g_splat_wide) {
             const int nwide = ceil_div(nnz, kWideChunk), nt = ceil_div(nwide, kBlock / 64);
             PLX_TRY(ensure(L->head_partial, (size_t)nwide * vdp * 4));
             PLX_TRY(ensure(L->tail_partial, (size_t)nwide * vdp * 4));

@@ -304,9 +304,21 @@ class RectangularLazyLattice(LazyTensor):
     def _matmul(self, V):
         n_out, n_in = self.xout.shape[-2], self.xin.shape[-2]
         assert V.shape[-2] == n_out, f"mismatched shapes? {V.shape, self.xout.shape}"
-        stacked_points = torch.cat((self.xout, self.xin), dim=-2)
         stacked_rhs = torch.nn.functional.pad(V, (0, 0, 0, n_in))          # zero rows for the points of xin
-        return _lattice_matvec(stacked_rhs, stacked_points, self.dkernel)[..., n_out:, :]
+        return _lattice_matvec(stacked_rhs, self._stacked_points(), self.dkernel)[..., n_out:, :]
+
+    def _stacked_points(self):
+        """[xout; xin].  Without a gradient to carry, the stacked tensor is made once per operator (and per state of its
+        two inputs): a fresh concatenation on every product is a fresh lattice-cache key, i.e. one lattice build per product
+        (measured, N = 1e6 + 2.5e5 points: 1.5 of the 9.8 ms of every K(x*, x) @ V on the same operator)."""
+        if torch.is_grad_enabled() and (self.xin.requires_grad or self.xout.requires_grad):
+            return torch.cat((self.xout, self.xin), dim=-2)
+        key = (self.xin._version, self.xout._version)
+        hit = self.__dict__.get("_stacked")
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat((self.xout.detach(), self.xin.detach()), dim=-2))
+            self.__dict__["_stacked"] = hit
+        return hit[1]
 
     def _transpose_nonbatch(self):
         return type(self)(self.xout, self.xin, self.dkernel)

@@ -77,7 +77,10 @@ def test_kernel_matmul_and_lattice_reuse(plx):
     xs_test = torch.randn(700, 3, device="cuda")
     with torch.no_grad():
         R = k(xs_test, x)
+        m1 = cache.misses
         got = R.matmul(V)
+        again = R.matmul(V)
+    assert cache.misses == m1 + 1 and torch.equal(got, again)         # the stacked points are made once per operator: one build
     ell = k.lengthscale.detach()
     big_x = torch.cat([x / ell, xs_test / ell]).cpu().numpy()
     big_v = np.concatenate([V.cpu().numpy(), np.zeros((700, 4), np.float32)])
@@ -718,13 +721,14 @@ def test_cg_iteration_without_standalone_reductions(plx, t):
 
 
 @pytest.mark.parametrize("n,d,ell,order,vd", [(3000, 18, 1.0, 3, 418), (3000, 18, 1.0, 1, 130), (20000, 8, 0.2, 1, 198),
-                                              (20000, 8, 0.2, 2, 256), (5000, 12, 0.5, 3, 500), (40000, 4, 0.05, 1, 126)])
+                                              (20000, 8, 0.2, 2, 256), (5000, 12, 0.5, 3, 500), (40000, 4, 0.05, 1, 126),
+                                              (3000, 18, 1.0, 3, 101), (20000, 8, 0.2, 1, 68), (5000, 12, 0.5, 2, 124)])
 def test_wide_blur_on_active_rows_equals_the_dense_passes(plx, n, d, ell, order, vd):
     """Wide rows on sparse lattices (round 6): a blur pass that touches only the vertices with a neighbour on its axis, in place
     (blur_active_rows_kernel + blur_active_store_kernel; the centre tap of every kernel profile is exactly 1, so the other rows
     do not change), gives what the dense passes give -- the same operations in the same order for the rows that change, the
     untouched rows as they were -- on lattices where every point has a simplex of its own and on partly shared ones, orders
-    1-3, one and two chunks per lane.  Also: the lists are rebuilt with the lattice, a centre tap other than 1 keeps the
+    1-3, one and two chunks per lane, rows of 17-31 chunks (lanes idle: the evaluation's 101 columns).  Also: the lists are rebuilt with the lattice, a centre tap other than 1 keeps the
     dense passes, and the whole filter (splat, blur, slice) agrees with the oracle."""
     from simplex_gp_amd import _native as nv
     lib = nv.lib()

@@ -518,7 +518,7 @@ def test_wide_right_hand_sides(plx):
     ref = rng.standard_normal((n, d)).astype(np.float32)
     taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
     lat = plx.Lattice().build(torch.from_numpy(ref).cuda(), taps)
-    for vd in (2, 5, 12, 13, 30, 110, 128, 198, 300):      # >= 125 columns take the row-parallel splat
+    for vd in (2, 5, 12, 13, 30, 64, 65, 68, 101, 110, 124, 128, 198, 300):      # >= 65 columns (17 chunks) take the row-parallel splat
         src = rng.standard_normal((n, vd)).astype(np.float32)
         out = lat.apply(torch.from_numpy(src).cuda()).cpu().numpy()
         assert out.shape == (n, vd)
@@ -590,11 +590,11 @@ def test_compacted_neighbour_table_equals_dense(plx, order):
         nv.check(lib.plx_tune(b"compact_nbr", 1), "plx_tune")
 
 
-@pytest.mark.parametrize("vd", [1, 3, 7, 12, 40, 130])
+@pytest.mark.parametrize("vd", [1, 3, 7, 12, 40, 70, 101, 130])
 def test_long_vertex_rows_every_splat_kernel(plx, vd):
     """Clouds whose points share a handful of simplices: every vertex row is hundreds to thousands of corners long,
     so rows span many lane-group runs, waves and workgroups (in-wave segmented scan + head / tail partials + fix-up)
-    in each of the splat kernels (scan: vd 1-4, lane groups: 5-64, wide: >= 125)."""
+    in each of the splat kernels (scan: vd 1-4, lane groups: 5-64, wide: >= 65 -- with idle lanes up to 124)."""
     rng = np.random.default_rng(200 + vd)
     taps = np.array([0.34608543, 1.0, 0.34608543], np.float32)
     cases = []
@@ -625,7 +625,7 @@ def test_every_tap_order_at_every_row_width(plx, ntaps):
     ref = (rng.standard_normal((n, d)) * 2.0).astype(np.float32)
     oracle.set_exact_mode(False)
     try:
-        for vd in (1, 3, 7, 17, 40, 110, 130):
+        for vd in (1, 3, 7, 17, 40, 66, 110, 130):
             src = rng.standard_normal((n, vd)).astype(np.float32)
             want = oracle.filter(src, ref, taps)
             got = plx.filter(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), torch.from_numpy(taps)).cpu().numpy()
