@@ -40,14 +40,34 @@ def position_hint(scaled, source, scale_of=None):
     holding the same VALUES mark bit-identical positions: the cache then serves the lattice it has instead of rebuilding it
     (an evaluation followed by the next training step: the same hyper-parameters twice).  The values are compared on the
     device (d floats and one read-back, only when identity and version counter already agree): the version counter alone
-    cannot vouch for them -- torch.optim.Adam(fused=True) writes parameters without moving it (measured on this image)."""
+    cannot vouch for them -- torch.optim.Adam(fused=True) writes parameters without moving it (measured on this image).
+    The hint: ((weak reference, version, shape) per source tensor, scale key); stack_hint() joins the hints of stacked parts."""
     import weakref
     try:
         scale_key = None if scale_of is None else (weakref.ref(scale_of), scale_of._version)
-        scaled._plx_positions_of = (weakref.ref(source), source._version, tuple(source.shape), scale_key)
+        scaled._plx_positions_of = (((weakref.ref(source), source._version, tuple(source.shape)),), scale_key)
     except (AttributeError, TypeError):
         pass
     return scaled
+
+
+def stack_hint(stacked, parts):
+    """`stacked` is the concatenation of `parts` (the rectangular operator's [xout; xin], py:150-156): if every part says
+    which data tensor it was scaled from, and by the same scale, the stack says so for all of them -- the stacked lattice of
+    the SAME two data tensors under a moved lengthscale (the validation split, epoch after epoch) is then rebuilt in place
+    with its point order kept instead of piling up in the cache as a new lattice per epoch."""
+    hints = [getattr(p, "_plx_positions_of", None) for p in parts]
+    if any(h is None for h in hints):
+        return stacked
+    scale = hints[0][1]
+    for h in hints[1:]:
+        if (h[1] is None) != (scale is None) or (scale is not None and (h[1][0]() is not scale[0]() or h[1][1] != scale[1])):
+            return stacked
+    try:
+        stacked._plx_positions_of = (tuple(src for h in hints for src in h[0]), scale)
+    except (AttributeError, TypeError):
+        pass
+    return stacked
 
 
 def carry_hint(dst, src):
@@ -62,22 +82,26 @@ def carry_hint(dst, src):
 
 
 def _same_hint(a, b):
-    if a is None or b is None:
+    """Both hints name the same live data tensors, in the same states, and none has been written since."""
+    if a is None or b is None or len(a[0]) != len(b[0]):
         return False
-    src = a[0]()
-    return src is not None and src is b[0]() and a[1] == b[1] and a[2] == b[2] and src._version == a[1]
+    for (ra, va, sa), (rb, vb, sb) in zip(a[0], b[0]):
+        src = ra()
+        if src is None or src is not rb() or va != vb or sa != sb or src._version != va:
+            return False
+    return True
 
 
 def _scale_tensor(hint):
     """The live parameter a hint's scale comes from, or None."""
-    k = hint[3] if hint is not None and len(hint) > 3 else None
+    k = hint[1] if hint is not None else None
     return None if k is None else k[0]()
 
 
 def _same_scale(a, b, snapshot):
     """Both hints name the same live scale parameter, its version counter has not moved since either was made, and it
     still holds the values `snapshot` (taken when the lattice was built) -- the last by comparison on the device."""
-    ka, kb = a[3] if len(a) > 3 else None, b[3] if len(b) > 3 else None
+    ka, kb = a[1], b[1]
     if ka is None or kb is None or snapshot is None:
         return False
     p = ka[0]()
@@ -316,7 +340,7 @@ class RectangularLazyLattice(LazyTensor):
         key = (self.xin._version, self.xout._version)
         hit = self.__dict__.get("_stacked")
         if hit is None or hit[0] != key:
-            hit = (key, torch.cat((self.xout.detach(), self.xin.detach()), dim=-2))
+            hit = (key, stack_hint(torch.cat((self.xout.detach(), self.xin.detach()), dim=-2), (self.xout, self.xin)))
             self.__dict__["_stacked"] = hit
         return hit[1]
 
@@ -351,7 +375,8 @@ class LatticeAccelerated(Kernel):
         scaled1 = position_hint(x1.div(self.lengthscale), x1, scale_of=getattr(self, "raw_lengthscale", None))
         if self._same_points(x1, x2):
             return SquareLazyLattice(scaled1, self.dkernel_fn)
-        return RectangularLazyLattice(scaled1, x2.div(self.lengthscale), self.dkernel_fn)
+        scaled2 = position_hint(x2.div(self.lengthscale), x2, scale_of=getattr(self, "raw_lengthscale", None))
+        return RectangularLazyLattice(scaled1, scaled2, self.dkernel_fn)
 
 
 def _lattice_kernel_factory(profile, default_order):

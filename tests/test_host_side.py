@@ -273,7 +273,7 @@ def test_lattice_cache_rebuilds_the_same_data_in_place_with_the_order_kept(monke
     # the kernel's forward tags its scaled positions with the data they came from
     k = plx.RBFLattice(order=1)
     op = k(y, y)
-    src, ver, shape, scale = op.x._plx_positions_of
+    ((src, ver, shape),), scale = op.x._plx_positions_of
     assert src() is y and ver == y._version and shape == tuple(y.shape)
     assert scale[0]() is k.raw_lengthscale and scale[1] == k.raw_lengthscale._version
     # ... and with the state of the parameter their scale comes from: the same data under the SAME lengthscale, as a new
@@ -287,3 +287,17 @@ def test_lattice_cache_rebuilds_the_same_data_in_place_with_the_order_kept(monke
     assert cache.get(k(y, y).x, taps) is lat and lat.builds == [False, True] and cache.same_positions == 1
     k2 = plx.RBFLattice(order=1)                                                                 # another kernel's lengthscale, equal
     assert cache.get(k2(y, y).x, taps) is lat and lat.builds == [False, True, True]               # or not: not the same state
+    # the rectangular operator's stacked positions [xout; xin] carry both sources: the same two data tensors again (the
+    # validation split, epoch after epoch) find their stacked lattice -- as it is under the same lengthscale, rebuilt in place
+    # with the order kept under a moved one -- instead of piling up; another split is another lattice
+    cache.clear()
+    ys, yt = torch.randn(5, 2), torch.randn(6, 2)
+    with torch.no_grad():
+        R = k(ys, y)
+        st = R._stacked_points()
+        assert R._stacked_points() is st and len(st._plx_positions_of[0]) == 2 and st.shape == (13, 2)
+        latr = cache.get(st, taps)
+        assert cache.get(k(ys, y)._stacked_points(), taps) is latr and latr.builds == [False] and len(cache._entries) == 1
+        k.raw_lengthscale.add_(0.05)
+        assert cache.get(k(ys, y)._stacked_points(), taps) is latr and latr.builds == [False, True] and len(cache._entries) == 1
+        assert cache.get(k(yt, y)._stacked_points(), taps) is not latr and len(cache._entries) == 2
