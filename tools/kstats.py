@@ -4,7 +4,7 @@ import csv, glob, os, sys
 d = sys.argv[1]
 rows_n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 filt = sys.argv[3] if len(sys.argv) > 3 else ""
-path = sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True))[-1]
+path = max(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)     # the newest run of the directory
 rows = list(csv.DictReader(open(path)))
 total = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"{path}: {len(rows)} kernels, {total / 1e6:.2f} ms of kernel time")
