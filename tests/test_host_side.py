@@ -182,6 +182,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.plx_num_vertices(None) == -1
     assert lib.plx_tune(b"no_such_key", 1) == 1 and b"no_such_key" in lib.plx_last_error()
     assert lib.plx_lattice_tune(None, b"xcd_remap", 1) == 1
+    # the Lanczos step: its shape limits, and the argument checks that come before any launch
+    assert lib.plx_lanczos_max_rows() == 256
+    assert lib.plx_lanczos_work_floats(10_623) > 0 and lib.plx_lanczos_work_floats(2_097_152) > 0
+    assert lib.plx_lanczos_work_floats(2_097_153) == -1 and lib.plx_lanczos_work_floats(0) == -1
+    assert lib.plx_lanczos_step(None, 64, None, 64, 0, None, None, None, None) == 1 and b"NULL" in lib.plx_last_error()
+    buf = (ctypes.c_float * 1024)()                                          # host memory: never reached by a launch below
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.plx_lanczos_step(p, 62, p, 62, 0, p, p, p, None) == 1 and b"multiple of 4" in lib.plx_last_error()
+    assert lib.plx_lanczos_step(p, 64, p, 100, 0, p, p, p, None) == 1      # ld < n
+    assert lib.plx_lanczos_step(p, 64, p, 64, 256, p, p, p, None) == 1     # more basis vectors than a step projects on
     # the diagnostic ablations are not part of the shipped library (libplx_diag.so only)
     if not os.environ.get("PLX_LIBRARY"):
         for key in (b"splat_ablate", b"blur_ablate", b"block_ablate"):
